@@ -1,0 +1,479 @@
+// fp32 MFMA GEMM and implicit-GEMM stride-2 convolutions for gfx950.
+//
+// One LDS-tiled main loop (v_mfma_f32_32x32x2_f32, exact fp32) is shared by
+//   * dd_gemm_f32            C = alpha*op(A)*op(B) + beta*C + bias
+//   * dd_conv2d_s2_down      stride-2 VALID conv (encoder fwd, decoder bwd-data)
+//   * dd_conv2d_s2_up        its transpose (decoder fwd, encoder bwd-data)
+//   * dd_conv2d_s2_wgrad     filter gradient of both
+// through pluggable tile loaders, so convolutions never materialise im2col
+// (reference ops: tf.nn.conv2d nets.py:547, tf.nn.conv2d_transpose nets.py:539,
+// `x @ kernel` nets.py:573 and their gradients via GradientTape tfutils.py:214).
+//
+// Tile: BMxBNx16, 256 threads = 4 waves in 2x2, each wave (BM/2)x(BN/2) as
+// 32x32 MFMA tiles.  LDS tiles are k-major ([16][B+4]) so the per-lane
+// operand fetch for the 32x32x2 MFMA (lane l -> row l&31, k l>>5) is a
+// conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
+// Global->register->LDS double buffering, one barrier per k-tile.
+// Split-K (deterministic: slabs in a caller workspace + a reduce pass) gives
+// small-M / huge-K problems enough workgroups to cover 256 CUs.
+#include "dd_common.h"
+#include "../../include/daydreamer_hip.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+// ---------------------------------------------------------------------------
+// Operand loaders.  load4(r, k, kend, v) returns four consecutive elements
+// along the operand's contiguous axis: KC = (r, k..k+3), RC = (r..r+3, k).
+// ---------------------------------------------------------------------------
+
+struct MatKC {  // op(X)[r][k] = p[r*ld + k]
+  const float* p; long ld; int R; int vec;
+  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if (r < R) {
+      const float* q = p + (long)r * ld + k;
+      if (vec && k + 3 < kend) {
+        float4 t = *reinterpret_cast<const float4*>(q);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (k + j < kend) ? q[j] : 0.f;
+      }
+    } else {
+      v[0] = v[1] = v[2] = v[3] = 0.f;
+    }
+  }
+};
+
+struct MatRC {  // op(X)[r][k] = p[k*ld + r]
+  const float* p; long ld; int R; int vec;
+  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if (k < kend) {
+      const float* q = p + (long)k * ld + r;
+      if (vec && r + 3 < R) {
+        float4 t = *reinterpret_cast<const float4*>(q);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (r + j < R) ? q[j] : 0.f;
+      }
+    } else {
+      v[0] = v[1] = v[2] = v[3] = 0.f;
+    }
+  }
+};
+
+__device__ __forceinline__ float cvt(float x, float) { return x; }
+__device__ __forceinline__ float cvt(unsigned char x, float s) { return (float)x * s; }
+
+// conv "down": rows = output pixels (n,sy,sx), k = (ky, kx*Cb + cb).
+template <typename T>
+struct ConvDownA {
+  const T* big; int npix, hs, ws, hb, wb, Cb, kwc; float scale; int vec;
+  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if (r >= npix) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
+    int n = r / (hs * ws); int rem = r - n * hs * ws;
+    int sy = rem / ws; int sx = rem - sy * ws;
+    long base = (((long)n * hb + 2 * sy) * wb + 2 * sx) * Cb;
+    long rowpitch = (long)wb * Cb;
+    if (vec && k + 3 < kend) {
+      int ky = k / kwc; int o = k - ky * kwc;
+      const float* q = reinterpret_cast<const float*>(big) + base + ky * rowpitch + o;
+      float4 t = *reinterpret_cast<const float4*>(q);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int kk = k + j;
+        if (kk < kend) {
+          int ky = kk / kwc; int o = kk - ky * kwc;
+          v[j] = cvt(big[base + ky * rowpitch + o], scale);
+        } else {
+          v[j] = 0.f;
+        }
+      }
+    }
+  }
+};
+
+// conv "up", one output-parity class: rows = class pixels (n,j,i), output
+// pixel (2j+py, 2i+px); k = (tap=(m,mx), cs) with source pixel (j-m, i-mx).
+struct ConvUpA {
+  const float* small; int npix, nj, ni, hs, ws, Cs, nkx; int vec;
+  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (r >= npix || k >= kend) return;
+    int n = r / (nj * ni); int rem = r - n * nj * ni;
+    int j = rem / ni; int i = rem - j * ni;
+    if (vec) {
+      int tap = k / Cs; int c = k - tap * Cs;
+      int m = tap / nkx; int mx = tap - m * nkx;
+      int sy = j - m, sx = i - mx;
+      if (sy < 0 || sy >= hs || sx < 0 || sx >= ws) return;
+      const float* q = small + (((long)n * hs + sy) * ws + sx) * Cs + c;
+      float4 t = *reinterpret_cast<const float4*>(q);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int kk = k + e;
+        if (kk >= kend) continue;
+        int tap = kk / Cs; int c = kk - tap * Cs;
+        int m = tap / nkx; int mx = tap - m * nkx;
+        int sy = j - m, sx = i - mx;
+        if (sy < 0 || sy >= hs || sx < 0 || sx >= ws) continue;
+        v[e] = small[(((long)n * hs + sy) * ws + sx) * Cs + c];
+      }
+    }
+  }
+};
+
+// conv "up" filter operand: B[k=(tap,cs)][n=cb] = W[ky][kx][cb][cs].
+struct ConvUpB {
+  const float* w; int Cb, Cs, kw, nkx, py, px; int vec;
+  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (r >= Cb || k >= kend) return;
+    if (vec) {
+      int tap = k / Cs; int c = k - tap * Cs;
+      int m = tap / nkx; int mx = tap - m * nkx;
+      int ky = py + 2 * m, kx = px + 2 * mx;
+      const float* q = w + (((long)ky * kw + kx) * Cb + r) * Cs + c;
+      float4 t = *reinterpret_cast<const float4*>(q);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int kk = k + e;
+        if (kk >= kend) continue;
+        int tap = kk / Cs; int c = kk - tap * Cs;
+        int m = tap / nkx; int mx = tap - m * nkx;
+        int ky = py + 2 * m, kx = px + 2 * mx;
+        v[e] = w[(((long)ky * kw + kx) * Cb + r) * Cs + c];
+      }
+    }
+  }
+};
+
+// filter gradient: rows r = (ky, kx*Cb + cb) (contiguous in runs of kw*Cb),
+// k = small-side pixel (n,sy,sx).
+template <typename T>
+struct ConvWgradA {
+  const T* big; int hs, ws, hb, wb, Cb, kwc, R; float scale; int vec;
+  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if (k >= kend) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
+    int n = k / (hs * ws); int rem = k - n * hs * ws;
+    int sy = rem / ws; int sx = rem - sy * ws;
+    long base = (((long)n * hb + 2 * sy) * wb + 2 * sx) * Cb;
+    long rowpitch = (long)wb * Cb;
+    if (vec && r + 3 < R) {
+      int ky = r / kwc; int o = r - ky * kwc;
+      const float* q = reinterpret_cast<const float*>(big) + base + ky * rowpitch + o;
+      float4 t = *reinterpret_cast<const float4*>(q);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int rr = r + j;
+        if (rr < R) {
+          int ky = rr / kwc; int o = rr - ky * kwc;
+          v[j] = cvt(big[base + ky * rowpitch + o], scale);
+        } else {
+          v[j] = 0.f;
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Epilogues: operator()(m, n, acc).
+// ---------------------------------------------------------------------------
+
+struct EpiMat {
+  float* C; long ldc; const float* bias; float alpha, beta; int M, N;
+  float* slab;  // non-null: split-K partial, raw accumulators
+  __device__ __forceinline__ void operator()(int m, int n, float v) const {
+    if (m >= M || n >= N) return;
+    if (slab) {
+      slab[((long)blockIdx.z * M + m) * N + n] = v;
+      return;
+    }
+    float r = alpha * v;
+    if (bias) r += bias[n];
+    long i = (long)m * ldc + n;
+    if (beta != 0.f) r += beta * C[i];
+    C[i] = r;
+  }
+};
+
+struct EpiConvUp {
+  float* big; const float* bias; int npix, nj, ni, hb, wb, Cb, py, px;
+  __device__ __forceinline__ void operator()(int m, int n, float v) const {
+    if (m >= npix || n >= Cb) return;
+    int img = m / (nj * ni); int rem = m - img * nj * ni;
+    int j = rem / ni; int i = rem - j * ni;
+    long a = (((long)img * hb + 2 * j + py) * wb + 2 * i + px) * Cb + n;
+    big[a] = bias ? v + bias[n] : v;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Main loop.
+// ---------------------------------------------------------------------------
+
+template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP>
+__global__ void __launch_bounds__(256, 2)
+k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
+  constexpr int PA = BM + 4, PB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * PA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+  const int kb = blockIdx.z * kps;
+  const int ke = min(K, kb + kps);
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;
+  static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float ra[NA][4], rb[NB][4];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int id = tid + i * 256;
+      if (AKC) al.load4(m0 + (id >> 2), k0 + (id & 3) * 4, ke, ra[i]);
+      else     al.load4(m0 + (id % (BM / 4)) * 4, k0 + id / (BM / 4), ke, ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int id = tid + i * 256;
+      if (BKC) bl.load4(n0 + (id >> 2), k0 + (id & 3) * 4, ke, rb[i]);
+      else     bl.load4(n0 + (id % (BN / 4)) * 4, k0 + id / (BN / 4), ke, rb[i]);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int id = tid + i * 256;
+      if (AKC) {
+        int r = id >> 2, kq = (id & 3) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[buf][(kq + j) * PA + r] = ra[i][j];
+      } else {
+        int k = id / (BM / 4), r = (id % (BM / 4)) * 4;
+        *reinterpret_cast<float4*>(&As[buf][k * PA + r]) =
+            make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int id = tid + i * 256;
+      if (BKC) {
+        int r = id >> 2, kq = (id & 3) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[buf][(kq + j) * PB + r] = rb[i][j];
+      } else {
+        int k = id / (BN / 4), r = (id % (BN / 4)) * 4;
+        *reinterpret_cast<float4*>(&Bs[buf][k * PB + r]) =
+            make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
+      }
+    }
+  };
+
+  const int nk = (ke - kb + BK - 1) / BK;
+  if (nk > 0) {
+    gload(kb);
+    sstore(0);
+  }
+  __syncthreads();
+  const int lk = lane >> 5, lr = lane & 31;
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) gload(kb + (t + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = As[buf][(kk + lk) * PA + wm0 + a * 32 + lr];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = Bs[buf][(kk + lk) * PB + wn0 + b * 32 + lr];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    if (t + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        int col = n0 + wn0 + b * 32 + lr;
+        ep(row, col, acc[a][b][r]);
+      }
+}
+
+__global__ void k_splitk_reduce(const float* __restrict__ slab, int S, long MN, int N,
+                                float* C, long ldc, const float* bias, float alpha, float beta) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN;
+       i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slab[(long)z * MN + i];
+    long m = i / N; int n = (int)(i - m * N);
+    float r = alpha * s;
+    if (bias) r += bias[n];
+    long o = m * ldc + n;
+    if (beta != 0.f) r += beta * C[o];
+    C[o] = r;
+  }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Split-K factor: enough workgroups to cover the chip, bounded by K and the
+// caller's workspace.
+int pick_split(long tiles, int K, long MN, size_t ws_bytes) {
+  if (tiles >= 192 || K < 128) return 1;
+  long s = (512 + tiles - 1) / tiles;
+  long maxs = K / 64;
+  if (s > maxs) s = maxs;
+  while (s > 1 && (size_t)s * MN * sizeof(float) > ws_bytes) --s;
+  return (int)(s < 1 ? 1 : s);
+}
+
+template <bool AKC, bool BKC, class AL, class BL>
+int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* bias,
+            float alpha, float beta, float* ws, size_t ws_bytes, hipStream_t st,
+            const char* name) {
+  if (M <= 0 || N <= 0) return 0;
+  const bool big = (M > 64 && N > 64);
+  const int T = big ? 128 : 64;
+  const int tm = dd_ceil_div(M, T), tn = dd_ceil_div(N, T);
+  const long MN = (long)M * N;
+  int S = pick_split((long)tm * tn, K, MN, ws ? ws_bytes : 0);
+  int kps = ((dd_ceil_div(K > 0 ? K : 1, S) + BK - 1) / BK) * BK;
+  S = K > 0 ? dd_ceil_div(K, kps) : 1;
+  EpiMat ep{C, ldc, bias, alpha, beta, M, N, S > 1 ? ws : nullptr};
+  dim3 grid(tm * tn, 1, S);
+  if (big)
+    k_mfma_gemm<128, 128, AKC, BKC, AL, BL, EpiMat><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  else
+    k_mfma_gemm<64, 64, AKC, BKC, AL, BL, EpiMat><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  DD_CHECK_LAUNCH(name);
+  if (S > 1) {
+    int blocks = (int)((MN + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    k_splitk_reduce<<<blocks, 256, 0, st>>>(ws, S, MN, N, C, ldc, bias, alpha, beta);
+    DD_CHECK_LAUNCH("dd_gemm_f32(split-k reduce)");
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dd_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
+                           long lda, long ldb, long ldc, int transA, int transB,
+                           float alpha, float beta, const float* bias,
+                           float* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int va = aligned16(A) && (lda % 4 == 0);
+  int vb = aligned16(B) && (ldb % 4 == 0);
+  const char* nm = "dd_gemm_f32";
+  if (!transA && !transB)
+    return run_mat<true, false>(MatKC{A, lda, M, va}, MatRC{B, ldb, N, vb}, M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm);
+  if (!transA && transB)
+    return run_mat<true, true>(MatKC{A, lda, M, va}, MatKC{B, ldb, N, vb}, M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm);
+  if (transA && !transB)
+    return run_mat<false, false>(MatRC{A, lda, M, va}, MatRC{B, ldb, N, vb}, M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm);
+  return run_mat<false, true>(MatRC{A, lda, M, va}, MatKC{B, ldb, N, vb}, M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm);
+}
+
+extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const float* bias,
+                                 float* small, int n_img, int hb, int wb, int Cb,
+                                 int hs, int ws_, int Cs, int k, float in_scale,
+                                 float* wsp, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_down: geometry");
+  const int M = n_img * hs * ws_, N = Cs, K = k * k * Cb;
+  const int kwc = k * Cb;
+  MatRC bl{w, Cs, Cs, aligned16(w) && (Cs % 4 == 0)};
+  if (big_is_u8) {
+    ConvDownA<unsigned char> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 0};
+    return run_mat<true, false>(al, bl, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+  }
+  int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
+  ConvDownA<float> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec};
+  return run_mat<true, false>(al, bl, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+}
+
+extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* bias, float* big,
+                               int n_img, int hs, int ws_, int Cs, int hb, int wb, int Cb, int k,
+                               void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_up: geometry");
+  int vec = aligned16(small) && aligned16(w) && (Cs % 4 == 0);
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int nj = (hb - py + 1) / 2, ni = (wb - px + 1) / 2;  // pixels of this parity
+      const int nky = (k - py + 1) / 2, nkx = (k - px + 1) / 2;  // taps of this parity
+      if (nj <= 0 || ni <= 0) continue;
+      const int M = n_img * nj * ni, N = Cb, K = nky * nkx * Cs;
+      EpiConvUp ep{big, bias, M, nj, ni, hb, wb, Cb, py, px};
+      if (nky <= 0 || nkx <= 0) {
+        // No filter tap reaches this parity (k == 1): bias only.
+        ConvUpA al{small, M, nj, ni, hs, ws_, Cs, 1, vec};
+        ConvUpB bl{w, Cb, Cs, k, 1, py, px, vec};
+        dim3 grid(dd_ceil_div(M, 64) * dd_ceil_div(N, 64), 1, 1);
+        k_mfma_gemm<64, 64, true, true, ConvUpA, ConvUpB, EpiConvUp><<<grid, 256, 0, st>>>(al, bl, ep, 0, BK, dd_ceil_div(M, 64));
+        DD_CHECK_LAUNCH("dd_conv2d_s2_up");
+        continue;
+      }
+      ConvUpA al{small, M, nj, ni, hs, ws_, Cs, nkx, vec};
+      ConvUpB bl{w, Cb, Cs, k, nkx, py, px, vec};
+      const int kps = ((K + BK - 1) / BK) * BK;
+      if (M > 64 && N > 64) {
+        int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 128);
+        k_mfma_gemm<128, 128, true, true, ConvUpA, ConvUpB, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+      } else {
+        int tm = dd_ceil_div(M, 64), tn = dd_ceil_div(N, 64);
+        k_mfma_gemm<64, 64, true, true, ConvUpA, ConvUpB, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+      }
+      DD_CHECK_LAUNCH("dd_conv2d_s2_up");
+    }
+  return 0;
+}
+
+extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float* dw,
+                                  int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
+                                  float in_scale, float beta, float* wsp, size_t ws_bytes,
+                                  void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_wgrad: geometry");
+  const int M = k * k * Cb, N = Cs, K = n_img * hs * ws_;
+  const int kwc = k * Cb;
+  MatRC bl{small, Cs, Cs, aligned16(small) && (Cs % 4 == 0)};
+  if (big_is_u8) {
+    ConvWgradA<unsigned char> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 0};
+    return run_mat<false, false>(al, bl, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+  }
+  int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
+  ConvWgradA<float> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec};
+  return run_mat<false, false>(al, bl, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+}

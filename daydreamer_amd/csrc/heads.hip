@@ -1,0 +1,341 @@
+// Loss heads and imagination-time scalar paths: reconstruction / reward /
+// continue log-prob losses (fused forward value + gradient), the Normal policy
+// head, the lambda-return scan with discount weights, and the critic / actor
+// loss seeds.
+//
+// Reference: MSEDist / SymlogDist tfutils.py:305-356, Bernoulli head
+// nets.py:469-471, Normal head nets.py:461-468, WorldModel.imagine
+// agent.py:256-259 (cont, weight), VFunction.target 'gve' agent.py:434-440,
+// VFunction.train agent.py:398-417, ImagActorCritic.loss agent.py:351-381.
+#include "dd_common.h"
+#include "../../include/daydreamer_hip.h"
+
+namespace {
+
+// loss[row] = sum_p (sigmoid(z) - x/255)^2 ; dz = coef * 2 (s - x) s (1 - s)
+__global__ void __launch_bounds__(256)
+k_image_loss(const float* __restrict__ z, const unsigned char* __restrict__ img,
+             float* __restrict__ loss, float* __restrict__ dz, long P, float coef) {
+  const long row = blockIdx.x;
+  const float* zr = z + row * P;
+  const unsigned char* ir = img + row * P;
+  float* dr = dz + row * P;
+  float acc = 0.f;
+  for (long p = threadIdx.x; p < P; p += 256) {
+    float s = sigmoidf_(zr[p]);
+    float d = s - (float)ir[p] * (1.f / 255.f);
+    acc += d * d;
+    dr[p] = coef * 2.f * d * s * (1.f - s);
+  }
+  acc = wave_sum(acc);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[row] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// wave per row: loss[row] = sum_d (pred - target)^2 ; dpred = coef*2*(pred-target)
+__global__ void __launch_bounds__(256)
+k_mse_loss(const float* __restrict__ pred, long ldp, const float* __restrict__ tgt, long ldt,
+           float* __restrict__ loss, float* __restrict__ dpred, long lddp, int rows, int D,
+           float coef) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    float e = pred[row * ldp + d] - tgt[row * ldt + d];
+    acc += e * e;
+    dpred[row * lddp + d] = coef * 2.f * e;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) loss[row] = acc;
+}
+
+// kind 0: symlog MSE (pred - symlog(t))^2 ; kind 1: Bernoulli(logits) NLL.
+__global__ void k_scalar_loss(const float* __restrict__ pred, const float* __restrict__ tgt,
+                              float* __restrict__ loss, float* __restrict__ dpred, long n,
+                              float coef, int kind) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p = pred[i], t = tgt[i];
+  if (kind == 0) {
+    float e = p - symlogf_(t);
+    loss[i] = e * e;
+    dpred[i] = coef * 2.f * e;
+  } else {
+    loss[i] = -(t * logsigmoidf_(p) + (1.f - t) * logsigmoidf_(-p));
+    dpred[i] = coef * (sigmoidf_(p) - t);
+  }
+}
+
+// action = tanh(o_mean) + ((hi-lo)*sigmoid(o_std)+lo) * eps   (eps may be null -> mode)
+__global__ void k_normal_head_fwd(const float* __restrict__ om, long ldm,
+                                  const float* __restrict__ os, long ldsd,
+                                  const float* __restrict__ eps, long lde,
+                                  float* __restrict__ act, long lda, int rows, int A,
+                                  float lo, float hi) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * A) return;
+  long r = i / A; int a = (int)(i - r * A);
+  float mean = tanhf(om[r * ldm + a]);
+  float v = mean;
+  if (eps) {
+    float std = (hi - lo) * sigmoidf_(os[r * ldsd + a]) + lo;
+    v += std * eps[r * lde + a];
+  }
+  act[r * lda + a] = v;
+}
+
+// Backward of the sampled action and of the (normalised) entropy bonus.
+// rows_ent: rows [0, rows_ent) carry the entropy term weighted by w[row].
+// d loss/d log(std_a) = -scale_a * w * ent_coef, ent_coef = 1/(count*(hi_ent-lo_ent)).
+// ent_row[row] = sum_a scale_a * (-ent_norm_a)  (loss value of the bonus).
+__global__ void __launch_bounds__(256)
+k_normal_head_bwd(const float* __restrict__ om, long ldm, const float* __restrict__ os, long ldsd,
+                  const float* __restrict__ eps, long lde, const float* __restrict__ dact, long ldda,
+                  const float* __restrict__ w, const float* __restrict__ scale,
+                  float* __restrict__ dom, long lddm, float* __restrict__ dos, long lddsd,
+                  float* __restrict__ ent_row, int rows, int rows_ent, int A,
+                  float lo, float hi, float ent_coef, float ent_lo, float ent_div) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float er = 0.f;
+  for (int a = lane; a < A; a += 64) {
+    float o = om[r * ldm + a], s = os[r * ldsd + a];
+    float mean = tanhf(o);
+    float sg = sigmoidf_(s);
+    float std = (hi - lo) * sg + lo;
+    float da = dact ? dact[r * ldda + a] : 0.f;
+    float dstd = da * eps[r * lde + a];
+    if (r < rows_ent) {
+      float sc = scale[a];
+      dstd += -sc * w[r] * ent_coef / std;
+      er += sc * -((logf(std) - ent_lo) / ent_div);
+    }
+    dom[r * lddm + a] = da * (1.f - mean * mean);
+    dos[r * lddsd + a] = dstd * (hi - lo) * sg * (1.f - sg);
+  }
+  er = wave_sum(er);
+  if (lane == 0 && ent_row) ent_row[r] = (r < rows_ent) ? er : 0.f;
+}
+
+// Per action dimension: sum and sum of squares (fp64) of the normalised
+// entropy over the first `rows` rows.  Single block.
+__global__ void __launch_bounds__(1024)
+k_actent_stats(const float* __restrict__ os, long ldsd, int rows, int A, float lo, float hi,
+               float ent_lo, float ent_div, double* __restrict__ out) {
+  __shared__ double sh[2][16];
+  for (int a = 0; a < A; ++a) {
+    double s = 0.0, q = 0.0;
+    for (long r = threadIdx.x; r < rows; r += 1024) {
+      float std = (hi - lo) * sigmoidf_(os[r * ldsd + a]) + lo;
+      float e = (logf(std) - ent_lo) / ent_div;
+      s += e; q += (double)e * e;
+    }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double ts = 0.0, tq = 0.0;
+      for (int i = 0; i < 16; ++i) { ts += sh[0][i]; tq += sh[1][i]; }
+      out[a] = ts; out[A + a] = tq;
+    }
+    __syncthreads();
+  }
+}
+
+// Thread per imagined trajectory (column n), sequential over the horizon.
+__global__ void k_imag_returns_fwd(const float* __restrict__ rew_raw, const float* __restrict__ val_raw,
+                                   const float* __restrict__ cont_raw, const float* __restrict__ first_cont,
+                                   float* __restrict__ reward, float* __restrict__ value,
+                                   float* __restrict__ cont, float* __restrict__ weight,
+                                   float* __restrict__ ret, int H, long N, float gamma, float lam) {
+  long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float wprod = 1.f;
+  for (int t = 0; t <= H; ++t) {
+    float c = t == 0 ? first_cont[n] : sigmoidf_(cont_raw[t * N + n]);
+    if (cont) cont[t * N + n] = c;
+    wprod *= gamma * c;
+    if (weight) weight[t * N + n] = wprod / gamma;
+    value[t * N + n] = symexpf_(val_raw[t * N + n]);
+    if (t > 0) reward[(t - 1) * N + n] = symexpf_(rew_raw[t * N + n]);
+  }
+  float R = value[H * N + n];
+  for (int t = H - 1; t >= 0; --t) {
+    float c = sigmoidf_(cont_raw[(t + 1) * N + n]);
+    float d = c * gamma;
+    float r = symexpf_(rew_raw[(t + 1) * N + n]);
+    R = r + d * ((1.f - lam) * value[(t + 1) * N + n] + lam * R);
+    ret[t * N + n] = R;
+  }
+}
+
+// dret [H,N], dbase [H,N] (gradient w.r.t. value[:-1] used as baseline).
+__global__ void k_imag_returns_bwd(const float* __restrict__ dret, const float* __restrict__ dbase,
+                                   const float* __restrict__ rew_raw, const float* __restrict__ val_raw,
+                                   const float* __restrict__ cont_raw, const float* __restrict__ value,
+                                   const float* __restrict__ ret, float* __restrict__ d_rew_raw,
+                                   float* __restrict__ d_val_raw, float* __restrict__ d_cont_raw,
+                                   int H, long N, float gamma, float lam) {
+  long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  d_rew_raw[n] = 0.f;
+  d_cont_raw[n] = 0.f;
+  float carry = 0.f;   // gradient flowing into R_t from R_{t-1}
+  float dv = 0.f;      // gradient accumulated for value_t from step t-1
+  for (int t = 0; t < H; ++t) {
+    float g = dret[t * N + n] + carry;
+    float c = sigmoidf_(cont_raw[(t + 1) * N + n]);
+    float d = c * gamma;
+    float vnext = value[(t + 1) * N + n];
+    float Rnext = (t + 1 < H) ? ret[(t + 1) * N + n] : vnext;
+    float A = (1.f - lam) * vnext + lam * Rnext;
+    // value_t: baseline grad + what step t-1 pushed into it
+    float dvt = dv + (dbase ? dbase[t * N + n] : 0.f);
+    d_val_raw[t * N + n] = dvt * expf(fabsf(val_raw[t * N + n]));
+    d_rew_raw[(t + 1) * N + n] = g * expf(fabsf(rew_raw[(t + 1) * N + n]));
+    d_cont_raw[(t + 1) * N + n] = g * A * gamma * c * (1.f - c);
+    dv = g * d * (1.f - lam);
+    carry = g * d * lam;
+  }
+  d_val_raw[H * N + n] = (dv + carry) * expf(fabsf(val_raw[H * N + n]));
+}
+
+// critic: loss_i = w_i * (out_i - symlog(ret_i))^2 ; dout = coef * 2 w (out - symlog ret)
+__global__ void k_critic_loss(const float* __restrict__ out, const float* __restrict__ ret,
+                              const float* __restrict__ w, float* __restrict__ loss,
+                              float* __restrict__ dout, long n, float coef) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float e = out[i] - symlogf_(ret[i]);
+  loss[i] = w[i] * e * e;
+  dout[i] = coef * 2.f * w[i] * e;
+}
+
+// actor: score = ((ret - base) * sc[0] - sc[1]) * sc[2]  (normaliser chain folded
+// into three device scalars), loss_i = w * (-score + ent_row);
+// dret = -w * coef * sc[0]*sc[2], dbase = -dret.
+__global__ void k_actor_seed(const float* __restrict__ ret, const float* __restrict__ base,
+                             const float* __restrict__ w, const float* __restrict__ ent_row,
+                             const float* __restrict__ sc, float* __restrict__ loss,
+                             float* __restrict__ dret, float* __restrict__ dbase, long n, float coef) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float score = ((ret[i] - base[i]) * sc[0] - sc[1]) * sc[2];
+  loss[i] = w[i] * (-score + (ent_row ? ent_row[i] : 0.f));
+  float g = -w[i] * coef * sc[0] * sc[2];
+  dret[i] = g;
+  dbase[i] = -g;
+}
+
+__global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b,
+                      float* __restrict__ o, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] - b[i];
+}
+
+inline int nblk(long n, int t = 256) { return (int)((n + t - 1) / t); }
+
+}  // namespace
+
+extern "C" int dd_image_loss(const float* z, const unsigned char* img, float* loss, float* dz,
+                             int rows, long P, float coef, void* stream) {
+  if (rows <= 0) return 0;
+  k_image_loss<<<rows, 256, 0, (hipStream_t)stream>>>(z, img, loss, dz, P, coef);
+  DD_CHECK_LAUNCH("dd_image_loss");
+  return 0;
+}
+
+extern "C" int dd_mse_loss(const float* pred, long ldp, const float* tgt, long ldt, float* loss,
+                           float* dpred, long lddp, int rows, int D, float coef, void* stream) {
+  if (rows <= 0) return 0;
+  k_mse_loss<<<nblk(rows, 4), 256, 0, (hipStream_t)stream>>>(pred, ldp, tgt, ldt, loss, dpred, lddp, rows, D, coef);
+  DD_CHECK_LAUNCH("dd_mse_loss");
+  return 0;
+}
+
+extern "C" int dd_scalar_loss(const float* pred, const float* tgt, float* loss, float* dpred,
+                              long n, float coef, int kind, void* stream) {
+  if (n <= 0) return 0;
+  k_scalar_loss<<<nblk(n), 256, 0, (hipStream_t)stream>>>(pred, tgt, loss, dpred, n, coef, kind);
+  DD_CHECK_LAUNCH("dd_scalar_loss");
+  return 0;
+}
+
+extern "C" int dd_normal_head_fwd(const float* om, long ldm, const float* os, long ldsd,
+                                  const float* eps, long lde, float* act, long lda,
+                                  int rows, int A, float lo, float hi, void* stream) {
+  if (rows <= 0) return 0;
+  k_normal_head_fwd<<<nblk((long)rows * A), 256, 0, (hipStream_t)stream>>>(om, ldm, os, ldsd, eps, lde, act, lda, rows, A, lo, hi);
+  DD_CHECK_LAUNCH("dd_normal_head_fwd");
+  return 0;
+}
+
+extern "C" int dd_normal_head_bwd(const float* om, long ldm, const float* os, long ldsd,
+                                  const float* eps, long lde, const float* dact, long ldda,
+                                  const float* w, const float* scale,
+                                  float* dom, long lddm, float* dos, long lddsd, float* ent_row,
+                                  int rows, int rows_ent, int A, float lo, float hi,
+                                  float ent_coef, float ent_lo, float ent_div, void* stream) {
+  if (rows <= 0) return 0;
+  k_normal_head_bwd<<<nblk(rows, 4), 256, 0, (hipStream_t)stream>>>(
+      om, ldm, os, ldsd, eps, lde, dact, ldda, w, scale, dom, lddm, dos, lddsd, ent_row,
+      rows, rows_ent, A, lo, hi, ent_coef, ent_lo, ent_div);
+  DD_CHECK_LAUNCH("dd_normal_head_bwd");
+  return 0;
+}
+
+extern "C" int dd_actent_stats(const float* os, long ldsd, int rows, int A, float lo, float hi,
+                               float ent_lo, float ent_div, double* out, void* stream) {
+  k_actent_stats<<<1, 1024, 0, (hipStream_t)stream>>>(os, ldsd, rows, A, lo, hi, ent_lo, ent_div, out);
+  DD_CHECK_LAUNCH("dd_actent_stats");
+  return 0;
+}
+
+extern "C" int dd_imag_returns_fwd(const float* rew_raw, const float* val_raw, const float* cont_raw,
+                                   const float* first_cont, float* reward, float* value,
+                                   float* cont, float* weight, float* ret, int H, long N,
+                                   float gamma, float lam, void* stream) {
+  if (N <= 0) return 0;
+  k_imag_returns_fwd<<<nblk(N), 256, 0, (hipStream_t)stream>>>(rew_raw, val_raw, cont_raw, first_cont, reward, value, cont, weight, ret, H, N, gamma, lam);
+  DD_CHECK_LAUNCH("dd_imag_returns_fwd");
+  return 0;
+}
+
+extern "C" int dd_imag_returns_bwd(const float* dret, const float* dbase, const float* rew_raw,
+                                   const float* val_raw, const float* cont_raw, const float* value,
+                                   const float* ret, float* d_rew_raw, float* d_val_raw,
+                                   float* d_cont_raw, int H, long N, float gamma, float lam,
+                                   void* stream) {
+  if (N <= 0) return 0;
+  k_imag_returns_bwd<<<nblk(N), 256, 0, (hipStream_t)stream>>>(dret, dbase, rew_raw, val_raw, cont_raw, value, ret, d_rew_raw, d_val_raw, d_cont_raw, H, N, gamma, lam);
+  DD_CHECK_LAUNCH("dd_imag_returns_bwd");
+  return 0;
+}
+
+extern "C" int dd_critic_loss(const float* out, const float* ret, const float* w, float* loss,
+                              float* dout, long n, float coef, void* stream) {
+  if (n <= 0) return 0;
+  k_critic_loss<<<nblk(n), 256, 0, (hipStream_t)stream>>>(out, ret, w, loss, dout, n, coef);
+  DD_CHECK_LAUNCH("dd_critic_loss");
+  return 0;
+}
+
+extern "C" int dd_actor_seed(const float* ret, const float* base, const float* w,
+                             const float* ent_row, const float* sc, float* loss, float* dret,
+                             float* dbase, long n, float coef, void* stream) {
+  if (n <= 0) return 0;
+  k_actor_seed<<<nblk(n), 256, 0, (hipStream_t)stream>>>(ret, base, w, ent_row, sc, loss, dret, dbase, n, coef);
+  DD_CHECK_LAUNCH("dd_actor_seed");
+  return 0;
+}
+
+extern "C" int dd_sub(const float* a, const float* b, float* o, long n, void* stream) {
+  if (n <= 0) return 0;
+  k_sub<<<nblk(n), 256, 0, (hipStream_t)stream>>>(a, b, o, n);
+  DD_CHECK_LAUNCH("dd_sub");
+  return 0;
+}

@@ -1,0 +1,396 @@
+// Row-wise memory-bound kernels: LayerNorm(+ELU) forward/backward, the
+// DreamerV2 GRU-cell epilogue forward/backward, and column reductions.
+//
+// One 64-lane wavefront owns one row: coalesced loads of the (rows, feature)
+// tile, butterfly shuffles for the per-row reductions, no LDS traffic on the
+// critical path.  Reference math: Norm nets.py:585-602 (population variance,
+// eps 1e-3), ELU alpha 1, RSSM._gru nets.py:149-160.
+#include "dd_common.h"
+#include <type_traits>
+#include "../../include/daydreamer_hip.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-3f;
+constexpr int WPB = 4;  // waves (rows in flight) per 256-thread block
+
+__device__ __forceinline__ float elu_(float y) { return y > 0.f ? y : expm1f(y); }
+
+// ---- LayerNorm + activation forward --------------------------------------
+// NPL = cached elements per lane (C <= 64*NPL); NPL = 0 re-reads the row.
+template <int NPL>
+__global__ void __launch_bounds__(256)
+k_ln_act_fwd(const float* __restrict__ z, long ldz, const float* __restrict__ gamma,
+             const float* __restrict__ beta, float* __restrict__ out, long ldo,
+             float* __restrict__ stats, int rows, int C, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
+    const float* zr = z + row * ldz;
+    float x[NPL > 0 ? NPL : 1];
+    float s = 0.f;
+    if (NPL > 0) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        int c = lane + 64 * i;
+        x[i] = c < C ? zr[c] : 0.f;
+        s += x[i];
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) s += zr[c];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    if (NPL > 0) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        int c = lane + 64 * i;
+        float d = c < C ? x[i] - mean : 0.f;
+        v += d * d;
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) { float d = zr[c] - mean; v += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)C + LN_EPS);
+    float* orow = out + row * ldo;
+    if (NPL > 0) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        int c = lane + 64 * i;
+        if (c < C) {
+          float y = (x[i] - mean) * rstd * gamma[c] + beta[c];
+          orow[c] = act ? elu_(y) : y;
+        }
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        float y = (zr[c] - mean) * rstd * gamma[c] + beta[c];
+        orow[c] = act ? elu_(y) : y;
+      }
+    }
+    if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  }
+}
+
+// ---- LayerNorm + activation backward (data gradient, optional fused
+// per-block parameter-gradient partials) ------------------------------------
+template <int NPL>
+__global__ void __launch_bounds__(256)
+k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
+             const float* __restrict__ out, long ldo, const float* __restrict__ stats,
+             const float* __restrict__ gamma, float* __restrict__ dz, long lddz,
+             float* __restrict__ partials, int rows, int C, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[NPL > 0 ? NPL : 1], pb[NPL > 0 ? NPL : 1];
+#pragma unroll
+  for (int i = 0; i < (NPL > 0 ? NPL : 1); ++i) { pg[i] = 0.f; pb[i] = 0.f; }
+  for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const float* dr = dout + row * ldd;
+    const float* zr = z + row * ldz;
+    const float* orow = out + row * ldo;
+    float* dzr = dz + row * lddz;
+    if (NPL > 0) {
+      float g[NPL > 0 ? NPL : 1], xh[NPL > 0 ? NPL : 1];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        int c = lane + 64 * i;
+        if (c < C) {
+          float dy = dr[c];
+          if (act) { float o = orow[c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
+          xh[i] = (zr[c] - mean) * rstd;
+          g[i] = dy * gamma[c];
+          pg[i] += dy * xh[i];
+          pb[i] += dy;
+          s1 += g[i];
+          s2 += g[i] * xh[i];
+        } else { g[i] = 0.f; xh[i] = 0.f; }
+      }
+      s1 = wave_sum(s1) / (float)C;
+      s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        int c = lane + 64 * i;
+        if (c < C) dzr[c] = rstd * (g[i] - s1 - xh[i] * s2);
+      }
+    } else {
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        float dy = dr[c];
+        if (act) { float o = orow[c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
+        float xh = (zr[c] - mean) * rstd;
+        float g = dy * gamma[c];
+        s1 += g; s2 += g * xh;
+      }
+      s1 = wave_sum(s1) / (float)C;
+      s2 = wave_sum(s2) / (float)C;
+      for (int c = lane; c < C; c += 64) {
+        float dy = dr[c];
+        if (act) { float o = orow[c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
+        float xh = (zr[c] - mean) * rstd;
+        dzr[c] = rstd * (dy * gamma[c] - s1 - xh * s2);
+      }
+    }
+  }
+  if (NPL > 0 && partials) {
+    __shared__ float sh[WPB][2][64 * (NPL > 0 ? NPL : 1)];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      sh[wave][0][lane + 64 * i] = pg[i];
+      sh[wave][1][lane + 64 * i] = pb[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) { a += sh[w][0][c]; b += sh[w][1][c]; }
+      partials[((long)blockIdx.x * 2) * C + c] = a;
+      partials[((long)blockIdx.x * 2 + 1) * C + c] = b;
+    }
+  }
+}
+
+// ---- generic LN parameter gradient: thread per column, 4 row lanes per
+// block, grid.y row chunks -> partials[grid.y][2][C] -------------------------
+__global__ void __launch_bounds__(256)
+k_ln_param_grad(const float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
+                const float* __restrict__ out, long ldo, const float* __restrict__ stats,
+                float* __restrict__ partials, int rows, int C, int act) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+    for (long row = (long)blockIdx.y * 4 + rl; row < rows; row += (long)gridDim.y * 4) {
+      float dy = dout[row * ldd + c];
+      if (act) { float o = out[row * ldo + c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
+      float xh = (z[row * ldz + c] - stats[row * 2]) * stats[row * 2 + 1];
+      a += dy * xh;
+      b += dy;
+    }
+  }
+  __shared__ float sh[4][2][64];
+  sh[rl][0][cl] = a; sh[rl][1][cl] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sa += sh[w][0][cl]; sb += sh[w][1][cl]; }
+    partials[((long)blockIdx.y * 2) * C + c] = sa;
+    partials[((long)blockIdx.y * 2 + 1) * C + c] = sb;
+  }
+}
+
+// out[w] = beta*out[w] + sum_p partials[p*stride + w]
+__global__ void k_col_reduce(const float* __restrict__ partials, int P, long stride, int W,
+                             float* __restrict__ out, float beta) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += partials[(long)p * stride + w];
+  out[w] = (beta != 0.f ? beta * out[w] : 0.f) + s;
+}
+
+// ---- GRU cell epilogue -----------------------------------------------------
+// z3 [rows, 3D] = concat[deter, x] @ W; LayerNorm over the whole 3D vector,
+// then reset = sig(r); cand = tanh(reset * c); update = sig(u - 1);
+// h' = update * cand + (1 - update) * h.
+__global__ void __launch_bounds__(256)
+k_gru_fwd(const float* __restrict__ z3, long ldz, const float* __restrict__ gamma,
+          const float* __restrict__ beta, const float* __restrict__ h, long ldh,
+          float* __restrict__ hn, long ldn, float* __restrict__ stats, int rows, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = 3 * D;
+  for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
+    const float* zr = z3 + row * ldz;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += zr[c];
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { float d = zr[c] - mean; v += d * d; }
+    const float rstd = rsqrtf(wave_sum(v) / (float)C + LN_EPS);
+    for (int j = lane; j < D; j += 64) {
+      float yr = (zr[j] - mean) * rstd * gamma[j] + beta[j];
+      float yc = (zr[D + j] - mean) * rstd * gamma[D + j] + beta[D + j];
+      float yu = (zr[2 * D + j] - mean) * rstd * gamma[2 * D + j] + beta[2 * D + j];
+      float r = sigmoidf_(yr);
+      float cand = tanhf(r * yc);
+      float u = sigmoidf_(yu - 1.f);
+      float hp = h[row * ldh + j];
+      hn[row * ldn + j] = u * cand + (1.f - u) * hp;
+    }
+    if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  }
+}
+
+// Backward: given dh' -> dz3 (through the LayerNorm), dh (direct path,
+// (1-update)*dh'), and dy3 (gradient at the LayerNorm output, for the bulk
+// parameter-gradient pass).
+__global__ void __launch_bounds__(256)
+k_gru_bwd(const float* __restrict__ dhn, long lddn, const float* __restrict__ z3, long ldz,
+          const float* __restrict__ stats, const float* __restrict__ gamma,
+          const float* __restrict__ beta, const float* __restrict__ h, long ldh,
+          float* __restrict__ dz3, long lddz, float* __restrict__ dh, long lddh,
+          float* __restrict__ dy3, long lddy, int rows, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = 3 * D;
+  for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
+    const float* zr = z3 + row * ldz;
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float* dyr = dy3 + row * lddy;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < D; j += 64) {
+      float xr = (zr[j] - mean) * rstd, xc = (zr[D + j] - mean) * rstd,
+            xu = (zr[2 * D + j] - mean) * rstd;
+      float yr = xr * gamma[j] + beta[j];
+      float yc = xc * gamma[D + j] + beta[D + j];
+      float yu = xu * gamma[2 * D + j] + beta[2 * D + j];
+      float r = sigmoidf_(yr);
+      float cand = tanhf(r * yc);
+      float u = sigmoidf_(yu - 1.f);
+      float hp = h[row * ldh + j];
+      float d = dhn[row * lddn + j];
+      float du = d * (cand - hp);
+      float dc = d * u;
+      dh[row * lddh + j] = d * (1.f - u);
+      float dpre = dc * (1.f - cand * cand);
+      float dyc = dpre * r;
+      float dyr_ = dpre * yc * r * (1.f - r);
+      float dyu = du * u * (1.f - u);
+      dyr[j] = dyr_; dyr[D + j] = dyc; dyr[2 * D + j] = dyu;
+      float gr = dyr_ * gamma[j], gc = dyc * gamma[D + j], gu = dyu * gamma[2 * D + j];
+      s1 += gr + gc + gu;
+      s2 += gr * xr + gc * xc + gu * xu;
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    float* dzr = dz3 + row * lddz;
+    // dy3 was written by this same lane for the same columns: plain re-read.
+    for (int j = lane; j < D; j += 64) {
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        int c = part * D + j;
+        float xh = (zr[c] - mean) * rstd;
+        dzr[c] = rstd * (dyr[c] * gamma[c] - s1 - xh * s2);
+      }
+    }
+  }
+}
+
+template <typename F>
+int dispatch_npl(int C, F f) {
+  if (C <= 64) return f(std::integral_constant<int, 1>());
+  if (C <= 128) return f(std::integral_constant<int, 2>());
+  if (C <= 256) return f(std::integral_constant<int, 4>());
+  if (C <= 512) return f(std::integral_constant<int, 8>());
+  if (C <= 768) return f(std::integral_constant<int, 12>());
+  if (C <= 1024) return f(std::integral_constant<int, 16>());
+  return f(std::integral_constant<int, 0>());
+}
+
+inline int row_blocks(long rows, int cap) {
+  long b = (rows + WPB - 1) / WPB;
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int dd_ln_act_fwd(const float* z, long ldz, const float* gamma, const float* beta,
+                             float* out, long ldo, float* stats, int rows, int C, int act,
+                             void* stream) {
+  if (rows <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = row_blocks(rows, 1 << 20);
+  return dispatch_npl(C, [&](auto npl) {
+    k_ln_act_fwd<decltype(npl)::value><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, rows, C, act);
+    DD_CHECK_LAUNCH("dd_ln_act_fwd");
+    return 0;
+  });
+}
+
+extern "C" int dd_ln_bwd_parts(int rows, int C) {
+  // Number of partial rows dd_ln_act_bwd's fused parameter-gradient pass uses.
+  if (C > 1024) {
+    long chunks = (rows + 63) / 64;
+    return (int)(chunks > 256 ? 256 : (chunks < 1 ? 1 : chunks));
+  }
+  return row_blocks(rows, 512);
+}
+
+extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
+                             const float* out, long ldo, const float* stats, const float* gamma,
+                             float* dz, long lddz, float* dgamma, float* dbeta, int accumulate,
+                             int rows, int C, int act, float* ws, size_t ws_bytes, void* stream) {
+  if (rows <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool want = dgamma != nullptr;
+  const int parts = dd_ln_bwd_parts(rows, C);
+  if (want) DD_REQUIRE(ws && (size_t)parts * 2 * C * sizeof(float) <= ws_bytes, "dd_ln_act_bwd: workspace too small");
+  const bool fused = want && C <= 1024;
+  int blocks = fused ? parts : row_blocks(rows, 1 << 20);
+  int rc = dispatch_npl(C, [&](auto npl) {
+    k_ln_act_bwd<decltype(npl)::value><<<blocks, 256, 0, st>>>(
+        dout, ldd, z, ldz, out, ldo, stats, gamma, dz, lddz, fused ? ws : nullptr, rows, C, act);
+    DD_CHECK_LAUNCH("dd_ln_act_bwd");
+    return 0;
+  });
+  if (rc || !want) return rc;
+  if (!fused) {
+    dim3 grid((C + 63) / 64, parts);
+    k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, ws, rows, C, act);
+    DD_CHECK_LAUNCH("dd_ln_act_bwd(param grad)");
+  }
+  // partials are [parts][2][C]: gamma rows at stride 2C from ws, beta rows from ws + C.
+  const int nb = (C + 255) / 256;
+  const float b = accumulate ? 1.f : 0.f;
+  k_col_reduce<<<nb, 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, b);
+  DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce gamma)");
+  k_col_reduce<<<nb, 256, 0, st>>>(ws + C, parts, 2L * C, C, dbeta, b);
+  DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce beta)");
+  return 0;
+}
+
+// Parameter gradients only (bulk pass after a scan): dgamma/dbeta from stored
+// dout / out / z / stats of all steps.
+extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, long ldz,
+                                const float* out, long ldo, const float* stats,
+                                float* dgamma, float* dbeta, int accumulate, int rows, int C,
+                                int act, float* ws, size_t ws_bytes, void* stream) {
+  if (rows <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  long chunks = (rows + 63) / 64;
+  const int parts = (int)(chunks > 256 ? 256 : (chunks < 1 ? 1 : chunks));
+  DD_REQUIRE(ws && (size_t)parts * 2 * C * sizeof(float) <= ws_bytes, "dd_ln_param_grad: workspace too small");
+  dim3 grid((C + 63) / 64, parts);
+  k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, ws, rows, C, act);
+  DD_CHECK_LAUNCH("dd_ln_param_grad");
+  const int nb = (C + 255) / 256;
+  const float b = accumulate ? 1.f : 0.f;
+  k_col_reduce<<<nb, 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, b);
+  DD_CHECK_LAUNCH("dd_ln_param_grad(reduce gamma)");
+  k_col_reduce<<<nb, 256, 0, st>>>(ws + C, parts, 2L * C, C, dbeta, b);
+  DD_CHECK_LAUNCH("dd_ln_param_grad(reduce beta)");
+  return 0;
+}
+
+extern "C" int dd_gru_cell_fwd(const float* z3, long ldz, const float* gamma, const float* beta,
+                               const float* h, long ldh, float* hn, long ldn, float* stats,
+                               int rows, int D, void* stream) {
+  if (rows <= 0) return 0;
+  k_gru_fwd<<<row_blocks(rows, 1 << 20), 256, 0, (hipStream_t)stream>>>(
+      z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, rows, D);
+  DD_CHECK_LAUNCH("dd_gru_cell_fwd");
+  return 0;
+}
+
+extern "C" int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
+                               const float* stats, const float* gamma, const float* beta,
+                               const float* h, long ldh, float* dz3, long lddz,
+                               float* dh, long lddh, float* dy3, long lddy,
+                               int rows, int D, void* stream) {
+  if (rows <= 0) return 0;
+  k_gru_bwd<<<row_blocks(rows, 1 << 20), 256, 0, (hipStream_t)stream>>>(
+      dhn, lddn, z3, ldz, stats, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, rows, D);
+  DD_CHECK_LAUNCH("dd_gru_cell_bwd");
+  return 0;
+}

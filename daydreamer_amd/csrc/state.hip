@@ -1,0 +1,403 @@
+// Learner state kernels: counter-based RNG (Philox4x32-10), the multi-tensor
+// optimizer (global-norm clip + weight decay + bias-corrected Adam over one
+// flat parameter arena), device-resident scalar controllers (AutoAdapt,
+// Normalize), batch statistics, and small data-movement helpers.
+//
+// Everything that changes from step to step (step counters, bias corrections,
+// controller scales) lives in device memory so a captured HIP graph can be
+// replayed unchanged.
+//
+// Reference: Optimizer tfutils.py:180-302, AutoAdapt tfutils.py:414-482,
+// Normalize tfutils.py:485-527, RSSM.obs_step reset mask nets.py:100-107.
+#include "dd_common.h"
+#include "../../include/daydreamer_hip.h"
+
+namespace {
+
+// ---- Philox4x32-10 ----------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// Element (o, i, c) of a [outer, inner, cols] tensor draws from
+//   counter = (c / 4, global_row, site, step), key = (seed_lo, seed_hi), word c % 4
+// with global_row = o * inner_global + inner_offset + i, so the stream does
+// not depend on how the batch axis is sharded across GPUs.
+// kind 0: uniform [0,1) = (x >> 8) * 2^-24.  kind 1: standard normal
+// (Box-Muller on word pairs (0,1) and (2,3)).
+__global__ void k_philox(float* __restrict__ out, long outer, long inner, int cols,
+                         long inner_global, long inner_offset, uint32_t seed_lo, uint32_t seed_hi,
+                         const unsigned long long* __restrict__ step_dev, uint32_t site, int kind) {
+  const int cb = (cols + 3) / 4;
+  const long total = outer * inner * cb;
+  const uint32_t step = (uint32_t)(*step_dev);
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (long)gridDim.x * blockDim.x) {
+    long row = id / cb; int blk = (int)(id - row * cb);
+    long o = row / inner, i = row - o * inner;
+    long grow = o * inner_global + inner_offset + i;
+    uint32_t c[4] = {(uint32_t)blk, (uint32_t)grow, site, step};
+    philox4x32(c, seed_lo, seed_hi);
+    float v[4];
+    if (kind == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (float)(c[j] >> 8) * (1.0f / 16777216.0f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        float u1 = ((float)(c[j] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float u2 = (float)(c[j + 1] >> 8) * (1.0f / 16777216.0f);
+        float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        v[j] = rad * cs; v[j + 1] = rad * sn;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int col = blk * 4 + j;
+      if (col < cols) out[row * cols + col] = v[j];
+    }
+  }
+}
+
+__global__ void k_counter_add(unsigned long long* c, unsigned long long v) { *c += v; }
+
+// ---- statistics --------------------------------------------------------------
+// Single block: sums[0]=sum x, sums[1]=sum x^2 (fp64); maxs[0]=max x,
+// maxs[1]=max(-x), maxs[2]=max|x|; sums[2]=sum |x|.
+__global__ void __launch_bounds__(1024)
+k_reduce_stats(const float* __restrict__ x, long n, long stride, double* __restrict__ sums,
+               float* __restrict__ maxs) {
+  double s = 0.0, q = 0.0, a = 0.0;
+  float mx = -INFINITY, mn = -INFINITY, ma = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    float v = x[i * stride];
+    s += v; q += (double)v * v; a += fabsf(v);
+    mx = fmaxf(mx, v); mn = fmaxf(mn, -v); ma = fmaxf(ma, fabsf(v));
+  }
+  s = wave_sum_d(s); q = wave_sum_d(q); a = wave_sum_d(a);
+  mx = wave_max(mx); mn = wave_max(mn); ma = wave_max(ma);
+  __shared__ double shd[3][16];
+  __shared__ float shf[3][16];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    shd[0][w] = s; shd[1][w] = q; shd[2][w] = a;
+    shf[0][w] = mx; shf[1][w] = mn; shf[2][w] = ma;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0, tq = 0, ta = 0; float tx = -INFINITY, tn = -INFINITY, tm = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      ts += shd[0][i]; tq += shd[1][i]; ta += shd[2][i];
+      tx = fmaxf(tx, shf[0][i]); tn = fmaxf(tn, shf[1][i]); tm = fmaxf(tm, shf[2][i]);
+    }
+    sums[0] = ts; sums[1] = tq; sums[2] = ta;
+    maxs[0] = tx; maxs[1] = tn; maxs[2] = tm;
+  }
+}
+
+// AutoAdapt 'mult' (tfutils.py:460-474): scale[i] updated from avg_i =
+// sums[i] / count.
+__global__ void k_autoadapt(float* __restrict__ scale, const double* __restrict__ sums, int n,
+                            double count, float target, float thres, float vel, float lo,
+                            float hi, int inverse) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float avg = (float)(sums[i] / count);
+  bool below = avg < (1.f / (1.f + thres)) * target;
+  bool above = avg > (1.f + thres) * target;
+  if (inverse) { bool t = below; below = above; above = t; }
+  float s = scale[i];
+  float adj = above ? s * (1.f + vel) : (below ? s / (1.f + vel) : s);
+  scale[i] = fminf(fmaxf(adj, lo), hi);
+}
+
+// Normalize (tfutils.py:498-527): state = {mean, sqrs, step} in fp64.
+// The input statistics are those of x; the normaliser sees in_scale * x
+// (in_off is not supported upstream of an update).  Writes transform
+// (offset, scale) such that y = (in_scale*x - offset) * scale.
+// impl: 0 off, 1 mean_std, 2 std.
+__global__ void k_normalize_update(double* __restrict__ state, const double* __restrict__ sums,
+                                   double count, const float* __restrict__ in_scale_dev,
+                                   double decay, double maxv, int impl, int do_update,
+                                   float* __restrict__ out_off_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = in_scale_dev ? (double)*in_scale_dev : 1.0;
+  if (do_update) {
+    double mean = a * sums[0] / count, sq = a * a * sums[1] / count;
+    state[2] += 1.0;
+    state[0] = decay * state[0] + (1.0 - decay) * mean;
+    state[1] = decay * state[1] + (1.0 - decay) * sq;
+  }
+  double corr = 1.0 - pow(decay, state[2]);
+  double mean = state[0] / corr;
+  double var = state[1] / corr - mean * mean;
+  double scale;
+  if (maxv > 0.0) scale = 1.0 / sqrt(fmax(var, 1.0 / (maxv * maxv)));
+  else scale = 1.0 / sqrt(var);
+  float off = 0.f, sc = 1.f;
+  if (impl == 1) { off = (float)mean; sc = (float)scale; }
+  else if (impl == 2) { sc = (float)scale; }
+  out_off_scale[0] = off;
+  out_off_scale[1] = sc;
+}
+
+// dst[i] = a[i] * (b ? b[i] : 1) * c   (tiny scalar glue, n small)
+__global__ void k_scalar_mul(float* dst, const float* a, const float* b, float c, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = a[i] * (b ? b[i] : 1.f) * c;
+}
+
+// ---- optimizer ---------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sumsq_partial(const float* __restrict__ g, long n, double* __restrict__ partial) {
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = g[i];
+    s += (double)v * v;
+  }
+  s = wave_sum_d(s);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// opt_state: [0]=step (as double), [1]=grad norm, [2]=finite flag
+__global__ void k_norm_finalize(const double* __restrict__ partial, int P, double* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < P; ++i) s += partial[i];
+  double norm = sqrt(s);
+  st[1] = norm;
+  bool fin = isfinite(norm);
+  st[2] = fin ? 1.0 : 0.0;
+  if (fin) st[0] += 1.0;  // tfutils.py:260 (step advances only when applied)
+}
+
+// p *= (1 - wd*lr) for i < n_decay, then Adam with bias correction
+// (tfutils.py:271-283), gradient scaled by clip / max(norm, clip).
+__global__ void __launch_bounds__(256)
+k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+       float* __restrict__ v, long n, long n_decay, const double* __restrict__ st,
+       float lr, float wd, float eps, float b1, float b2, float clip) {
+  if (st[2] == 0.0) return;  // non-finite gradient norm: skip, host raises
+  const float norm = (float)st[1];
+  const float gs = clip > 0.f ? clip / fmaxf(norm, clip) : 1.f;
+  const float t = (float)st[0];
+  const float c1 = 1.f / (1.f - powf(b1, t)), c2 = 1.f / (1.f - powf(b2, t));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float gi = g[i] * gs;
+    float pi = p[i];
+    if (i < n_decay) pi *= (1.f - wd * lr);
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
+  }
+}
+
+// ---- data movement ------------------------------------------------------------
+__global__ void k_fill(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_copy2d(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd,
+                         long rows, int cols) {
+  long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cols; int c = (int)(i - r * cols);
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+
+// out = prev*(1-f) + init*f, f = first[row*fstride]  (init broadcast over rows;
+// prev may be null -> treated as zeros)
+__global__ void k_reset_mask(const float* __restrict__ prev, long ldp, const float* __restrict__ first,
+                             long fstride, const float* __restrict__ init, float* __restrict__ out,
+                             long ldo, long rows, int cols) {
+  long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cols; int c = (int)(i - r * cols);
+    float f = first[r * fstride];
+    float pv = prev ? prev[r * ldp + c] : 0.f;
+    float iv = init ? init[c] : 0.f;
+    out[r * ldo + c] = pv * (1.f - f) + iv * f;
+  }
+}
+
+// dprev += dout * (1 - f)
+__global__ void k_reset_mask_bwd(const float* __restrict__ dout, long ldo, const float* __restrict__ first,
+                                 long fstride, float* __restrict__ dprev, long ldp, long rows, int cols) {
+  long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cols; int c = (int)(i - r * cols);
+    dprev[r * ldp + c] += dout[r * ldo + c] * (1.f - first[r * fstride]);
+  }
+}
+
+// Batch preparation from the wire format: bool (u8) flags -> float.
+//   first_f = is_first, cont_f = 1 - is_terminal, act_masked = action*(1-is_first)
+__global__ void k_batch_prep(const unsigned char* __restrict__ is_first,
+                             const unsigned char* __restrict__ is_terminal,
+                             const float* __restrict__ action, float* __restrict__ first_f,
+                             float* __restrict__ cont_f, float* __restrict__ act_masked, long ldm,
+                             long n, int A) {
+  long total = n * (A > 0 ? A : 1);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / (A > 0 ? A : 1); int a = (int)(i - r * (A > 0 ? A : 1));
+    float f = is_first[r] ? 1.f : 0.f;
+    if (a == 0) { first_f[r] = f; cont_f[r] = is_terminal[r] ? 0.f : 1.f; }
+    if (A > 0) act_masked[r * ldm + a] = action[r * A + a] * (1.f - f);
+  }
+}
+
+// y = tanh(x) ; or dx = dy * (1 - tanh(x)^2) (accumulating)
+__global__ void k_tanh_fwd(const float* x, float* y, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = tanhf(x[i]);
+}
+__global__ void k_tanh_bwd(const float* x, const float* dy, float* dx, int n, float beta) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { float t = tanhf(x[i]); dx[i] = (beta != 0.f ? beta * dx[i] : 0.f) + dy[i] * (1.f - t * t); }
+}
+
+inline int gsz(long n, int t = 256, int cap = 4096) {
+  long b = (n + t - 1) / t;
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int dd_philox(float* out, long outer, long inner, int cols, long inner_global,
+                         long inner_offset, unsigned long long seed,
+                         const unsigned long long* step_dev, unsigned site, int kind, void* stream) {
+  long total = outer * inner * ((cols + 3) / 4);
+  if (total <= 0) return 0;
+  k_philox<<<gsz(total), 256, 0, (hipStream_t)stream>>>(out, outer, inner, cols, inner_global, inner_offset,
+      (uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32), step_dev, site, kind);
+  DD_CHECK_LAUNCH("dd_philox");
+  return 0;
+}
+
+extern "C" int dd_counter_add(unsigned long long* counter, unsigned long long v, void* stream) {
+  k_counter_add<<<1, 1, 0, (hipStream_t)stream>>>(counter, v);
+  DD_CHECK_LAUNCH("dd_counter_add");
+  return 0;
+}
+
+extern "C" int dd_reduce_stats(const float* x, long n, long stride, double* sums, float* maxs,
+                               void* stream) {
+  k_reduce_stats<<<1, 1024, 0, (hipStream_t)stream>>>(x, n, stride, sums, maxs);
+  DD_CHECK_LAUNCH("dd_reduce_stats");
+  return 0;
+}
+
+extern "C" int dd_autoadapt_update(float* scale, const double* sums, int n, double count,
+                                   float target, float thres, float vel, float lo, float hi,
+                                   int inverse, void* stream) {
+  k_autoadapt<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(scale, sums, n, count, target, thres, vel, lo, hi, inverse);
+  DD_CHECK_LAUNCH("dd_autoadapt_update");
+  return 0;
+}
+
+extern "C" int dd_normalize_update(double* state, const double* sums, double count,
+                                   const float* in_scale_dev, double decay, double maxv, int impl,
+                                   int do_update, float* out_off_scale, void* stream) {
+  k_normalize_update<<<1, 1, 0, (hipStream_t)stream>>>(state, sums, count, in_scale_dev, decay, maxv, impl, do_update, out_off_scale);
+  DD_CHECK_LAUNCH("dd_normalize_update");
+  return 0;
+}
+
+extern "C" int dd_scalar_mul(float* dst, const float* a, const float* b, float c, int n, void* stream) {
+  k_scalar_mul<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(dst, a, b, c, n);
+  DD_CHECK_LAUNCH("dd_scalar_mul");
+  return 0;
+}
+
+extern "C" int dd_grad_norm(const float* g, long n, double* opt_state, double* ws, size_t ws_bytes,
+                            void* stream) {
+  int P = gsz(n, 256, 1024);
+  DD_REQUIRE(ws && (size_t)P * sizeof(double) <= ws_bytes, "dd_grad_norm: workspace too small");
+  k_sumsq_partial<<<P, 256, 0, (hipStream_t)stream>>>(g, n, ws);
+  DD_CHECK_LAUNCH("dd_grad_norm");
+  k_norm_finalize<<<1, 1, 0, (hipStream_t)stream>>>(ws, P, opt_state);
+  DD_CHECK_LAUNCH("dd_grad_norm(finalize)");
+  return 0;
+}
+
+extern "C" int dd_adam_step(float* p, const float* g, float* m, float* v, long n, long n_decay,
+                            const double* opt_state, float lr, float wd, float eps, float b1,
+                            float b2, float clip, void* stream) {
+  if (n <= 0) return 0;
+  k_adam<<<gsz(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, n_decay, opt_state, lr, wd, eps, b1, b2, clip);
+  DD_CHECK_LAUNCH("dd_adam_step");
+  return 0;
+}
+
+extern "C" int dd_fill(float* p, long n, float v, void* stream) {
+  if (n <= 0) return 0;
+  k_fill<<<gsz(n), 256, 0, (hipStream_t)stream>>>(p, n, v);
+  DD_CHECK_LAUNCH("dd_fill");
+  return 0;
+}
+
+extern "C" int dd_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols,
+                         void* stream) {
+  if (rows * cols <= 0) return 0;
+  k_copy2d<<<gsz(rows * cols), 256, 0, (hipStream_t)stream>>>(src, lds, dst, ldd, rows, cols);
+  DD_CHECK_LAUNCH("dd_copy2d");
+  return 0;
+}
+
+extern "C" int dd_reset_mask(const float* prev, long ldp, const float* first, long fstride,
+                             const float* init, float* out, long ldo, long rows, int cols,
+                             void* stream) {
+  if (rows * cols <= 0) return 0;
+  k_reset_mask<<<gsz(rows * cols), 256, 0, (hipStream_t)stream>>>(prev, ldp, first, fstride, init, out, ldo, rows, cols);
+  DD_CHECK_LAUNCH("dd_reset_mask");
+  return 0;
+}
+
+extern "C" int dd_reset_mask_bwd(const float* dout, long ldo, const float* first, long fstride,
+                                 float* dprev, long ldp, long rows, int cols, void* stream) {
+  if (rows * cols <= 0) return 0;
+  k_reset_mask_bwd<<<gsz(rows * cols), 256, 0, (hipStream_t)stream>>>(dout, ldo, first, fstride, dprev, ldp, rows, cols);
+  DD_CHECK_LAUNCH("dd_reset_mask_bwd");
+  return 0;
+}
+
+extern "C" int dd_batch_prep(const unsigned char* is_first, const unsigned char* is_terminal,
+                             const float* action, float* first_f, float* cont_f,
+                             float* act_masked, long ldm, long n, int A, void* stream) {
+  if (n <= 0) return 0;
+  k_batch_prep<<<gsz(n * (A > 0 ? A : 1)), 256, 0, (hipStream_t)stream>>>(is_first, is_terminal, action, first_f, cont_f, act_masked, ldm, n, A);
+  DD_CHECK_LAUNCH("dd_batch_prep");
+  return 0;
+}
+
+extern "C" int dd_tanh_fwd(const float* x, float* y, int n, void* stream) {
+  k_tanh_fwd<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, y, n);
+  DD_CHECK_LAUNCH("dd_tanh_fwd");
+  return 0;
+}
+
+extern "C" int dd_tanh_bwd(const float* x, const float* dy, float* dx, int n, float beta, void* stream) {
+  k_tanh_bwd<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, dy, dx, n, beta);
+  DD_CHECK_LAUNCH("dd_tanh_bwd");
+  return 0;
+}

@@ -1,0 +1,28 @@
+import os
+import sys
+import pathlib
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+  sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+  config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def hip():
+  """The HIP backend on cuda:0; GPU tests fail loudly if it cannot load."""
+  import torch
+  from daydreamer_amd import hipops
+  assert torch.cuda.is_available(), 'gpu test collected without a GPU'
+  return hipops.HipOps('cuda:0')
+
+
+@pytest.fixture(scope='session')
+def ref():
+  from oracle import ref_ops
+  return ref_ops.RefOps('cpu')

@@ -1,0 +1,370 @@
+"""Per-kernel parity: every C-ABI entry point (through daydreamer_amd.hipops)
+against its CPU restatement oracle/ref_ops.py on the same seeded inputs.
+Tolerances: fp32 contractions 2e-4 relative to the output scale (different
+summation order), elementwise 1e-5; integer / one-hot outputs bit-exact."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+  g = torch.Generator().manual_seed(seed)
+  return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, rtol=2e-4, atol=None, what=''):
+  a = a.detach().cpu().double()
+  b = b.detach().cpu().double()
+  scale = float(b.abs().max()) + 1e-30
+  atol = rtol * scale if atol is None else atol
+  err = float((a - b).abs().max())
+  assert err <= atol, f'{what}: max err {err:.3e} > {atol:.3e} (scale {scale:.3e})'
+
+
+def both(hip, ref, fn, tensors, outs):
+  """Run fn(ops, *tensors) on both backends; tensors listed in `outs` (indices)
+  are compared afterwards."""
+  cpu = [t.clone() if torch.is_tensor(t) else t for t in tensors]
+  gpu = [t.cuda() if torch.is_tensor(t) else t for t in tensors]
+  fn(ref, *cpu)
+  fn(hip, *gpu)
+  torch.cuda.synchronize()
+  return [(gpu[i], cpu[i]) for i in outs]
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [
+    (50, 256, 1040, 0, 0), (2500, 512, 1280, 0, 0), (130, 70, 33, 0, 0),
+    (200, 300, 1000, 0, 1), (1280, 512, 4000, 1, 0), (7, 64, 50, 1, 0),
+    (96, 96, 96, 1, 1), (1, 256, 96, 1, 0), (300, 16, 512, 0, 0),
+    (64, 6, 30, 0, 1), (333, 129, 1030, 0, 0)])
+def test_gemm(hip, ref, M, N, K, ta, tb):
+  A = rnd(*((K, M) if ta else (M, K)), seed=1)
+  B = rnd(*((N, K) if tb else (K, N)), seed=2)
+  C = rnd(M, N, seed=3)
+  bias = rnd(N, seed=4)
+  for beta, bs in ((0.0, None), (1.0, bias)):
+    def fn(ops, A, B, C, bias):
+      ops.gemm(A, B, C, bool(ta), bool(tb), 0.5, beta, bias if bs is not None else None)
+    (g, c), = both(hip, ref, fn, [A, B, C, bias], [2])
+    close(g, c, what=f'gemm {M}x{N}x{K} ta{ta} tb{tb} beta{beta}')
+
+
+def test_gemm_views(hip, ref):
+  """Column slices of wider buffers as operands and output (ld != cols)."""
+  Abuf, Bbuf, Cbuf = rnd(100, 300, seed=1), rnd(80, 64, seed=2), rnd(100, 200, seed=3)
+  def fn(ops, Abuf, Bbuf, Cbuf):
+    ops.gemm(Abuf[:, 16:96], Bbuf[:, 8:40], Cbuf[:, 100:132], False, False, 1.0, 1.0)
+  (g, c), = both(hip, ref, fn, [Abuf, Bbuf, Cbuf], [2])
+  close(g, c, what='gemm views')
+  # unaligned leading dimension / odd offsets -> scalar loader path
+  Abuf, Bbuf, Cbuf = rnd(37, 103, seed=4), rnd(50, 31, seed=5), rnd(37, 31, seed=6)
+  def fn2(ops, Abuf, Bbuf, Cbuf):
+    ops.gemm(Abuf[:, 3:53], Bbuf, Cbuf, False, False, 1.0, 0.0)
+  (g, c), = both(hip, ref, fn2, [Abuf, Bbuf, Cbuf], [2])
+  close(g, c, what='gemm unaligned')
+
+
+CONVS = [  # n, hb, Cb, hs, Cs, k, u8
+    (3, 64, 3, 31, 16, 4, True), (3, 31, 16, 14, 32, 4, False),
+    (2, 14, 32, 6, 64, 4, False), (5, 6, 64, 2, 128, 4, False),
+    (4, 5, 64, 1, 320, 5, False), (3, 13, 32, 5, 64, 5, False),
+    (2, 30, 16, 13, 32, 6, False), (2, 64, 3, 30, 16, 6, False)]
+
+
+@pytest.mark.parametrize('n,hb,Cb,hs,Cs,k,u8', CONVS)
+def test_conv_down(hip, ref, n, hb, Cb, hs, Cs, k, u8):
+  if u8:
+    big = torch.randint(0, 256, (n, hb, hb, Cb), dtype=torch.uint8,
+                        generator=torch.Generator().manual_seed(1))
+  else:
+    big = rnd(n, hb, hb, Cb, seed=1)
+  w, bias, small = rnd(k, k, Cb, Cs, seed=2, scale=0.1), rnd(Cs, seed=3), torch.zeros(n, hs, hs, Cs)
+  def fn(ops, big, w, bias, small):
+    ops.conv_down(big, w, bias, small, k, 1.0 / 255.0 if u8 else 1.0)
+  (g, c), = both(hip, ref, fn, [big, w, bias, small], [3])
+  close(g, c, what='conv_down')
+
+
+@pytest.mark.parametrize('n,hb,Cb,hs,Cs,k,u8', CONVS)
+def test_conv_up(hip, ref, n, hb, Cb, hs, Cs, k, u8):
+  small, w, bias = rnd(n, hs, hs, Cs, seed=1), rnd(k, k, Cb, Cs, seed=2, scale=0.1), rnd(Cb, seed=3)
+  big = torch.full((n, hb, hb, Cb), 7.0)
+  def fn(ops, small, w, bias, big):
+    ops.conv_up(small, w, bias, big, k)
+  (g, c), = both(hip, ref, fn, [small, w, bias, big], [3])
+  close(g, c, what='conv_up')
+
+
+@pytest.mark.parametrize('n,hb,Cb,hs,Cs,k,u8', CONVS)
+def test_conv_wgrad(hip, ref, n, hb, Cb, hs, Cs, k, u8):
+  if u8:
+    big = torch.randint(0, 256, (n, hb, hb, Cb), dtype=torch.uint8,
+                        generator=torch.Generator().manual_seed(1))
+  else:
+    big = rnd(n, hb, hb, Cb, seed=1)
+  small, dw = rnd(n, hs, hs, Cs, seed=2), rnd(k, k, Cb, Cs, seed=3)
+  for beta in (0.0, 1.0):
+    def fn(ops, big, small, dw):
+      ops.conv_wgrad(big, small, dw, k, 1.0 / 255.0 if u8 else 1.0, beta)
+    (g, c), = both(hip, ref, fn, [big, small, dw], [2])
+    close(g, c, what=f'conv_wgrad beta{beta}')
+
+
+def test_conv_adjoint_large(hip):
+  """Size-independent property at full C2 layer size: <down(x), y> == <x, up(y)>
+  (the transposed conv is the exact adjoint of the conv)."""
+  n, hb, Cb, hs, Cs, k = 64, 31, 64, 14, 128, 4
+  x = rnd(n, hb, hb, Cb, seed=1).cuda()
+  y = rnd(n, hs, hs, Cs, seed=2).cuda()
+  w = rnd(k, k, Cb, Cs, seed=3, scale=0.1).cuda()
+  dx, dy = torch.empty_like(y), torch.empty_like(x)
+  hip.conv_down(x, w, None, dx, k)
+  hip.conv_up(y, w, None, dy, k)
+  a = float((dx.double() * y.double()).sum())
+  b = float((x.double() * dy.double()).sum())
+  assert abs(a - b) <= 1e-4 * max(abs(a), abs(b), 1.0), (a, b)
+
+
+@pytest.mark.parametrize('rows,C,act', [(50, 256, 1), (2500, 512, 1), (1000, 64, 1),
+                                        (77, 768, 0), (33, 40, 1), (9, 1500, 1), (300, 1024, 0)])
+def test_ln_act(hip, ref, rows, C, act):
+  z, gamma, beta = rnd(rows, C, seed=1, scale=2.0), 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+  out, stats, dout = torch.zeros(rows, C), torch.zeros(rows, 2), rnd(rows, C, seed=4)
+  dz, dg, db = torch.zeros(rows, C), rnd(C, seed=5), rnd(C, seed=6)
+  def fn(ops, z, gamma, beta, out, stats, dout, dz, dg, db):
+    ops.ln_act_fwd(z, gamma, beta, out, stats, bool(act))
+    ops.ln_act_bwd(dout, z, out, stats, gamma, dz, dg, db, True, bool(act))
+  res = both(hip, ref, fn, [z, gamma, beta, out, stats, dout, dz, dg, db], [3, 4, 6, 7, 8])
+  for (g, c), nm in zip(res, ['out', 'stats', 'dz', 'dgamma', 'dbeta']):
+    close(g, c, rtol=1e-4, what=f'ln {nm}')
+  dg2, db2 = torch.zeros(C), torch.zeros(C)
+  def fn2(ops, z, gamma, beta, out, stats, dout, dg2, db2):
+    ops.ln_act_fwd(z, gamma, beta, out, stats, bool(act))
+    ops.ln_param_grad(dout, z, out, stats, dg2, db2, False, bool(act))
+  res = both(hip, ref, fn2, [z, gamma, beta, out, stats, dout, dg2, db2], [6, 7])
+  for (g, c), nm in zip(res, ['dgamma', 'dbeta']):
+    close(g, c, rtol=1e-4, what=f'ln_param_grad {nm}')
+
+
+def test_ln_act_views(hip, ref):
+  buf, obuf = rnd(40, 600, seed=1), torch.zeros(40, 700)
+  gamma, beta, stats = 1 + 0.1 * rnd(256, seed=2), 0.1 * rnd(256, seed=3), torch.zeros(40, 2)
+  def fn(ops, buf, gamma, beta, obuf, stats):
+    ops.ln_act_fwd(buf[:, 100:356], gamma, beta, obuf[:, 256:512], stats, True)
+  (g, c), = both(hip, ref, fn, [buf, gamma, beta, obuf, stats], [3])
+  close(g, c, rtol=1e-5, what='ln views')
+
+
+@pytest.mark.parametrize('rows,D', [(50, 256), (2500, 256), (17, 64), (5, 1024), (9, 96)])
+def test_gru(hip, ref, rows, D):
+  z3, gamma, beta = rnd(rows, 3 * D, seed=1, scale=2.0), 1 + 0.1 * rnd(3 * D, seed=2), 0.1 * rnd(3 * D, seed=3)
+  h, hn, stats, dhn = rnd(rows, D, seed=4), torch.zeros(rows, D), torch.zeros(rows, 2), rnd(rows, D, seed=5)
+  dz3, dh, dy3 = torch.zeros(rows, 3 * D), torch.zeros(rows, D), torch.zeros(rows, 3 * D)
+  def fn(ops, z3, gamma, beta, h, hn, stats, dhn, dz3, dh, dy3):
+    ops.gru_fwd(z3, gamma, beta, h, hn, stats)
+    ops.gru_bwd(dhn, z3, stats, gamma, beta, h, dz3, dh, dy3)
+  res = both(hip, ref, fn, [z3, gamma, beta, h, hn, stats, dhn, dz3, dh, dy3], [4, 7, 8, 9])
+  for (g, c), nm in zip(res, ['hn', 'dz3', 'dh', 'dy3']):
+    close(g, c, rtol=1e-4, what=f'gru {nm}')
+
+
+@pytest.mark.parametrize('rows,G,C,unimix', [(50, 32, 32, 0.01), (2500, 32, 32, 0.01),
+                                             (96, 8, 8, 0.01), (10, 64, 64, 0.01), (40, 5, 12, 0.0)])
+def test_stats_sample(hip, ref, rows, G, C, unimix):
+  x = rnd(rows, G * C, seed=1, scale=2.0)
+  u = torch.rand(rows, G, generator=torch.Generator().manual_seed(2))
+  logit, wide = torch.zeros(rows, G * C), torch.zeros(rows, G * C + 40)
+  dlogit, dstoch, dx = rnd(rows, G * C, seed=3), rnd(rows, G * C, seed=4), torch.zeros(rows, G * C)
+  def fn(ops, x, u, logit, wide, dlogit, dstoch, dx):
+    ops.stats_fwd(x, u, logit, wide[:, 24:24 + G * C], G, C, unimix, 0)
+    ops.stats_bwd(x, dlogit, dstoch, dx, G, C, unimix)
+  res = both(hip, ref, fn, [x, u, logit, wide, dlogit, dstoch, dx], [2, 3, 6])
+  close(*res[0], rtol=1e-5, what='logit')
+  g, c = res[1]
+  # discrete draws: bit-exact except where u sits within float noise of a CDF edge
+  diff = (g.cpu() != c).reshape(rows, -1).any(-1)
+  assert int(diff.sum()) <= max(1, rows * G // 20000), f'{int(diff.sum())} rows differ'
+  assert float(g.sum()) == rows * G
+  close(*res[2], rtol=1e-4, what='dx')
+  # argmax mode
+  def fn2(ops, x, logit, wide):
+    ops.stats_fwd(x, None, logit, wide[:, 24:24 + G * C], G, C, unimix, 1)
+  res = both(hip, ref, fn2, [x, logit, wide], [2])
+  assert torch.equal(res[0][0].cpu(), res[0][1])
+
+
+def test_sampler_distribution(hip):
+  """Property at full size: empirical class frequencies match the unimixed
+  softmax probabilities."""
+  rows, G, C = 20000, 32, 32
+  x = rnd(1, G * C, seed=1).repeat(rows, 1).cuda()
+  u = torch.rand(rows, G, generator=torch.Generator().manual_seed(3)).cuda()
+  logit, st = torch.zeros(rows, G * C).cuda(), torch.zeros(rows, G * C).cuda()
+  hip.stats_fwd(x, u, logit, st, G, C, 0.01, 0)
+  freq = st.mean(0).cpu().double()
+  p = torch.exp(logit[0].cpu().double())
+  assert float((freq - p).abs().max()) < 5 * (0.25 / rows) ** 0.5
+
+
+@pytest.mark.parametrize('rows,G,C', [(50, 32, 32), (2500, 32, 32), (96, 8, 8), (10, 64, 64)])
+def test_kl(hip, ref, rows, G, C):
+  a = torch.log_softmax(rnd(rows, G, C, seed=1), -1).reshape(rows, G * C).contiguous()
+  b = torch.log_softmax(rnd(rows, G, C, seed=2), -1).reshape(rows, G * C).contiguous()
+  kl, ea, eb = torch.zeros(rows), torch.zeros(rows), torch.zeros(rows)
+  da, db, coef = torch.zeros(rows, G * C), torch.zeros(rows, G * C), torch.tensor([0.7])
+  def fn(ops, a, b, kl, ea, eb, da, db, coef):
+    ops.kl_fwd(a, b, kl, ea, eb, G, C)
+    ops.kl_bwd(a, b, coef, 1.0 / rows, 0.8, da, db, G, C)
+  res = both(hip, ref, fn, [a, b, kl, ea, eb, da, db, coef], [2, 3, 4, 5, 6])
+  for (g, c), nm in zip(res, ['kl', 'ent_post', 'ent_prior', 'dpost', 'dprior']):
+    close(g, c, rtol=1e-4, what=f'kl {nm}')
+
+
+def test_losses(hip, ref):
+  rows = 37
+  z = rnd(rows, 8, 8, 3, seed=1)
+  img = torch.randint(0, 256, (rows, 8, 8, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+  loss, dz = torch.zeros(rows), torch.zeros(rows, 8, 8, 3)
+  res = both(hip, ref, lambda ops, z, img, loss, dz: ops.image_loss(z, img, loss, dz, 0.01),
+             [z, img, loss, dz], [2, 3])
+  for g, c in res:
+    close(g, c, rtol=1e-5, what='image_loss')
+  pred, tgt, dp = rnd(rows, 19, seed=3), rnd(rows, 19, seed=4), torch.zeros(rows, 19)
+  res = both(hip, ref, lambda ops, pred, tgt, loss, dp: ops.mse_loss(pred, tgt, loss, dp, 0.3),
+             [pred, tgt, loss, dp], [2, 3])
+  for g, c in res:
+    close(g, c, rtol=1e-5, what='mse_loss')
+  for kind in (0, 1):
+    p1, t1 = rnd(1000, seed=5, scale=3.0), rnd(1000, seed=6, scale=3.0)
+    if kind == 1:
+      t1 = (t1 > 0).float()
+    l1, d1 = torch.zeros(1000), torch.zeros(1000)
+    res = both(hip, ref, lambda ops, p1, t1, l1, d1: ops.scalar_loss(p1, t1, l1, d1, 0.2, kind),
+               [p1, t1, l1, d1], [2, 3])
+    for g, c in res:
+      close(g, c, rtol=1e-5, what=f'scalar_loss {kind}')
+
+
+def test_normal_head(hip, ref):
+  rows, A, rows_ent = 400, 16, 300
+  om, os, eps = rnd(rows, A, seed=1), rnd(rows, A, seed=2), rnd(rows, A, seed=3)
+  act, dact, w = torch.zeros(rows, A + 8), rnd(rows, A, seed=4), torch.rand(rows)
+  scale, dom, dos, er = torch.rand(A), torch.zeros(rows, A), torch.zeros(rows, A), torch.zeros(rows)
+  lo, hi = 0.1, 1.0
+  ent_lo, ent_div = float(np.log(lo)), float(np.log(hi) - np.log(lo))
+  out = torch.zeros(2 * A, dtype=torch.float64)
+  def fn(ops, om, os, eps, act, dact, w, scale, dom, dos, er, out):
+    ops.normal_head_fwd(om, os, eps, act[:, 4:4 + A], lo, hi)
+    ops.normal_head_bwd(om, os, eps, dact, w, scale, dom, dos, er, rows_ent, lo, hi,
+                        1.0 / (rows_ent * ent_div), ent_lo, ent_div)
+    ops.actent_stats(os, rows_ent, lo, hi, ent_lo, ent_div, out)
+  res = both(hip, ref, fn, [om, os, eps, act, dact, w, scale, dom, dos, er, out], [3, 7, 8, 9, 10])
+  for (g, c), nm in zip(res, ['action', 'dom', 'dos', 'ent_row', 'actent']):
+    close(g, c, rtol=2e-5, what=f'normal_head {nm}')
+
+
+@pytest.mark.parametrize('H,N', [(15, 2500), (5, 256), (3, 7)])
+def test_imag_returns(hip, ref, H, N):
+  rr, vr, cr = rnd(H + 1, N, seed=1), rnd(H + 1, N, seed=2), rnd(H + 1, N, seed=3, scale=2.0) + 2
+  fc = (torch.rand(N) > 0.1).float()
+  reward, value, cont = torch.zeros(H, N), torch.zeros(H + 1, N), torch.zeros(H + 1, N)
+  weight, ret = torch.zeros(H + 1, N), torch.zeros(H, N)
+  dret, dbase = rnd(H, N, seed=4), rnd(H, N, seed=5)
+  drr, dvr, dcr = torch.zeros(H + 1, N), torch.zeros(H + 1, N), torch.zeros(H + 1, N)
+  def fn(ops, rr, vr, cr, fc, reward, value, cont, weight, ret, dret, dbase, drr, dvr, dcr):
+    ops.imag_returns_fwd(rr, vr, cr, fc, reward, value, cont, weight, ret, H, N, 0.995, 0.95)
+    ops.imag_returns_bwd(dret, dbase, rr, vr, cr, value, ret, drr, dvr, dcr, H, N, 0.995, 0.95)
+  res = both(hip, ref, fn, [rr, vr, cr, fc, reward, value, cont, weight, ret, dret, dbase, drr, dvr, dcr],
+             [4, 5, 6, 7, 8, 11, 12, 13])
+  for (g, c), nm in zip(res, ['reward', 'value', 'cont', 'weight', 'ret', 'drr', 'dvr', 'dcr']):
+    close(g, c, rtol=2e-5, what=f'imag_returns {nm}')
+
+
+def test_critic_actor_seed(hip, ref):
+  H, N = 5, 300
+  out, ret, w = rnd(H, N, seed=1), rnd(H, N, seed=2, scale=3.0), torch.rand(H + 1, N)
+  loss, dout = torch.zeros(H, N), torch.zeros(H, N)
+  res = both(hip, ref, lambda ops, out, ret, w, loss, dout: ops.critic_loss(out, ret, w, loss, dout, 0.1),
+             [out, ret, w, loss, dout], [3, 4])
+  for g, c in res:
+    close(g, c, rtol=1e-5, what='critic_loss')
+  base, er, sc = rnd(H + 1, N, seed=3), rnd(H + 1, N, seed=4), torch.tensor([1.3, 0.2, 0.7])
+  dret, dbase = torch.zeros(H, N), torch.zeros(H, N)
+  res = both(hip, ref, lambda ops, ret, base, w, er, sc, loss, dret, dbase:
+             ops.actor_seed(ret, base, w, er, sc, loss, dret, dbase, 0.01),
+             [ret, base, w, er, sc, loss, dret, dbase], [5, 6, 7])
+  for g, c in res:
+    close(g, c, rtol=1e-5, what='actor_seed')
+
+
+def test_philox(hip, ref):
+  step = torch.tensor([12345], dtype=torch.int64)
+  for kind, cols in ((0, 32), (1, 16), (0, 7), (1, 6)):
+    out = torch.zeros(3, 50, cols)
+    res = both(hip, ref, lambda ops, out, step: ops.philox(out, 3, 50, cols, 80, 30, 0x1234567890, step, 5, kind),
+               [out, step], [0])
+    g, c = res[0]
+    if kind == 0:
+      assert torch.equal(g.cpu(), c), 'philox uniforms must be bit-exact'
+    else:
+      close(g, c, rtol=1e-5, atol=2e-5, what='philox normal')
+  # sharding invariance: rows [30,80) of the global field equal a shard with offset 30
+  full, shard = torch.zeros(3, 80, 32).cuda(), torch.zeros(3, 50, 32).cuda()
+  hip.philox(full, 3, 80, 32, 80, 0, 7, step.cuda(), 1, 0)
+  hip.philox(shard, 3, 50, 32, 80, 30, 7, step.cuda(), 1, 0)
+  assert torch.equal(full[:, 30:], shard)
+
+
+def test_state_kernels(hip, ref):
+  x = rnd(40000, seed=1)
+  sums, maxs = torch.zeros(3, dtype=torch.float64), torch.zeros(3)
+  res = both(hip, ref, lambda ops, x, sums, maxs: ops.reduce_stats(x, sums, maxs), [x, sums, maxs], [1, 2])
+  close(*res[0], rtol=1e-9, what='reduce sums')
+  close(*res[1], rtol=0, atol=0, what='reduce maxs')
+  xs = rnd(300, 7, seed=2)
+  res = both(hip, ref, lambda ops, xs, sums, maxs: ops.reduce_stats(xs[:, 3], sums, maxs), [xs, sums, maxs], [1, 2])
+  close(*res[0], rtol=1e-9, what='reduce strided')
+  # optimizer
+  n, nd = 100000, 60000
+  p, g, m, v = rnd(n, seed=3), rnd(n, seed=4, scale=5.0), rnd(n, seed=5).abs() * 0.1, rnd(n, seed=6).abs() * 0.1
+  st = torch.tensor([3.0, 0.0, 0.0], dtype=torch.float64)
+  def fn(ops, p, g, m, v, st):
+    ops.grad_norm(g, st)
+    ops.adam_step(p, g, m, v, nd, st, 1e-3, 1e-2, 1e-6, 0.9, 0.999, 100.0)
+  res = both(hip, ref, fn, [p, g, m, v, st], [0, 2, 3, 4])
+  for (a, b), nm in zip(res, ['p', 'm', 'v', 'state']):
+    close(a, b, rtol=1e-5, what=f'adam {nm}')
+  # autoadapt + normalize
+  scale, s2 = torch.tensor([1.0, 0.5, 0.02]), torch.tensor([30.0, 5.0, 10.0], dtype=torch.float64)
+  res = both(hip, ref, lambda ops, scale, s2: ops.autoadapt_update(scale, s2, 10.0, 1.0, 0.1, 0.1, 1e-3, 1.0, True),
+             [scale, s2], [0])
+  close(*res[0], rtol=1e-6, what='autoadapt')
+  state, sm, outv = torch.tensor([0.1, 0.5, 3.0], dtype=torch.float64), torch.tensor([20.0, 90.0, 0.0], dtype=torch.float64), torch.zeros(2)
+  insc = torch.tensor([1.5])
+  res = both(hip, ref, lambda ops, state, sm, insc, outv: ops.normalize_update(state, sm, 50.0, insc, 0.99, 1e8, 1, True, outv),
+             [state, sm, insc, outv], [0, 3])
+  close(*res[0], rtol=1e-12, what='normalize state')
+  close(*res[1], rtol=1e-6, what='normalize out')
+
+
+def test_misc(hip, ref):
+  prev, first, init, out = rnd(20, 64, seed=1), (torch.rand(20, 5) > 0.5).float(), rnd(64, seed=2), torch.zeros(20, 100)
+  dprev = rnd(20, 64, seed=3)
+  def fn(ops, prev, first, init, out, dprev):
+    ops.reset_mask(prev, first[:, 2], init, out[:, 10:74])
+    ops.reset_mask_bwd(out[:, 10:74], first[:, 2], dprev)
+  res = both(hip, ref, fn, [prev, first, init, out, dprev], [3, 4])
+  for g, c in res:
+    close(g, c, rtol=1e-6, what='reset_mask')
+  isf, ist = torch.rand(6, 9) > 0.7, torch.rand(6, 9) > 0.8
+  act, ff, cf, am = rnd(6, 9, 5, seed=4), torch.zeros(6, 9), torch.zeros(6, 9), torch.zeros(54, 12)
+  res = both(hip, ref, lambda ops, isf, ist, act, ff, cf, am: ops.batch_prep(isf, ist, act, ff, cf, am[:, 7:12]),
+             [isf, ist, act, ff, cf, am], [3, 4, 5])
+  for g, c in res:
+    close(g, c, rtol=0, atol=0, what='batch_prep')
+  x, dy, dx = rnd(256, seed=5), rnd(256, seed=6), rnd(256, seed=7)
+  res = both(hip, ref, lambda ops, x, dy, dx: ops.tanh_bwd(x, dy, dx, 1.0), [x, dy, dx], [2])
+  close(*res[0], rtol=1e-5, what='tanh_bwd')

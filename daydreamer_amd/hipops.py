@@ -1,0 +1,456 @@
+"""ctypes binding of libdaydreamer_hip.so (include/daydreamer_hip.h).
+
+`HipOps` is the only compute backend of the learner: every method launches a
+hand-written gfx950 kernel on torch's current HIP stream.  PyTorch is used for
+device memory and streams only.  There is no CPU or eager fallback: if the
+shared library is missing or no GPU is visible, construction raises.
+
+Tensors are passed as torch tensors; 2-D arguments may be column slices of
+wider buffers (stride(1) == 1, stride(0) = leading dimension).
+"""
+
+import ctypes
+import pathlib
+
+import torch
+
+_LIB_PATH = pathlib.Path(__file__).parent / 'libdaydreamer_hip.so'
+_lib = None
+
+c_f = ctypes.c_float
+c_d = ctypes.c_double
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_p = ctypes.c_void_p
+c_z = ctypes.c_size_t
+c_u = ctypes.c_uint
+c_ull = ctypes.c_ulonglong
+
+_SIGS = {
+    'dd_gemm_f32': [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p, c_p, c_z, c_p],
+    'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
+    'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
+    'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_p],
+    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
+    'dd_ln_bwd_parts': [c_i, c_i],
+    'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
+    'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p],
+    'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
+    'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
+    'dd_cat_kl_fwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    'dd_cat_kl_bwd': [c_p, c_l, c_p, c_l, c_p, c_f, c_f, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    'dd_image_loss': [c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_p],
+    'dd_mse_loss': [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
+    'dd_scalar_loss': [c_p, c_p, c_p, c_p, c_l, c_f, c_i, c_p],
+    'dd_normal_head_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_f, c_p],
+    'dd_normal_head_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p],
+    'dd_actent_stats': [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p],
+    'dd_imag_returns_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_p],
+    'dd_imag_returns_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_p],
+    'dd_critic_loss': [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
+    'dd_actor_seed': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
+    'dd_sub': [c_p, c_p, c_p, c_l, c_p],
+    'dd_philox': [c_p, c_l, c_l, c_i, c_l, c_l, c_ull, c_p, c_u, c_i, c_p],
+    'dd_counter_add': [c_p, c_ull, c_p],
+    'dd_reduce_stats': [c_p, c_l, c_l, c_p, c_p, c_p],
+    'dd_autoadapt_update': [c_p, c_p, c_i, c_d, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
+    'dd_normalize_update': [c_p, c_p, c_d, c_p, c_d, c_d, c_i, c_i, c_p, c_p],
+    'dd_scalar_mul': [c_p, c_p, c_p, c_f, c_i, c_p],
+    'dd_grad_norm': [c_p, c_l, c_p, c_p, c_z, c_p],
+    'dd_adam_step': [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
+    'dd_fill': [c_p, c_l, c_f, c_p],
+    'dd_copy2d': [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
+    'dd_reset_mask': [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_l, c_i, c_p],
+    'dd_reset_mask_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p],
+    'dd_batch_prep': [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_p],
+    'dd_tanh_fwd': [c_p, c_p, c_i, c_p],
+    'dd_tanh_bwd': [c_p, c_p, c_p, c_i, c_f, c_p],
+}
+
+EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
+
+
+def load_library():
+  """Load the shared library and declare prototypes.  Raises if missing."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not _LIB_PATH.exists():
+    raise RuntimeError(
+        f'{_LIB_PATH} not found: build it with __graft_entry__.build() '
+        f'(make -C daydreamer_amd/csrc).  There is no fallback path.')
+  lib = ctypes.CDLL(str(_LIB_PATH))
+  for name, args in _SIGS.items():
+    fn = getattr(lib, name)
+    fn.argtypes = args
+    fn.restype = c_i
+  lib.dd_version.restype = c_i
+  lib.dd_last_error.restype = ctypes.c_char_p
+  _lib = lib
+  return lib
+
+
+def _ptr(t):
+  return 0 if t is None else t.data_ptr()
+
+
+def _mat(t):
+  """(ptr, ld) of a row-major 2-D view."""
+  assert t.dim() == 2, t.shape
+  assert t.shape[1] == 1 or t.stride(1) == 1, (t.shape, t.stride())
+  ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+  return t.data_ptr(), ld
+
+
+def _vec(t):
+  """(ptr, stride) of a 1-D view."""
+  assert t.dim() == 1, t.shape
+  return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else 1)
+
+
+class HipOps:
+
+  name = 'hip'
+
+  def __init__(self, device='cuda:0', ws_bytes=512 << 20):
+    if not torch.cuda.is_available():
+      raise RuntimeError('HipOps needs a visible MI355X (no CPU fallback).')
+    self.lib = load_library()
+    self.device = torch.device(device)
+    self.ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=self.device)
+    self.ws_bytes = ws_bytes
+
+  @property
+  def stream(self):
+    return torch.cuda.current_stream(self.device).cuda_stream
+
+  def _check(self, rc, name):
+    if rc != 0:
+      raise RuntimeError(
+          f'{name} failed ({rc}): {self.lib.dd_last_error().decode()}')
+
+  # ---- contractions ---------------------------------------------------------
+
+  def gemm(self, A, B, C, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
+    M, N = C.shape
+    K = A.shape[0] if ta else A.shape[1]
+    assert (A.shape[1] if ta else A.shape[0]) == M, (A.shape, C.shape, ta)
+    assert (B.shape == (N, K)) if tb else (B.shape == (K, N)), (B.shape, K, N, tb)
+    a, lda = _mat(A)
+    b, ldb = _mat(B)
+    c, ldc = _mat(C)
+    self._check(self.lib.dd_gemm_f32(
+        a, b, c, M, N, K, lda, ldb, ldc, int(ta), int(tb), alpha, beta,
+        _ptr(bias), self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_gemm_f32')
+
+  def conv_down(self, big, w, bias, small, k, in_scale=1.0):
+    n, hb, wb, cb = big.shape
+    n2, hs, ws, cs = small.shape
+    assert n == n2 and big.is_contiguous() and small.is_contiguous()
+    assert tuple(w.shape) == (k, k, cb, cs) and w.is_contiguous()
+    self._check(self.lib.dd_conv2d_s2_down(
+        big.data_ptr(), int(big.dtype == torch.uint8), w.data_ptr(), _ptr(bias),
+        small.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale,
+        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_conv2d_s2_down')
+
+  def conv_up(self, small, w, bias, big, k):
+    n, hs, ws, cs = small.shape
+    n2, hb, wb, cb = big.shape
+    assert n == n2 and big.is_contiguous() and small.is_contiguous()
+    assert tuple(w.shape) == (k, k, cb, cs) and w.is_contiguous()
+    self._check(self.lib.dd_conv2d_s2_up(
+        small.data_ptr(), w.data_ptr(), _ptr(bias), big.data_ptr(),
+        n, hs, ws, cs, hb, wb, cb, k, self.stream), 'dd_conv2d_s2_up')
+
+  def conv_wgrad(self, big, small, dw, k, in_scale=1.0, beta=0.0):
+    n, hb, wb, cb = big.shape
+    n2, hs, ws, cs = small.shape
+    assert n == n2 and big.is_contiguous() and small.is_contiguous()
+    assert tuple(dw.shape) == (k, k, cb, cs) and dw.is_contiguous()
+    self._check(self.lib.dd_conv2d_s2_wgrad(
+        big.data_ptr(), int(big.dtype == torch.uint8), small.data_ptr(),
+        dw.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale, beta,
+        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_conv2d_s2_wgrad')
+
+  # ---- LayerNorm / GRU -------------------------------------------------------
+
+  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True):
+    rows, C = z.shape
+    zp, ldz = _mat(z)
+    op, ldo = _mat(out)
+    self._check(self.lib.dd_ln_act_fwd(
+        zp, ldz, gamma.data_ptr(), beta.data_ptr(), op, ldo, stats.data_ptr(),
+        rows, C, int(act), self.stream), 'dd_ln_act_fwd')
+
+  def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
+                 dbeta=None, accumulate=False, act=True):
+    rows, C = z.shape
+    dp, ldd = _mat(dout)
+    zp, ldz = _mat(z)
+    op, ldo = _mat(out)
+    dzp, lddz = _mat(dz)
+    self._check(self.lib.dd_ln_act_bwd(
+        dp, ldd, zp, ldz, op, ldo, stats.data_ptr(), gamma.data_ptr(), dzp,
+        lddz, _ptr(dgamma), _ptr(dbeta), int(accumulate), rows, C, int(act),
+        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_ln_act_bwd')
+
+  def ln_param_grad(self, dout, z, out, stats, dgamma, dbeta,
+                    accumulate=False, act=True):
+    rows, C = z.shape
+    dp, ldd = _mat(dout)
+    zp, ldz = _mat(z)
+    op, ldo = _mat(out) if out is not None else (0, 0)
+    self._check(self.lib.dd_ln_param_grad(
+        dp, ldd, zp, ldz, op, ldo, stats.data_ptr(), dgamma.data_ptr(),
+        dbeta.data_ptr(), int(accumulate), rows, C, int(act),
+        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_ln_param_grad')
+
+  def gru_fwd(self, z3, gamma, beta, h, hn, stats):
+    rows, D = h.shape
+    zp, ldz = _mat(z3)
+    hp, ldh = _mat(h)
+    np_, ldn = _mat(hn)
+    self._check(self.lib.dd_gru_cell_fwd(
+        zp, ldz, gamma.data_ptr(), beta.data_ptr(), hp, ldh, np_, ldn,
+        stats.data_ptr(), rows, D, self.stream), 'dd_gru_cell_fwd')
+
+  def gru_bwd(self, dhn, z3, stats, gamma, beta, h, dz3, dh, dy3):
+    rows, D = h.shape
+    a, lda = _mat(dhn)
+    zp, ldz = _mat(z3)
+    hp, ldh = _mat(h)
+    dzp, lddz = _mat(dz3)
+    dhp, lddh = _mat(dh)
+    dyp, lddy = _mat(dy3)
+    self._check(self.lib.dd_gru_cell_bwd(
+        a, lda, zp, ldz, stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+        hp, ldh, dzp, lddz, dhp, lddh, dyp, lddy, rows, D, self.stream),
+        'dd_gru_cell_bwd')
+
+  # ---- categorical latent -----------------------------------------------------
+
+  def stats_fwd(self, x, u, logit, stoch, G, C, unimix, mode=0):
+    rows = x.shape[0]
+    xp, ldx = _mat(x)
+    up, ldu = _mat(u) if u is not None else (0, 0)
+    lp, ldl = _mat(logit)
+    sp, lds = _mat(stoch)
+    self._check(self.lib.dd_stats_sample_fwd(
+        xp, ldx, up, ldu, lp, ldl, sp, lds, rows, G, C, unimix, mode,
+        self.stream), 'dd_stats_sample_fwd')
+
+  def stats_bwd(self, x, dlogit, dstoch, dx, G, C, unimix):
+    rows = x.shape[0]
+    xp, ldx = _mat(x)
+    lp, ldl = _mat(dlogit) if dlogit is not None else (0, 0)
+    sp, lds = _mat(dstoch) if dstoch is not None else (0, 0)
+    dp, ldd = _mat(dx)
+    self._check(self.lib.dd_stats_sample_bwd(
+        xp, ldx, lp, ldl, sp, lds, dp, ldd, rows, G, C, unimix, self.stream),
+        'dd_stats_sample_bwd')
+
+  def kl_fwd(self, post, prior, kl, ent_post, ent_prior, G, C):
+    rows = post.shape[0]
+    pp, ldp = _mat(post)
+    qp, ldq = _mat(prior)
+    self._check(self.lib.dd_cat_kl_fwd(
+        pp, ldp, qp, ldq, kl.data_ptr(), ent_post.data_ptr(),
+        ent_prior.data_ptr(), rows, G, C, self.stream), 'dd_cat_kl_fwd')
+
+  def kl_bwd(self, post, prior, coef_dev, coef_host, balance, dpost, dprior,
+             G, C):
+    rows = post.shape[0]
+    pp, ldp = _mat(post)
+    qp, ldq = _mat(prior)
+    dp, lddp = _mat(dpost)
+    dq, lddq = _mat(dprior)
+    self._check(self.lib.dd_cat_kl_bwd(
+        pp, ldp, qp, ldq, _ptr(coef_dev), coef_host, balance, dp, lddp, dq,
+        lddq, rows, G, C, self.stream), 'dd_cat_kl_bwd')
+
+  # ---- losses / imagination scalars -------------------------------------------
+
+  def image_loss(self, z, img, loss, dz, coef):
+    rows = z.shape[0]
+    P = z[0].numel()
+    assert z.is_contiguous() and img.is_contiguous() and img.dtype == torch.uint8
+    self._check(self.lib.dd_image_loss(
+        z.data_ptr(), img.data_ptr(), loss.data_ptr(), dz.data_ptr(), rows, P,
+        coef, self.stream), 'dd_image_loss')
+
+  def mse_loss(self, pred, tgt, loss, dpred, coef):
+    rows, D = pred.shape
+    pp, ldp = _mat(pred)
+    tp, ldt = _mat(tgt)
+    dp, ldd = _mat(dpred)
+    self._check(self.lib.dd_mse_loss(
+        pp, ldp, tp, ldt, loss.data_ptr(), dp, ldd, rows, D, coef,
+        self.stream), 'dd_mse_loss')
+
+  def scalar_loss(self, pred, tgt, loss, dpred, coef, kind):
+    n = pred.numel()
+    assert pred.is_contiguous() and tgt.is_contiguous()
+    self._check(self.lib.dd_scalar_loss(
+        pred.data_ptr(), tgt.data_ptr(), loss.data_ptr(), dpred.data_ptr(), n,
+        coef, kind, self.stream), 'dd_scalar_loss')
+
+  def normal_head_fwd(self, om, os, eps, act, lo, hi):
+    rows, A = om.shape
+    a, lda = _mat(om)
+    b, ldb = _mat(os)
+    e, lde = _mat(eps) if eps is not None else (0, 0)
+    c, ldc = _mat(act)
+    self._check(self.lib.dd_normal_head_fwd(
+        a, lda, b, ldb, e, lde, c, ldc, rows, A, lo, hi, self.stream),
+        'dd_normal_head_fwd')
+
+  def normal_head_bwd(self, om, os, eps, dact, w, scale, dom, dos, ent_row,
+                      rows_ent, lo, hi, ent_coef, ent_lo, ent_div):
+    rows, A = om.shape
+    a, lda = _mat(om)
+    b, ldb = _mat(os)
+    e, lde = _mat(eps)
+    d, ldd = _mat(dact) if dact is not None else (0, 0)
+    m, ldm = _mat(dom)
+    s, lds = _mat(dos)
+    self._check(self.lib.dd_normal_head_bwd(
+        a, lda, b, ldb, e, lde, d, ldd, _ptr(w), _ptr(scale), m, ldm, s, lds,
+        _ptr(ent_row), rows, rows_ent, A, lo, hi, ent_coef, ent_lo, ent_div,
+        self.stream), 'dd_normal_head_bwd')
+
+  def actent_stats(self, os, rows, lo, hi, ent_lo, ent_div, out):
+    b, ldb = _mat(os)
+    self._check(self.lib.dd_actent_stats(
+        b, ldb, rows, os.shape[1], lo, hi, ent_lo, ent_div, out.data_ptr(),
+        self.stream), 'dd_actent_stats')
+
+  def imag_returns_fwd(self, rew_raw, val_raw, cont_raw, first_cont, reward,
+                       value, cont, weight, ret, H, N, gamma, lam):
+    self._check(self.lib.dd_imag_returns_fwd(
+        rew_raw.data_ptr(), val_raw.data_ptr(), cont_raw.data_ptr(),
+        first_cont.data_ptr(), reward.data_ptr(), value.data_ptr(),
+        _ptr(cont), _ptr(weight), ret.data_ptr(), H, N, gamma, lam,
+        self.stream), 'dd_imag_returns_fwd')
+
+  def imag_returns_bwd(self, dret, dbase, rew_raw, val_raw, cont_raw, value,
+                       ret, d_rew_raw, d_val_raw, d_cont_raw, H, N, gamma, lam):
+    self._check(self.lib.dd_imag_returns_bwd(
+        dret.data_ptr(), _ptr(dbase), rew_raw.data_ptr(), val_raw.data_ptr(),
+        cont_raw.data_ptr(), value.data_ptr(), ret.data_ptr(),
+        d_rew_raw.data_ptr(), d_val_raw.data_ptr(), d_cont_raw.data_ptr(), H,
+        N, gamma, lam, self.stream), 'dd_imag_returns_bwd')
+
+  def critic_loss(self, out, ret, w, loss, dout, coef):
+    self._check(self.lib.dd_critic_loss(
+        out.data_ptr(), ret.data_ptr(), w.data_ptr(), loss.data_ptr(),
+        dout.data_ptr(), out.numel(), coef, self.stream), 'dd_critic_loss')
+
+  def actor_seed(self, ret, base, w, ent_row, sc, loss, dret, dbase, coef):
+    self._check(self.lib.dd_actor_seed(
+        ret.data_ptr(), base.data_ptr(), w.data_ptr(), _ptr(ent_row),
+        sc.data_ptr(), loss.data_ptr(), dret.data_ptr(), dbase.data_ptr(),
+        ret.numel(), coef, self.stream), 'dd_actor_seed')
+
+  def sub(self, a, b, o):
+    self._check(self.lib.dd_sub(
+        a.data_ptr(), b.data_ptr(), o.data_ptr(), o.numel(), self.stream),
+        'dd_sub')
+
+  # ---- learner state ---------------------------------------------------------------
+
+  def philox(self, out, outer, inner, cols, inner_global, inner_offset, seed,
+             step_dev, site, kind):
+    assert out.is_contiguous() and out.numel() == outer * inner * cols
+    self._check(self.lib.dd_philox(
+        out.data_ptr(), outer, inner, cols, inner_global, inner_offset, seed,
+        step_dev.data_ptr(), site, kind, self.stream), 'dd_philox')
+
+  def counter_add(self, counter, v=1):
+    self._check(self.lib.dd_counter_add(counter.data_ptr(), v, self.stream),
+                'dd_counter_add')
+
+  def reduce_stats(self, x, sums, maxs):
+    p, stride = _vec(x)
+    self._check(self.lib.dd_reduce_stats(
+        p, x.shape[0], stride, sums.data_ptr(), maxs.data_ptr(), self.stream),
+        'dd_reduce_stats')
+
+  def autoadapt_update(self, scale, sums, count, target, thres, vel, lo, hi,
+                       inverse):
+    self._check(self.lib.dd_autoadapt_update(
+        scale.data_ptr(), sums.data_ptr(), scale.numel(), count, target, thres,
+        vel, lo, hi, int(inverse), self.stream), 'dd_autoadapt_update')
+
+  def normalize_update(self, state, sums, count, in_scale_dev, decay, maxv,
+                       impl, do_update, out):
+    self._check(self.lib.dd_normalize_update(
+        state.data_ptr(), sums.data_ptr(), count, _ptr(in_scale_dev), decay,
+        maxv, impl, int(do_update), out.data_ptr(), self.stream),
+        'dd_normalize_update')
+
+  def scalar_mul(self, dst, a, b, c):
+    self._check(self.lib.dd_scalar_mul(
+        dst.data_ptr(), a.data_ptr(), _ptr(b), c, dst.numel(), self.stream),
+        'dd_scalar_mul')
+
+  def grad_norm(self, g, opt_state):
+    self._check(self.lib.dd_grad_norm(
+        g.data_ptr(), g.numel(), opt_state.data_ptr(), self.ws.data_ptr(),
+        self.ws_bytes, self.stream), 'dd_grad_norm')
+
+  def adam_step(self, p, g, m, v, n_decay, opt_state, lr, wd, eps, b1, b2,
+                clip):
+    self._check(self.lib.dd_adam_step(
+        p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+        n_decay, opt_state.data_ptr(), lr, wd, eps, b1, b2, clip, self.stream),
+        'dd_adam_step')
+
+  def fill(self, t, v=0.0):
+    assert t.is_contiguous()
+    self._check(self.lib.dd_fill(t.data_ptr(), t.numel(), v, self.stream),
+                'dd_fill')
+
+  def copy2d(self, src, dst):
+    rows, cols = src.shape
+    s, lds = _mat(src)
+    d, ldd = _mat(dst)
+    self._check(self.lib.dd_copy2d(s, lds, d, ldd, rows, cols, self.stream),
+                'dd_copy2d')
+
+  def reset_mask(self, prev, first, init, out):
+    rows, cols = out.shape
+    p, ldp = _mat(prev) if prev is not None else (0, 0)
+    f, fs = _vec(first)
+    o, ldo = _mat(out)
+    self._check(self.lib.dd_reset_mask(
+        p, ldp, f, fs, _ptr(init), o, ldo, rows, cols, self.stream),
+        'dd_reset_mask')
+
+  def reset_mask_bwd(self, dout, first, dprev):
+    rows, cols = dout.shape
+    d, ldo = _mat(dout)
+    f, fs = _vec(first)
+    p, ldp = _mat(dprev)
+    self._check(self.lib.dd_reset_mask_bwd(
+        d, ldo, f, fs, p, ldp, rows, cols, self.stream), 'dd_reset_mask_bwd')
+
+  def batch_prep(self, is_first, is_terminal, action, first_f, cont_f,
+                 act_masked):
+    n = is_first.numel()
+    A = action.shape[-1]
+    m, ldm = _mat(act_masked)
+    self._check(self.lib.dd_batch_prep(
+        is_first.data_ptr(), is_terminal.data_ptr(), action.data_ptr(),
+        first_f.data_ptr(), cont_f.data_ptr(), m, ldm, n, A, self.stream),
+        'dd_batch_prep')
+
+  def tanh_fwd(self, x, y):
+    self._check(self.lib.dd_tanh_fwd(x.data_ptr(), y.data_ptr(), x.numel(),
+                                     self.stream), 'dd_tanh_fwd')
+
+  def tanh_bwd(self, x, dy, dx, beta=0.0):
+    self._check(self.lib.dd_tanh_bwd(
+        x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), beta,
+        self.stream), 'dd_tanh_bwd')

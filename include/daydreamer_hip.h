@@ -1,0 +1,197 @@
+/* C ABI of libdaydreamer_hip.so: the MI355X (gfx950) kernels behind the
+ * DreamerV2+ learner step.
+ *
+ * The reference (danijar/daydreamer) has no FFI on this path: its learner is
+ * Python (embodied/agents/dreamerv2plus/{agent,nets,tfutils}.py) whose
+ * arithmetic is TensorFlow/XLA ops.  Each entry point below replaces the TF
+ * op(s) cited next to it; a maintainer binds them with ctypes (see
+ * INTEGRATION.md).  Paths are relative to embodied/agents/dreamerv2plus/.
+ *
+ * Conventions: every function returns 0 on success or a non-zero HIP / -1
+ * argument error (text via dd_last_error()); all pointers are DEVICE pointers
+ * to fp32 unless noted; matrices are row-major with an explicit leading
+ * dimension `ld*` (in elements) so column slices of wider buffers can be
+ * passed without copies; the caller owns all memory including the `ws`
+ * scratch workspace; nothing synchronises; `stream` is a hipStream_t (may be
+ * a capturing stream).
+ */
+#ifndef DAYDREAMER_HIP_H_
+#define DAYDREAMER_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int dd_version(void);
+const char* dd_last_error(void);
+
+/* ---- dense / conv contractions (MFMA fp32) -------------------------------- */
+
+/* C[M,N] = alpha * op(A) @ op(B) + beta * C + bias[N]   (bias may be NULL)
+ * op(A) is A[M,K] (transA=0) or A stored [K,M] (transA=1); likewise B [K,N] /
+ * stored [N,K].  Replaces `x @ kernel (+ bias)` nets.py:573-579 and its
+ * gradients taken by GradientTape, tfutils.py:214.  ws: split-K scratch. */
+int dd_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
+                long lda, long ldb, long ldc, int transA, int transB,
+                float alpha, float beta, const float* bias,
+                float* ws, size_t ws_bytes, void* stream);
+
+/* Stride-2 VALID convolution family over NHWC tensors.  "big" is the
+ * full-resolution side [n,hb,wb,Cb], "small" the downsampled side
+ * [n,hs,ws,Cs], filter w[k,k,Cb,Cs] (= tf.nn.conv2d's [kh,kw,in,out] for the
+ * encoder, tf.nn.conv2d_transpose's [kh,kw,out,in] for the decoder).
+ *   down : small = conv(big) (+bias[Cs])     tf.nn.conv2d nets.py:547 (encoder
+ *          forward) and the input-gradient of conv2d_transpose (decoder bwd)
+ *   up   : big = conv^T(small) (+bias[Cb])   tf.nn.conv2d_transpose nets.py:539
+ *          (decoder forward) and the input-gradient of conv2d (encoder bwd)
+ *   wgrad: dw = beta*dw + sum big (x) small  filter gradient of both
+ * big may be uint8 (big_is_u8=1, values scaled by in_scale: the `/255`
+ * of Agent.preprocess agent.py:129-130 fused into the first conv). */
+int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const float* bias,
+                      float* small, int n_img, int hb, int wb, int Cb,
+                      int hs, int ws_, int Cs, int k, float in_scale,
+                      float* ws, size_t ws_bytes, void* stream);
+int dd_conv2d_s2_up(const float* small, const float* w, const float* bias, float* big,
+                    int n_img, int hs, int ws_, int Cs, int hb, int wb, int Cb, int k,
+                    void* stream);
+int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float* dw,
+                       int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
+                       float in_scale, float beta, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- LayerNorm(+ELU), GRU cell -------------------------------------------- */
+
+/* out = act(LN(z)*gamma+beta), eps 1e-3, population variance; act 0 none,
+ * 1 elu.  stats[rows,2] = (mean, rstd).  Norm nets.py:585-602 + get_act. */
+int dd_ln_act_fwd(const float* z, long ldz, const float* gamma, const float* beta,
+                  float* out, long ldo, float* stats, int rows, int C, int act, void* stream);
+/* dz from dout; if dgamma != NULL also dgamma/dbeta (accumulate: += ). */
+int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
+                  const float* out, long ldo, const float* stats, const float* gamma,
+                  float* dz, long lddz, float* dgamma, float* dbeta, int accumulate,
+                  int rows, int C, int act, float* ws, size_t ws_bytes, void* stream);
+int dd_ln_bwd_parts(int rows, int C);
+/* dgamma/dbeta only, from stored activations of all scan steps. */
+int dd_ln_param_grad(const float* dout, long ldd, const float* z, long ldz,
+                     const float* out, long ldo, const float* stats,
+                     float* dgamma, float* dbeta, int accumulate, int rows, int C,
+                     int act, float* ws, size_t ws_bytes, void* stream);
+
+/* RSSM._gru nets.py:149-160 after the [D+U,3D] matmul: LayerNorm over all 3D,
+ * reset/cand/update gates, new deter.  z3 [rows,3D]; h, hn [rows,D]. */
+int dd_gru_cell_fwd(const float* z3, long ldz, const float* gamma, const float* beta,
+                    const float* h, long ldh, float* hn, long ldn, float* stats,
+                    int rows, int D, void* stream);
+/* dz3 (through LN), dh = (1-update)*dhn, dy3 = gradient at the LN output. */
+int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
+                    const float* stats, const float* gamma, const float* beta,
+                    const float* h, long ldh, float* dz3, long lddz,
+                    float* dh, long lddh, float* dy3, long lddy,
+                    int rows, int D, void* stream);
+
+/* ---- categorical latent ------------------------------------------------------ */
+
+/* logit = log((1-unimix)*softmax(x)+unimix/C); stoch = one_hot(draw).
+ * mode 0: inverse-CDF draw with u[rows,G]; mode 1: argmax.
+ * RSSM._stats_layer nets.py:165-170 + OneHotDist.sample tfutils.py:368-378. */
+int dd_stats_sample_fwd(const float* x, long ldx, const float* u, long ldu,
+                        float* logit, long ldl, float* stoch, long lds,
+                        int rows, int G, int C, float unimix, int mode, void* stream);
+/* dx from dlogit (NULL ok) and the straight-through dstoch (NULL ok),
+ * tfutils.py:380-381. */
+int dd_stats_sample_bwd(const float* x, long ldx, const float* dlogit, long ldl,
+                        const float* dstoch, long lds, float* dx, long lddx,
+                        int rows, int G, int C, float unimix, void* stream);
+/* kl[row] = sum_g KL(post||prior) and both entropies.  RSSM.kl_loss
+ * nets.py:178-183 (value; lhs == rhs numerically). */
+int dd_cat_kl_fwd(const float* post, long ldp, const float* prior, long ldq,
+                  float* kl, float* ent_post, float* ent_prior,
+                  int rows, int G, int C, void* stream);
+/* Balanced gradient: dpost = c*(1-balance)*dKL/dpost, dprior = c*balance*
+ * dKL/dprior with c = coef_host * (*coef_dev). */
+int dd_cat_kl_bwd(const float* post, long ldp, const float* prior, long ldq,
+                  const float* coef_dev, float coef_host, float balance,
+                  float* dpost, long lddp, float* dprior, long lddq,
+                  int rows, int G, int C, void* stream);
+
+/* ---- losses and imagination scalars --------------------------------------------- */
+
+/* sigmoid + MSEDist(sum) against u8 image/255: nets.py:325, tfutils.py:320-329. */
+int dd_image_loss(const float* z, const unsigned char* img, float* loss, float* dz,
+                  int rows, long P, float coef, void* stream);
+int dd_mse_loss(const float* pred, long ldp, const float* tgt, long ldt, float* loss,
+                float* dpred, long lddp, int rows, int D, float coef, void* stream);
+/* kind 0 SymlogDist tfutils.py:347-356; kind 1 Bernoulli(logits) nets.py:469-471 */
+int dd_scalar_loss(const float* pred, const float* tgt, float* loss, float* dpred,
+                   long n, float coef, int kind, void* stream);
+/* Normal head nets.py:461-468 with reparameterised sample (eps NULL: mode). */
+int dd_normal_head_fwd(const float* om, long ldm, const float* os, long ldsd,
+                       const float* eps, long lde, float* act, long lda,
+                       int rows, int A, float lo, float hi, void* stream);
+int dd_normal_head_bwd(const float* om, long ldm, const float* os, long ldsd,
+                       const float* eps, long lde, const float* dact, long ldda,
+                       const float* w, const float* scale,
+                       float* dom, long lddm, float* dos, long lddsd, float* ent_row,
+                       int rows, int rows_ent, int A, float lo, float hi,
+                       float ent_coef, float ent_lo, float ent_div, void* stream);
+int dd_actent_stats(const float* os, long ldsd, int rows, int A, float lo, float hi,
+                    float ent_lo, float ent_div, double* out, void* stream);
+/* symexp / sigmoid of the head outputs, discount weights agent.py:256-259 and
+ * the 'gve' lambda-return agent.py:434-440, one thread per trajectory. */
+int dd_imag_returns_fwd(const float* rew_raw, const float* val_raw, const float* cont_raw,
+                        const float* first_cont, float* reward, float* value,
+                        float* cont, float* weight, float* ret, int H, long N,
+                        float gamma, float lam, void* stream);
+int dd_imag_returns_bwd(const float* dret, const float* dbase, const float* rew_raw,
+                        const float* val_raw, const float* cont_raw, const float* value,
+                        const float* ret, float* d_rew_raw, float* d_val_raw,
+                        float* d_cont_raw, int H, long N, float gamma, float lam, void* stream);
+int dd_critic_loss(const float* out, const float* ret, const float* w, float* loss,
+                   float* dout, long n, float coef, void* stream);
+int dd_actor_seed(const float* ret, const float* base, const float* w, const float* ent_row,
+                  const float* sc, float* loss, float* dret, float* dbase, long n, float coef,
+                  void* stream);
+int dd_sub(const float* a, const float* b, float* o, long n, void* stream);
+
+/* ---- learner state ------------------------------------------------------------- */
+
+/* Philox4x32-10 noise keyed by (seed, *step_dev, site, global row).
+ * kind 0 uniform [0,1), kind 1 standard normal. */
+int dd_philox(float* out, long outer, long inner, int cols, long inner_global,
+              long inner_offset, unsigned long long seed,
+              const unsigned long long* step_dev, unsigned site, int kind, void* stream);
+int dd_counter_add(unsigned long long* counter, unsigned long long v, void* stream);
+/* sums = {sum, sum sq, sum abs} (fp64), maxs = {max, max(-x), max|x|}. */
+int dd_reduce_stats(const float* x, long n, long stride, double* sums, float* maxs, void* stream);
+int dd_autoadapt_update(float* scale, const double* sums, int n, double count,
+                        float target, float thres, float vel, float lo, float hi,
+                        int inverse, void* stream);
+int dd_normalize_update(double* state, const double* sums, double count,
+                        const float* in_scale_dev, double decay, double maxv, int impl,
+                        int do_update, float* out_off_scale, void* stream);
+int dd_scalar_mul(float* dst, const float* a, const float* b, float c, int n, void* stream);
+/* opt_state = {step, grad_norm, finite}: tf.linalg.global_norm tfutils.py:243 */
+int dd_grad_norm(const float* g, long n, double* opt_state, double* ws, size_t ws_bytes,
+                 void* stream);
+/* clip + weight decay (first n_decay elements) + Adam, tfutils.py:244-283. */
+int dd_adam_step(float* p, const float* g, float* m, float* v, long n, long n_decay,
+                 const double* opt_state, float lr, float wd, float eps, float b1,
+                 float b2, float clip, void* stream);
+int dd_fill(float* p, long n, float v, void* stream);
+int dd_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, void* stream);
+/* is_first reset of RSSM.obs_step nets.py:100-107 and its gradient. */
+int dd_reset_mask(const float* prev, long ldp, const float* first, long fstride,
+                  const float* init, float* out, long ldo, long rows, int cols, void* stream);
+int dd_reset_mask_bwd(const float* dout, long ldo, const float* first, long fstride,
+                      float* dprev, long ldp, long rows, int cols, void* stream);
+int dd_batch_prep(const unsigned char* is_first, const unsigned char* is_terminal,
+                  const float* action, float* first_f, float* cont_f,
+                  float* act_masked, long ldm, long n, int A, void* stream);
+int dd_tanh_fwd(const float* x, float* y, int n, void* stream);
+int dd_tanh_bwd(const float* x, const float* dy, float* dx, int n, float beta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* DAYDREAMER_HIP_H_ */
