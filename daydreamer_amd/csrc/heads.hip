@@ -90,7 +90,7 @@ __global__ void k_normal_head_fwd(const float* __restrict__ om, long ldm,
 // Backward of the sampled action and of the (normalised) entropy bonus.
 // rows_ent: rows [0, rows_ent) carry the entropy term weighted by w[row].
 // d loss/d log(std_a) = -scale_a * w * ent_coef, ent_coef = 1/(count*(hi_ent-lo_ent)).
-// ent_row[row] = sum_a scale_a * (-ent_norm_a)  (loss value of the bonus).
+// ent_row[row] = w[row] * sum_a scale_a * (-ent_norm_a)  (weighted loss value of the bonus).
 __global__ void __launch_bounds__(256)
 k_normal_head_bwd(const float* __restrict__ om, long ldm, const float* __restrict__ os, long ldsd,
                   const float* __restrict__ eps, long lde, const float* __restrict__ dact, long ldda,
@@ -118,7 +118,7 @@ k_normal_head_bwd(const float* __restrict__ om, long ldm, const float* __restric
     dos[r * lddsd + a] = dstd * (hi - lo) * sg * (1.f - sg);
   }
   er = wave_sum(er);
-  if (lane == 0 && ent_row) ent_row[r] = (r < rows_ent) ? er : 0.f;
+  if (lane == 0 && ent_row) ent_row[r] = (r < rows_ent) ? w[r] * er : 0.f;
 }
 
 // Per action dimension: sum and sum of squares (fp64) of the normalised

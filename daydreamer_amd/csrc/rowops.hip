@@ -190,6 +190,22 @@ __global__ void k_col_reduce(const float* __restrict__ partials, int P, long str
   out[w] = (beta != 0.f ? beta * out[w] : 0.f) + s;
 }
 
+// column sums: partials[grid.y][C]
+__global__ void __launch_bounds__(256)
+k_col_sum(const float* __restrict__ x, long ldx, float* __restrict__ partials, long rows, int C) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a = 0.f;
+  if (c < C)
+    for (long row = (long)blockIdx.y * 4 + rl; row < rows; row += (long)gridDim.y * 4)
+      a += x[row * ldx + c];
+  __shared__ float sh[4][64];
+  sh[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && c < C)
+    partials[(long)blockIdx.y * C + c] = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+}
+
 // ---- GRU cell epilogue -----------------------------------------------------
 // z3 [rows, 3D] = concat[deter, x] @ W; LayerNorm over the whole 3D vector,
 // then reset = sig(r); cand = tanh(reset * c); update = sig(u - 1);
@@ -392,5 +408,21 @@ extern "C" int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, lon
   k_gru_bwd<<<row_blocks(rows, 1 << 20), 256, 0, (hipStream_t)stream>>>(
       dhn, lddn, z3, ldz, stats, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, rows, D);
   DD_CHECK_LAUNCH("dd_gru_cell_bwd");
+  return 0;
+}
+
+// out[c] = beta*out[c] + sum_rows x[row][c]   (bias gradients)
+extern "C" int dd_col_sum(const float* x, long ldx, float* out, float beta, long rows, int C,
+                          float* ws, size_t ws_bytes, void* stream) {
+  if (C <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  long chunks = (rows + 255) / 256;
+  int parts = (int)(chunks > 512 ? 512 : (chunks < 1 ? 1 : chunks));
+  DD_REQUIRE(ws && (size_t)parts * C * sizeof(float) <= ws_bytes, "dd_col_sum: workspace too small");
+  dim3 grid((C + 63) / 64, parts);
+  k_col_sum<<<grid, 256, 0, st>>>(x, ldx, ws, rows, C);
+  DD_CHECK_LAUNCH("dd_col_sum");
+  k_col_reduce<<<(C + 255) / 256, 256, 0, st>>>(ws, parts, (long)C, C, out, beta);
+  DD_CHECK_LAUNCH("dd_col_sum(reduce)");
   return 0;
 }

@@ -35,6 +35,7 @@ _SIGS = {
     'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_ln_bwd_parts': [c_i, c_i],
     'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
+    'dd_col_sum': [c_p, c_l, c_p, c_f, c_l, c_i, c_p, c_z, c_p],
     'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p],
     'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
@@ -206,6 +207,13 @@ class HipOps:
         dp, ldd, zp, ldz, op, ldo, stats.data_ptr(), dgamma.data_ptr(),
         dbeta.data_ptr(), int(accumulate), rows, C, int(act),
         self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_ln_param_grad')
+
+  def col_sum(self, x, out, beta=0.0):
+    rows, C = x.shape
+    xp, ldx = _mat(x)
+    self._check(self.lib.dd_col_sum(
+        xp, ldx, out.data_ptr(), beta, rows, C, self.ws.data_ptr(),
+        self.ws_bytes, self.stream), 'dd_col_sum')
 
   def gru_fwd(self, z3, gamma, beta, h, hn, stats):
     rows, D = h.shape

@@ -78,6 +78,10 @@ int dd_ln_param_grad(const float* dout, long ldd, const float* z, long ldz,
                      float* dgamma, float* dbeta, int accumulate, int rows, int C,
                      int act, float* ws, size_t ws_bytes, void* stream);
 
+/* out[c] = beta*out[c] + sum_rows x[row][c]: bias gradients. */
+int dd_col_sum(const float* x, long ldx, float* out, float beta, long rows, int C,
+               float* ws, size_t ws_bytes, void* stream);
+
 /* RSSM._gru nets.py:149-160 after the [D+U,3D] matmul: LayerNorm over all 3D,
  * reset/cand/update gates, new deter.  z3 [rows,3D]; h, hn [rows,D]. */
 int dd_gru_cell_fwd(const float* z3, long ldz, const float* gamma, const float* beta,

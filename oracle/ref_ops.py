@@ -163,6 +163,10 @@ class RefOps:
     dgamma.copy_(dgamma + dg if accumulate else dg)
     dbeta.copy_(dbeta + db if accumulate else db)
 
+  def col_sum(self, x, out, beta=0.0):
+    r = x.sum(0)
+    out.copy_(beta * out + r if beta != 0.0 else r)
+
   def gru_fwd(self, z3, gamma, beta, h, hn, stats):
     D = h.shape[1]
     mean = z3.mean(-1, keepdim=True)
@@ -312,7 +316,7 @@ class RefOps:
     wv = torch.zeros(rows, dtype=om.dtype, device=om.device)
     wv[:rows_ent] = w.reshape(-1)[:rows_ent]
     dstd = dstd + (-scale[None] * (wv * live)[:, None] * ent_coef / std)
-    er = (scale[None] * -((torch.log(std) - ent_lo) / ent_div)).sum(-1) * live
+    er = (scale[None] * -((torch.log(std) - ent_lo) / ent_div)).sum(-1) * live * wv
     dom.copy_(da * (1 - mean * mean))
     dos.copy_(dstd * (hi - lo) * sg * (1 - sg))
     if ent_row is not None:
