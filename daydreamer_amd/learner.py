@@ -1,0 +1,1053 @@
+"""The DreamerV2+ learner step on MI355X: explicit forward and hand-derived
+backward over HIP kernels (no autograd, no tracing compiler).
+
+Host-side mirror of the reference's `Agent.train` (reference
+embodied/agents/dreamerv2plus/agent.py:67-93): world-model update
+(WorldModel.train/loss agent.py:157-212, RSSM.observe nets.py:66-117), then
+imagination with the *updated* world model (WorldModel.imagine agent.py:234-261),
+critic update (VFunction.train agent.py:398-417, update_slow 444-454) and actor
+update by backprop through the rollout (ImagActorCritic.update/loss
+agent.py:326-381); optimizers as tfutils.py:180-283.
+
+Design (MI355X-first):
+  * every tensor lives in preallocated HBM buffers; the three optimizer groups
+    are flat arenas (params / grads / Adam m / v) so clipping, weight decay,
+    Adam and the data-parallel all-reduce are single passes over one buffer;
+  * replay tensors stay batch-major [B,T,...]; a scan step addresses row
+    b*T+t through the leading dimension, so the posterior states land directly
+    in the [B*T, feat] matrix the heads and the imagination consume;
+  * exact-algebra restructurings of the reference graph: the `embed` and
+    action slices of the obs_out / img_in matmuls are hoisted out of the T-step
+    scan; `initial()` is evaluated once per step on one row; weight gradients
+    of scan layers are one bulk GEMM over all steps; reward / cont heads are
+    evaluated once per trajectory;
+  * everything that varies from step to step (RNG step, Adam step, controller
+    scales) is device-resident, so the step is capturable into HIP graphs.
+
+`ops` is the kernel backend (daydreamer_amd.hipops.HipOps in the product).
+"""
+
+import math
+
+import numpy as np
+import torch
+
+from . import spec as specs
+
+F32 = torch.float32
+
+# noise sites for the Philox counter
+SITE_OBS_PRIOR, SITE_OBS_POST, SITE_IMG, SITE_ACT, SITE_POLICY = 0, 1, 2, 3, 4
+
+
+class ParamGroup:
+  """Flat arena for one optimizer: params, grads and Adam moments; the
+  weight-decayed tensors ('kernel') come first so decay is a prefix."""
+
+  def __init__(self, plist, device, trainable=True, dtype=F32):
+    F32 = dtype
+    order = [p for p in plist if p.decay] + [p for p in plist if not p.decay]
+    self.specs = order
+    self.n = sum(p.size for p in order)
+    self.n_decay = sum(p.size for p in order if p.decay)
+    self.flat = torch.zeros(self.n, dtype=F32, device=device)
+    self.p, self.g = {}, {}
+    if trainable:
+      self.gflat = torch.zeros(self.n, dtype=F32, device=device)
+      self.m = torch.zeros(self.n, dtype=F32, device=device)
+      self.v = torch.zeros(self.n, dtype=F32, device=device)
+      self.opt_state = torch.zeros(3, dtype=torch.float64, device=device)
+    off = 0
+    for p in order:
+      self.p[p.name] = self.flat[off:off + p.size].view(p.shape)
+      if trainable:
+        self.g[p.name] = self.gflat[off:off + p.size].view(p.shape)
+      off += p.size
+
+  def load(self, arrays):
+    for p in self.specs:
+      self.p[p.name].copy_(torch.as_tensor(np.asarray(arrays[p.name])
+                                           ).reshape(p.shape))
+
+
+class Lin:
+  """Parameters of one Linear layer (+ LayerNorm when norm)."""
+
+  def __init__(self, grp, prefix, norm, rows=None):
+    self.norm = norm
+    W, dW = grp.p[f'{prefix}/kernel'], grp.g.get(f'{prefix}/kernel')
+    if rows is not None:  # row slice of a concatenated-input kernel
+      W, dW = W[rows[0]:rows[1]], (dW[rows[0]:rows[1]] if dW is not None else None)
+    self.W, self.dW = W, dW
+    if norm:
+      self.gamma, self.beta = grp.p[f'{prefix}/norm/scale'], grp.p[f'{prefix}/norm/bias']
+      self.dgamma, self.dbeta = grp.g.get(f'{prefix}/norm/scale'), grp.g.get(f'{prefix}/norm/bias')
+    else:
+      self.bias, self.dbias = grp.p[f'{prefix}/bias'], grp.g.get(f'{prefix}/bias')
+    self.units = W.shape[1]
+
+
+class Act:
+  """Activations (and their gradients) of one Lin in one row space."""
+
+  def __init__(self, L, rows, units, norm, grads=True):
+    self.z = L.zeros(rows, units)
+    if norm:
+      self.out = L.zeros(rows, units)
+      self.stats = L.zeros(rows, 2)
+      if grads:
+        self.dz = L.zeros(rows, units)
+    if grads:
+      self.dout = L.zeros(rows, units)
+
+
+class Learner:
+
+  def __init__(self, spec, ops, device, batch, length, params=None, seed=0,
+               rank=0, world=1, comm=None, noise_seed=0, dtype=F32):
+    self.spec, self.ops, self.device = spec, ops, torch.device(device)
+    self.dtype = dtype  # float32 in the product; tests may use float64
+    self.cfg = cfg = spec.cfg
+    self.B, self.T = batch, length
+    self.N = batch * length
+    self.H = cfg['imag_horizon']
+    self.M = (self.H + 1) * self.N
+    self.rank, self.world, self.comm = rank, world, comm
+    self.Bg = batch * world
+    self.Ng = self.N * world
+    self.noise_seed = noise_seed
+    self._nbytes = 0
+    s = spec
+    self.D, self.U, self.S, self.A = s.deter, s.units, s.stoch, s.act_dim
+    self.G, self.C, self.F = s.groups, s.classes, s.feat
+    self.unimix = float(cfg['rssm']['unimix'])
+    assert len(s.dec_cnn_keys) <= 1 and len(s.enc_cnn_keys) <= 1, \
+        'multiple image keys are not implemented yet'
+    assert cfg['actor_grad_cont'] == 'backprop' and cfg['critic_type'] == 'vfunction'
+    assert cfg['actor_return'] == 'gve' and cfg['critic_return'] == 'gve'
+    assert cfg['scorenorm']['impl'] in ('off', 'std')
+    for k in ('model_opt', 'actor_opt', 'critic_opt'):
+      assert cfg[k]['opt'] == 'adam' and not cfg[k]['warmup']
+    # ---- parameters
+    self.groups = {
+        'model': ParamGroup(s.group('model'), self.device, dtype=dtype),
+        'actor': ParamGroup(s.group('actor'), self.device, dtype=dtype),
+        'critic': ParamGroup(s.group('critic'), self.device, dtype=dtype),
+        'critic_target': ParamGroup(s.group('critic_target'), self.device,
+                                    trainable=False, dtype=dtype)}
+    init = params if params is not None else specs.init_params(s, seed)
+    for g in self.groups.values():
+      g.load(init)
+    # ---- device scalars
+    self.step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+    self.wmkl_scale = torch.ones(1, dtype=dtype, device=self.device)
+    self.actent_scale = torch.ones(self.A, dtype=dtype, device=self.device)
+    self.norm_state = {k: torch.zeros(3, dtype=torch.float64, device=self.device)
+                       for k in ('ret', 'score', 'adv')}
+    self.norm_os = {k: torch.zeros(2, dtype=dtype, device=self.device)
+                    for k in ('ret', 'score', 'adv')}
+    self.sc = torch.zeros(3, dtype=dtype, device=self.device)
+    self.slow_updates = -1
+    self.stat_names = []
+    self.stat_sums = torch.zeros(64, 3, dtype=torch.float64, device=self.device)
+    self.stat_maxs = torch.zeros(64, 3, dtype=dtype, device=self.device)
+    self.actent_sums = torch.zeros(2 * self.A, dtype=torch.float64, device=self.device)
+    self.zero_rows = None
+    self._build_layers()
+    self._build_buffers()
+
+  # ------------------------------------------------------------------ memory
+
+  def zeros(self, *shape, dtype=None):
+    t = torch.zeros(*shape, dtype=dtype or self.dtype, device=self.device)
+    self._nbytes += t.numel() * t.element_size()
+    return t
+
+  def _build_layers(self):
+    s, m = self.spec, self.groups['model']
+    cfg = self.cfg
+    D, S, A = self.D, self.S, self.A
+    self.P = P = {}
+    for i in range(cfg['encoder']['mlp_layers'] if s.enc_mlp_keys else 0):
+      P[f'enc/mlp/dense{i}'] = Lin(m, f'enc/mlp/dense{i}', True)
+    P['img_in'] = Lin(m, 'rssm/img_in', True)
+    P['img_in_s'] = Lin(m, 'rssm/img_in', True, rows=(0, S))
+    P['gru_h'] = Lin(m, 'rssm/gru_out', True, rows=(0, D))
+    P['gru_x'] = Lin(m, 'rssm/gru_out', True, rows=(D, D + self.U))
+    self.n_prior = cfg['rssm']['prior_layers']
+    for i in range(self.n_prior):
+      P[f'img_out_{i}'] = Lin(m, f'rssm/img_out_{i}', True)
+    P['img_stats'] = Lin(m, 'rssm/img_stats', False)
+    P['obs_out_h'] = Lin(m, 'rssm/obs_out', True, rows=(0, D))
+    e0 = D
+    self.cnn_feat = 0
+    if s.enc_convs:
+      last = s.enc_convs[-1]
+      self.cnn_feat = last.h_small * last.h_small * last.c_small
+      P['obs_out_cnn'] = Lin(m, 'rssm/obs_out', True, rows=(e0, e0 + self.cnn_feat))
+      e0 += self.cnn_feat
+    if s.enc_mlp_keys:
+      P['obs_out_mlp'] = Lin(m, 'rssm/obs_out', True, rows=(e0, D + s.embed))
+    P['obs_stats'] = Lin(m, 'rssm/obs_stats', False)
+
+    def head(name, group, cfgkey, outs):
+      g = self.groups[group]
+      layers = [Lin(g, f'{name}/dense{i}', True)
+                for i in range(cfg[cfgkey]['layers'])]
+      return layers, [Lin(g, f'{name}/{o}', False) for o in outs]
+    self.heads = {
+        'reward': head('reward', 'model', 'reward_head', ['dist_out/out']),
+        'cont': head('cont', 'model', 'cont_head', ['dist_out/out']),
+        'actor': head('actor', 'actor', 'actor', ['dist_out/out', 'dist_out/std']),
+        'critic': head('critic', 'critic', 'critic', ['dist_out/out']),
+        'critic_target': head('critic_target', 'critic_target', 'critic',
+                              ['dist_out/out'])}
+    if s.dec_mlp_keys:
+      g = m
+      n = cfg['decoder']['mlp_layers']
+      self.heads['dec_mlp'] = (
+          [Lin(g, f'dec/mlp/dense{i}', True) for i in range(n)],
+          [Lin(g, f'dec/mlp/dist_{k}/out', False) for k in s.dec_mlp_keys])
+
+  def _head_acts(self, name, rows, grads=True):
+    layers, outs = self.heads[name]
+    return ([Act(self, rows, l.units, True, grads) for l in layers],
+            [Act(self, rows, o.units, False, grads) for o in outs])
+
+  def _build_buffers(self):
+    s = self.spec
+    B, T, N, H, M = self.B, self.T, self.N, self.H, self.M
+    D, U, S, A, F, G = self.D, self.U, self.S, self.A, self.F, self.G
+    z = self.zeros
+    b = self.b = {}
+    # ---- inputs (wire format, batch-major)
+    if s.enc_cnn_keys:
+      hw, c = s.image_hw, s.image_c
+      b['image'] = z(N, hw, hw, c, dtype=torch.uint8)
+    if s.enc_mlp_keys:
+      b['vec_in'] = z(N, s.enc_mlp_in)
+    if s.dec_mlp_keys:
+      b['vec_tgt'] = {k: z(N, int(np.prod(v))) for k, v in s.dec_mlp_keys.items()}
+    b['action'] = z(N, A)
+    b['reward'] = z(N)
+    b['is_first'] = z(N, dtype=torch.uint8)
+    b['is_terminal'] = z(N, dtype=torch.uint8)
+    b['first'] = z(N)
+    b['cont'] = z(N)
+    # ---- noise
+    b['u_prior'] = z(T, B, G)
+    b['u_post'] = z(T, B, G)
+    b['u_img'] = z(max(H, 1), N, G)
+    b['eps'] = z(H + 1, N, A)
+    # ---- encoder
+    self.enc_act = []
+    for cl in s.enc_convs:
+      rows = N * cl.h_small * cl.h_small
+      self.enc_act.append(dict(
+          z=z(N, cl.h_small, cl.h_small, cl.c_small),
+          out=z(N, cl.h_small, cl.h_small, cl.c_small),
+          stats=z(rows, 2), dz=z(N, cl.h_small, cl.h_small, cl.c_small),
+          dout=z(N, cl.h_small, cl.h_small, cl.c_small)))
+    self.enc_mlp_act = [Act(self, N, self.P[f'enc/mlp/dense{i}'].units, True)
+                        for i in range(self.cfg['encoder']['mlp_layers']
+                                       if s.enc_mlp_keys else 0)]
+    # ---- observe scan (batch-major [B,T,...] buffers)
+    b['post'] = z(N, F)            # [deter | stoch] of the posterior
+    b['hprev'] = z(N, D)
+    b['xin'] = z(N, S + A)
+    self.a_img_in = Act(self, N, U, True)
+    b['z3'] = z(N, 3 * D)
+    b['gstats'] = z(N, 2)
+    b['dz3'] = z(N, 3 * D)
+    b['dy3'] = z(N, 3 * D)
+    b['dhprev'] = z(N, D)
+    b['dxin_s'] = z(N, S)
+    self.a_img_out = [Act(self, N, U, True) for _ in range(self.n_prior)]
+    self.a_img_stats = Act(self, N, S, False)
+    self.a_obs_out = Act(self, N, U, True)
+    self.a_obs_stats = Act(self, N, S, False)
+    b['prior_logit'] = z(N, S)
+    b['post_logit'] = z(N, S)
+    b['prior_stoch'] = z(N, S)
+    b['dprior_logit'] = z(N, S)
+    b['dpost_logit'] = z(N, S)
+    b['dfeat'] = z(N, F)
+    b['kl'] = z(N)
+    b['ent_post'] = z(N)
+    b['ent_prior'] = z(N)
+    # initial(): one row
+    b['init_deter'] = z(1, D)
+    b['init_stoch'] = z(1, S)
+    b['init_logit'] = z(1, S)
+    b['dinit_deter'] = z(1, D)
+    self.a_init_out = [Act(self, 1, U, True, grads=False) for _ in range(self.n_prior)]
+    self.a_init_stats = Act(self, 1, S, False, grads=False)
+    # carry state between train calls
+    b['carry'] = z(B, F)
+    # ---- heads on the posterior
+    self.acts_wm = {k: self._head_acts(k, N) for k in ('reward', 'cont')}
+    if s.dec_mlp_keys:
+      self.acts_wm['dec_mlp'] = self._head_acts('dec_mlp', N)
+    b['loss_reward'] = z(N)
+    b['loss_cont'] = z(N)
+    b['loss_vec'] = {k: z(N) for k in s.dec_mlp_keys}
+    self.dec_act = []
+    for cl in s.dec_convs:
+      shp = (N, cl.h_big, cl.h_big, cl.c_big)
+      d = dict(z=z(*shp), dz=z(*shp))
+      if cl.norm:
+        d.update(out=z(*shp), stats=z(N * cl.h_big * cl.h_big, 2), dout=z(*shp))
+      self.dec_act.append(d)
+    if s.dec_convs:
+      b['loss_image'] = z(N)
+      c0 = s.dec_convs[0]
+      b['bias_tiled'] = z(c0.k * c0.k * c0.c_big)
+      b['dbias_tiled'] = z(c0.k * c0.k * c0.c_big)
+    # ---- imagination (time-major [H+1, N, ...])
+    W = F + A
+    b['traj'] = z(H + 1, N, W)     # [deter | stoch | action]
+    b['dtraj'] = z(H + 1, N, W)
+    self.ai_img_in = Act(self, H * N, U, True)
+    b['iz3'] = z(H * N, 3 * D)
+    b['igstats'] = z(H * N, 2)
+    b['idz3'] = z(N, 3 * D)
+    b['idy3'] = z(N, 3 * D)
+    b['idh'] = z(N, D)
+    self.ai_img_out = [Act(self, H * N, U, True) for _ in range(self.n_prior)]
+    self.ai_img_stats = Act(self, H * N, S, False)
+    b['ilogit'] = z(N, S)
+    self.acts_im = {
+        'actor': self._head_acts('actor', M),
+        'reward': self._head_acts('reward', M),
+        'cont': self._head_acts('cont', M),
+        'critic': self._head_acts('critic', H * N),
+        'critic_target': self._head_acts('critic_target', M)}
+    for k in ('value', 'cont', 'weight', 'value2', 'ent_row'):
+      b['i_' + k] = z(M)
+    for k in ('reward', 'ret', 'ret2', 'diff', 'crit_loss', 'actor_loss',
+              'dret', 'dbase'):
+      b['i_' + k] = z(max(H * N, 1))
+    b['dom'] = z(M, A)
+    b['dos'] = z(M, A)
+    self.zero_rows = z(max(N, B))
+
+  # ----------------------------------------------------------- small helpers
+
+  def stat(self, name, x, count=None):
+    """Register / compute batch statistics of a vector into a metric slot."""
+    if name not in self.stat_names:
+      self.stat_names.append(name)
+    k = self.stat_names.index(name)
+    self.ops.reduce_stats(x, self.stat_sums[k], self.stat_maxs[k])
+    return k
+
+  def allreduce(self, t):
+    if self.comm is not None and self.world > 1:
+      self.comm.allreduce_sum(t)
+
+  def lin_fwd(self, P, A, x, sel=None):
+    sel = sel or (lambda t: t)
+    zv = sel(A.z)
+    self.ops.gemm(x, P.W, zv, bias=None if P.norm else P.bias)
+    if not P.norm:
+      return zv
+    self.ops.ln_act_fwd(zv, P.gamma, P.beta, sel(A.out), sel(A.stats), True)
+    return sel(A.out)
+
+  def lin_bwd(self, P, A, x, sel=None, dx=None, dx_beta=0.0, params=True):
+    """Gradient w.r.t. the layer output is in A.dout.  Writes parameter
+    gradients (params=True, bulk over the selected rows) and dx."""
+    sel = sel or (lambda t: t)
+    ops = self.ops
+    if P.norm:
+      dz = sel(A.dz)
+      ops.ln_act_bwd(sel(A.dout), sel(A.z), sel(A.out), sel(A.stats), P.gamma,
+                     dz, P.dgamma if params else None,
+                     P.dbeta if params else None, False, True)
+    else:
+      dz = sel(A.dout)
+      if params:
+        ops.col_sum(dz, P.dbias)
+    if params:
+      ops.gemm(x, dz, P.dW, ta=True)
+    if dx is not None:
+      ops.gemm(dz, P.W, dx, tb=True, beta=dx_beta)
+    return dz
+
+  def mlp_fwd(self, layers, acts, x, sel=None):
+    for P, A in zip(layers, acts):
+      x = self.lin_fwd(P, A, x, sel)
+    return x
+
+  def mlp_bwd(self, layers, acts, x0, sel=None, dx=None, dx_beta=0.0,
+              params=True):
+    """Backward through a DenseLN stack; the top layer's A.dout must hold the
+    incoming gradient.  x0 is the stack input."""
+    sel = sel or (lambda t: t)
+    for i in reversed(range(len(layers))):
+      xin = x0 if i == 0 else sel(acts[i - 1].out)
+      tgt = dx if i == 0 else sel(acts[i - 1].dout)
+      self.lin_bwd(layers[i], acts[i], xin, sel, tgt,
+                   dx_beta if i == 0 else 0.0, params)
+
+  def head_fwd(self, name, acts, x, sel=None):
+    layers, outs = self.heads[name]
+    la, oa = acts
+    h = self.mlp_fwd(layers, la, x, sel)
+    return [self.lin_fwd(P, A, h, sel) for P, A in zip(outs, oa)]
+
+  def head_bwd(self, name, acts, x, sel=None, dx=None, dx_beta=0.0,
+               params=True):
+    """Output-layer gradients must be in the out-acts' .dout."""
+    sel = sel or (lambda t: t)
+    layers, outs = self.heads[name]
+    la, oa = acts
+    top = sel(la[-1].out)
+    for j, (P, A) in enumerate(zip(outs, oa)):
+      self.lin_bwd(P, A, top, sel, sel(la[-1].dout), 0.0 if j == 0 else 1.0,
+                   params)
+    self.mlp_bwd(layers, la, x, sel, dx, dx_beta, params)
+
+  # ----------------------------------------------------------------- encoder
+
+  def encoder_fwd(self):
+    s, ops, b = self.spec, self.ops, self.b
+    m = self.groups['model']
+    x = b.get('image')
+    for i, (cl, a) in enumerate(zip(s.enc_convs, self.enc_act)):
+      ops.conv_down(x, m.p[f'{cl.name}/kernel'], m.p[f'{cl.name}/bias'], a['z'],
+                    cl.k, 1.0 / 255.0 if i == 0 else 1.0)
+      C = cl.c_small
+      ops.ln_act_fwd(a['z'].view(-1, C), m.p[f'{cl.name}/norm/scale'],
+                     m.p[f'{cl.name}/norm/bias'], a['out'].view(-1, C),
+                     a['stats'], True)
+      x = a['out']
+    if s.enc_mlp_keys:
+      layers = [self.P[f'enc/mlp/dense{i}'] for i in range(len(self.enc_mlp_act))]
+      self.mlp_fwd(layers, self.enc_mlp_act, b['vec_in'])
+    # hoisted embed part of obs_out: written straight into its pre-LN buffer
+    zo = self.a_obs_out.z
+    first = True
+    if s.enc_convs:
+      ops.gemm(self.enc_act[-1]['out'].view(self.N, -1), self.P['obs_out_cnn'].W, zo)
+      first = False
+    if s.enc_mlp_keys:
+      ops.gemm(self.enc_mlp_act[-1].out, self.P['obs_out_mlp'].W, zo,
+               beta=0.0 if first else 1.0)
+
+  def encoder_bwd(self):
+    """Consumes a_obs_out.dz (all steps) as the gradient of the hoisted
+    embed matmul."""
+    s, ops, b = self.spec, self.ops, self.b
+    m = self.groups['model']
+    dzo = self.a_obs_out.dz
+    if s.enc_mlp_keys:
+      P = self.P['obs_out_mlp']
+      top = self.enc_mlp_act[-1]
+      ops.gemm(top.out, dzo, P.dW, ta=True)
+      ops.gemm(dzo, P.W, top.dout, tb=True)
+      layers = [self.P[f'enc/mlp/dense{i}'] for i in range(len(self.enc_mlp_act))]
+      self.mlp_bwd(layers, self.enc_mlp_act, b['vec_in'])
+    if s.enc_convs:
+      P = self.P['obs_out_cnn']
+      top = self.enc_act[-1]
+      ops.gemm(top['out'].view(self.N, -1), dzo, P.dW, ta=True)
+      ops.gemm(dzo, P.W, top['dout'].view(self.N, -1), tb=True)
+      for i in reversed(range(len(s.enc_convs))):
+        cl, a = s.enc_convs[i], self.enc_act[i]
+        C = cl.c_small
+        ops.ln_act_bwd(a['dout'].view(-1, C), a['z'].view(-1, C),
+                       a['out'].view(-1, C), a['stats'],
+                       m.p[f'{cl.name}/norm/scale'], a['dz'].view(-1, C),
+                       m.g[f'{cl.name}/norm/scale'], m.g[f'{cl.name}/norm/bias'],
+                       False, True)
+        ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
+        big = b['image'] if i == 0 else self.enc_act[i - 1]['out']
+        ops.conv_wgrad(big, a['dz'], m.g[f'{cl.name}/kernel'], cl.k,
+                       1.0 / 255.0 if i == 0 else 1.0)
+        if i > 0:
+          ops.conv_up(a['dz'], m.p[f'{cl.name}/kernel'], None,
+                      self.enc_act[i - 1]['dout'], cl.k)
+
+  # ----------------------------------------------------------------- decoder
+
+  def decoder_fwd(self, feat):
+    s, ops, b = self.spec, self.ops, self.b
+    m = self.groups['model']
+    N = self.N
+    if s.dec_convs:
+      c0, a0 = s.dec_convs[0], self.dec_act[0]
+      kk = c0.k * c0.k
+      bt = b['bias_tiled'].view(kk, c0.c_big)
+      ops.copy2d(m.p[f'{c0.name}/bias'].view(1, -1).expand(kk, c0.c_big), bt)
+      ops.gemm(feat, m.p[f'{c0.name}/kernel'].view(kk * c0.c_big, self.F),
+               a0['z'].view(N, -1), tb=True, bias=b['bias_tiled'])
+      x = None
+      for i, (cl, a) in enumerate(zip(s.dec_convs, self.dec_act)):
+        if i > 0:
+          ops.conv_up(x, m.p[f'{cl.name}/kernel'], m.p[f'{cl.name}/bias'],
+                      a['z'], cl.k)
+        if cl.norm:
+          C = cl.c_big
+          ops.ln_act_fwd(a['z'].view(-1, C), m.p[f'{cl.name}/norm/scale'],
+                         m.p[f'{cl.name}/norm/bias'], a['out'].view(-1, C),
+                         a['stats'], True)
+          x = a['out']
+      last = self.dec_act[-1]
+      scale = self.cfg['loss_scales'].get(list(s.dec_cnn_keys)[0], 1.0)
+      ops.image_loss(last['z'], b['image'], b['loss_image'], last['dz'],
+                     scale / self.Ng)
+    if s.dec_mlp_keys:
+      outs = self.head_fwd('dec_mlp', self.acts_wm['dec_mlp'], feat)
+      for (k, v), o, A in zip(s.dec_mlp_keys.items(), outs,
+                              self.acts_wm['dec_mlp'][1]):
+        scale = self.cfg['loss_scales'].get(k, 1.0)
+        ops.mse_loss(o, b['vec_tgt'][k], b['loss_vec'][k], A.dout,
+                     scale / self.Ng)
+
+  def decoder_bwd(self, feat, dfeat, beta):
+    s, ops, b = self.spec, self.ops, self.b
+    m = self.groups['model']
+    N = self.N
+    if s.dec_mlp_keys:
+      self.head_bwd('dec_mlp', self.acts_wm['dec_mlp'], feat, None, dfeat, beta)
+      beta = 1.0
+    if s.dec_convs:
+      for i in reversed(range(len(s.dec_convs))):
+        cl, a = s.dec_convs[i], self.dec_act[i]
+        C = cl.c_big
+        if cl.norm:
+          ops.ln_act_bwd(a['dout'].view(-1, C), a['z'].view(-1, C),
+                         a['out'].view(-1, C), a['stats'],
+                         m.p[f'{cl.name}/norm/scale'], a['dz'].view(-1, C),
+                         m.g[f'{cl.name}/norm/scale'],
+                         m.g[f'{cl.name}/norm/bias'], False, True)
+        ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
+        if i > 0:
+          prev = self.dec_act[i - 1]
+          ops.conv_wgrad(a['dz'], prev['out'], m.g[f'{cl.name}/kernel'], cl.k)
+          ops.conv_down(a['dz'], m.p[f'{cl.name}/kernel'], None, prev['dout'],
+                        cl.k)
+        else:
+          kk = cl.k * cl.k
+          dzv = a['dz'].view(N, -1)
+          ops.gemm(dzv, feat, m.g[f'{cl.name}/kernel'].view(kk * C, self.F),
+                   ta=True)
+          ops.gemm(dzv, m.p[f'{cl.name}/kernel'].view(kk * C, self.F), dfeat,
+                   beta=beta)
+
+  # ------------------------------------------------------------------- RSSM
+
+  def initial_fwd(self):
+    """RSSM.initial 'learned2' (reference nets.py:54-62) on one row."""
+    ops, b = self.ops, self.b
+    m = self.groups['model']
+    ops.tanh_fwd(m.p['rssm/initial_deter'], b['init_deter'])
+    x = b['init_deter']
+    for i in range(self.n_prior):
+      x = self.lin_fwd(self.P[f'img_out_{i}'], self.a_init_out[i], x)
+    xs = self.lin_fwd(self.P['img_stats'], self.a_init_stats, x)
+    ops.stats_fwd(xs, None, b['init_logit'], b['init_stoch'], self.G, self.C,
+                  self.unimix, 1)
+
+  def cell_fwd(self, xin, hprev, hn, A_in, z3, gstats, A_out, A_stats, sel):
+    """RSSM.img_step up to the prior statistics (reference nets.py:119-134).
+    xin [rows,S+A], hprev [rows,D] -> hn [rows,D]; returns raw stats."""
+    ops = self.ops
+    x1 = self.lin_fwd(self.P['img_in'], A_in, xin, sel)
+    z3v = sel(z3)
+    ops.gemm(hprev, self.P['gru_h'].W, z3v)
+    ops.gemm(x1, self.P['gru_x'].W, z3v, beta=1.0)
+    g = self.P['gru_h']
+    ops.gru_fwd(z3v, g.gamma, g.beta, hprev, hn, sel(gstats))
+    x = hn
+    for i in range(self.n_prior):
+      x = self.lin_fwd(self.P[f'img_out_{i}'], A_out[i], x, sel)
+    return self.lin_fwd(self.P['img_stats'], A_stats, x, sel)
+
+  def cell_bwd(self, dhn_total, dxs, hprev, A_in, z3, gstats, A_out, A_stats,
+               sel, dz3, dy3, dh_direct, dxin, dxin_beta, dxin_P):
+    """Data-gradient backward of cell_fwd.  dhn_total [rows,D] holds the
+    gradient w.r.t. the new deter and is accumulated into in place; dxs is the
+    gradient w.r.t. the raw prior statistics (in A_stats.dout).  Outputs:
+    dz3, dy3 (GRU), dh_direct = (1-update)*dhn + dz3 @ Wg_h^T, and
+    dxin (+)= dz_in @ W_in^T restricted to dxin_P's rows."""
+    ops = self.ops
+    n = self.n_prior
+    ops.gemm(sel(A_stats.dout), self.P['img_stats'].W, sel(A_out[-1].dout), tb=True)
+    for i in reversed(range(n)):
+      tgt = dhn_total if i == 0 else sel(A_out[i - 1].dout)
+      self.lin_bwd(self.P[f'img_out_{i}'], A_out[i], None, sel, tgt,
+                   1.0 if i == 0 else 0.0, params=False)
+    g = self.P['gru_h']
+    ops.gru_bwd(dhn_total, sel(z3), sel(gstats), g.gamma, g.beta, hprev, dz3,
+                dh_direct, dy3)
+    ops.gemm(dz3, self.P['gru_h'].W, dh_direct, tb=True, beta=1.0)
+    ops.gemm(dz3, self.P['gru_x'].W, sel(A_in.dout), tb=True)
+    self.lin_bwd(self.P['img_in'], A_in, None, sel, None, params=False)
+    ops.gemm(sel(A_in.dz), dxin_P.W, dxin, tb=True, beta=dxin_beta)
+
+  def reset_carry(self):
+    """state=None: the carried state is RSSM.initial() (reference
+    agent.py:39-40, 71-72)."""
+    b, D = self.b, self.D
+    self.initial_fwd()
+    self.ops.copy2d(b['init_deter'].expand(self.B, D), b['carry'][:, :D])
+    self.ops.copy2d(b['init_stoch'].expand(self.B, self.S), b['carry'][:, D:])
+
+  def observe_fwd(self, use_carry=True):
+    ops, b = self.ops, self.b
+    B, T, D, S, F = self.B, self.T, self.D, self.S, self.F
+    bt = lambda t_: (lambda buf: buf.view(B, T, -1)[:, t_])
+    first = b['first'].view(B, T)
+    post = b['post'].view(B, T, F)
+    for t in range(T):
+      sel = bt(t)
+      if t == 0:
+        pd = b['carry'][:, :D] if use_carry else None
+        ps = b['carry'][:, D:] if use_carry else None
+      else:
+        pd, ps = post[:, t - 1, :D], post[:, t - 1, D:]
+      hprev = sel(b['hprev'])
+      xin = sel(b['xin'])
+      ops.reset_mask(pd, first[:, t], b['init_deter'], hprev)
+      ops.reset_mask(ps, first[:, t], b['init_stoch'], xin[:, :S])
+      xs = self.cell_fwd(xin, hprev, post[:, t, :D], self.a_img_in, b['z3'],
+                         b['gstats'], self.a_img_out, self.a_img_stats, sel)
+      ops.stats_fwd(xs, b['u_prior'][t], sel(b['prior_logit']),
+                    sel(b['prior_stoch']), self.G, self.C, self.unimix, 0)
+      # posterior: obs_out on concat[deter, embed]; embed part already in z
+      Ao = self.a_obs_out
+      ops.gemm(post[:, t, :D], self.P['obs_out_h'].W, sel(Ao.z), beta=1.0)
+      Po = self.P['obs_out_h']
+      ops.ln_act_fwd(sel(Ao.z), Po.gamma, Po.beta, sel(Ao.out), sel(Ao.stats), True)
+      xq = self.lin_fwd(self.P['obs_stats'], self.a_obs_stats, sel(Ao.out), sel)
+      ops.stats_fwd(xq, b['u_post'][t], sel(b['post_logit']), post[:, t, D:],
+                    self.G, self.C, self.unimix, 0)
+
+  def observe_bwd(self):
+    """Reverse scan.  On entry dfeat holds the heads' gradient w.r.t. every
+    posterior [deter | stoch]; dpost_logit / dprior_logit hold the KL
+    gradients."""
+    ops, b = self.ops, self.b
+    B, T, D, S, F = self.B, self.T, self.D, self.S, self.F
+    bt = lambda t_: (lambda buf: buf.view(B, T, -1)[:, t_])
+    first = b['first'].view(B, T)
+    post = b['post'].view(B, T, F)
+    dfeat = b['dfeat'].view(B, T, F)
+    Ao, Po = self.a_obs_out, self.P['obs_out_h']
+    for t in reversed(range(T)):
+      sel = bt(t)
+      ddeter, dstoch = dfeat[:, t, :D], dfeat[:, t, D:]
+      # posterior sample + statistics
+      ops.stats_bwd(sel(self.a_obs_stats.z), sel(b['dpost_logit']), dstoch,
+                    sel(self.a_obs_stats.dout), self.G, self.C, self.unimix)
+      ops.gemm(sel(self.a_obs_stats.dout), self.P['obs_stats'].W, sel(Ao.dout), tb=True)
+      ops.ln_act_bwd(sel(Ao.dout), sel(Ao.z), sel(Ao.out), sel(Ao.stats),
+                     Po.gamma, sel(Ao.dz), None, None, False, True)
+      ops.gemm(sel(Ao.dz), Po.W, ddeter, tb=True, beta=1.0)
+      # prior statistics (KL only; the prior sample is unused downstream)
+      ops.stats_bwd(sel(self.a_img_stats.z), sel(b['dprior_logit']), None,
+                    sel(self.a_img_stats.dout), self.G, self.C, self.unimix)
+      self.cell_bwd(ddeter, None, sel(b['hprev']), self.a_img_in, b['z3'],
+                    b['gstats'], self.a_img_out, self.a_img_stats, sel,
+                    sel(b['dz3']), sel(b['dy3']), sel(b['dhprev']),
+                    sel(b['dxin_s']), 0.0, self.P['img_in_s'])
+      if t > 0:
+        ops.reset_mask_bwd(sel(b['dhprev']), first[:, t], dfeat[:, t - 1, :D])
+        ops.reset_mask_bwd(sel(b['dxin_s']), first[:, t], dfeat[:, t - 1, D:])
+    # ---- bulk parameter gradients over all T steps
+    m = self.groups['model']
+    P = self.P
+    lnp = lambda L, A: ops.ln_param_grad(A.dout, A.z, A.out, A.stats, L.dgamma,
+                                         L.dbeta, False, True)
+    As, Aq = self.a_img_stats, self.a_obs_stats
+    ops.gemm(Ao.out, Aq.dout, P['obs_stats'].dW, ta=True)
+    ops.col_sum(Aq.dout, P['obs_stats'].dbias)
+    ops.gemm(b['post'][:, :D], Ao.dz, P['obs_out_h'].dW, ta=True)
+    lnp(P['obs_out_h'], Ao)
+    ops.gemm(self.a_img_out[-1].out, As.dout, P['img_stats'].dW, ta=True)
+    ops.col_sum(As.dout, P['img_stats'].dbias)
+    for i in range(self.n_prior):
+      xin = b['post'][:, :D] if i == 0 else self.a_img_out[i - 1].out
+      ops.gemm(xin, self.a_img_out[i].dz, P[f'img_out_{i}'].dW, ta=True)
+      lnp(P[f'img_out_{i}'], self.a_img_out[i])
+    ops.gemm(b['hprev'], b['dz3'], P['gru_h'].dW, ta=True)
+    ops.gemm(self.a_img_in.out, b['dz3'], P['gru_x'].dW, ta=True)
+    g = P['gru_h']
+    ops.ln_param_grad(b['dy3'], b['z3'], None, b['gstats'], g.dgamma, g.dbeta,
+                      False, False)
+    ops.gemm(b['xin'], self.a_img_in.dz, P['img_in'].dW, ta=True)
+    lnp(P['img_in'], self.a_img_in)
+    # learned initial deter: rows with is_first take init_deter
+    ops.gemm(b['first'].view(-1, 1), b['dhprev'], b['dinit_deter'], ta=True)
+    ops.tanh_bwd(m.p['rssm/initial_deter'], b['dinit_deter'].view(-1),
+                 m.g['rssm/initial_deter'], 0.0)
+
+  # --------------------------------------------------------------- optimizer
+
+  def opt_step(self, name, cfgkey):
+    g = self.groups[name]
+    c = self.cfg[cfgkey]
+    self.allreduce(g.gflat)
+    self.ops.grad_norm(g.gflat, g.opt_state)
+    self.ops.adam_step(g.flat, g.gflat, g.m, g.v, g.n_decay, g.opt_state,
+                       c['lr'], c['wd'], c['eps'], 0.9, 0.999, c['clip'])
+
+  # ------------------------------------------------------------------ phases
+
+  def upload(self, data):
+    """Host -> HBM staging of one replay minibatch (wire format)."""
+    s, b = self.spec, self.b
+    dev = self.device
+    def put(dst, arr, dtype=None):
+      t = torch.from_numpy(np.ascontiguousarray(arr))
+      if dtype is not None:
+        t = t.to(dtype)
+      dst.copy_(t.reshape(dst.shape).to(dev, non_blocking=True))
+    if s.enc_cnn_keys:
+      put(b['image'], data[s.enc_cnn_keys[0]])
+    if s.enc_mlp_keys:
+      cols = []
+      for k in s.enc_mlp_keys:
+        v = np.asarray(data[k], np.float32).reshape(self.N, -1)
+        cols.append(v)
+      put(b['vec_in'], np.concatenate(cols, -1))
+    for k in s.dec_mlp_keys:
+      put(b['vec_tgt'][k], np.asarray(data[k], np.float32))
+    put(b['action'], np.asarray(data['action'], np.float32))
+    put(b['reward'], np.asarray(data['reward'], np.float32))
+    put(b['is_first'], np.asarray(data['is_first']).astype(np.uint8))
+    put(b['is_terminal'], np.asarray(data['is_terminal']).astype(np.uint8))
+
+  def phase_prep(self):
+    ops, b = self.ops, self.b
+    B, T, N, H, G, A = self.B, self.T, self.N, self.H, self.G, self.A
+    ops.counter_add(self.step_ctr, 1)
+    ops.batch_prep(b['is_first'], b['is_terminal'], b['action'], b['first'],
+                   b['cont'], b['xin'][:, self.S:])
+    r0 = self.rank * B
+    ops.philox(b['u_prior'], T, B, G, self.Bg, r0, self.noise_seed, self.step_ctr, SITE_OBS_PRIOR, 0)
+    ops.philox(b['u_post'], T, B, G, self.Bg, r0, self.noise_seed, self.step_ctr, SITE_OBS_POST, 0)
+    if H > 0:
+      ops.philox(b['u_img'], H, N, G, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_IMG, 0)
+    ops.philox(b['eps'], H + 1, N, A, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_ACT, 1)
+
+  def phase_wm_fwd(self, use_carry):
+    ops, b, cfg = self.ops, self.b, self.cfg
+    N = self.N
+    self.encoder_fwd()
+    self.initial_fwd()
+    self.observe_fwd(use_carry)
+    feat = b['post']
+    self.decoder_fwd(feat)
+    ls = cfg['loss_scales']
+    (rew,) = self.head_fwd('reward', self.acts_wm['reward'], feat)
+    ops.scalar_loss(rew.view(-1), b['reward'], b['loss_reward'],
+                    self.acts_wm['reward'][1][0].dout.view(-1),
+                    ls.get('reward', 1.0) / self.Ng, 0)
+    (cont,) = self.head_fwd('cont', self.acts_wm['cont'], feat)
+    ops.scalar_loss(cont.view(-1), b['cont'], b['loss_cont'],
+                    self.acts_wm['cont'][1][0].dout.view(-1),
+                    ls.get('cont', 1.0) / self.Ng, 1)
+    ops.kl_fwd(b['post_logit'], b['prior_logit'], b['kl'], b['ent_post'],
+               b['ent_prior'], self.G, self.C)
+    k = self.stat('kl_loss', b['kl'])
+    # AutoAdapt is updated before it is used (reference tfutils.py:441-442)
+    self.allreduce(self.stat_sums[k])
+    c = cfg['wmkl']
+    if c['impl'] == 'mult':
+      ops.autoadapt_update(self.wmkl_scale, self.stat_sums[k], float(self.Ng),
+                           c['target'], 0.1, c['vel'], c['min'], c['max'], False)
+    self.stat('post_ent', b['ent_post'])
+    self.stat('prior_ent', b['ent_prior'])
+    self.stat('reward_loss', b['loss_reward'])
+    self.stat('cont_loss', b['loss_cont'])
+    if self.spec.dec_convs:
+      self.stat('image_loss', b['loss_image'])
+    for kk in self.spec.dec_mlp_keys:
+      self.stat(f'{kk}_loss', b['loss_vec'][kk])
+
+  def phase_wm_bwd(self):
+    ops, b, cfg = self.ops, self.b, self.cfg
+    feat, dfeat = b['post'], b['dfeat']
+    gh = cfg['grad_heads']
+    beta = 0.0
+    for name in ('reward', 'cont'):
+      flow = name in gh
+      self.head_bwd(name, self.acts_wm[name], feat, None,
+                    dfeat if flow else None, beta)
+      if flow:
+        beta = 1.0
+    if 'decoder' in gh:
+      self.decoder_bwd(feat, dfeat, beta)
+    else:
+      if beta == 0.0:
+        ops.fill(dfeat, 0.0)
+      tmp = self.b.setdefault('dfeat_sink', self.zeros(self.N, self.F))
+      self.decoder_bwd(feat, tmp, 0.0)
+    ops.kl_bwd(b['post_logit'], b['prior_logit'], self.wmkl_scale,
+               cfg['loss_scales'].get('kl', 1.0) / self.Ng, cfg['wmkl_balance'],
+               b['dpost_logit'], b['dprior_logit'], self.G, self.C)
+    self.observe_bwd()
+    self.encoder_bwd()
+    self.opt_step('model', 'model_opt')
+    # carry the last posterior to the next call (reference agent.py:211)
+    post = b['post'].view(self.B, self.T, self.F)
+    ops.copy2d(post[:, self.T - 1], b['carry'])
+
+  def phase_imagine(self):
+    ops, b, cfg = self.ops, self.b, self.cfg
+    N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
+    traj = b['traj']
+    ca = cfg['actor']
+    lo, hi = ca['minstd'], ca['maxstd']
+    ops.copy2d(b['post'], traj[0][:, :F])
+    la, oa = self.acts_im['actor']
+    for t in range(H + 1):
+      st = lambda buf, t_=t: buf.view(H + 1, N, -1)[t_]
+      om, os_ = self.head_fwd('actor', self.acts_im['actor'], traj[t][:, :F], st)
+      ops.normal_head_fwd(om, os_, b['eps'][t], traj[t][:, F:], lo, hi)
+      if t < H:
+        si = lambda buf, t_=t: buf.view(H, N, -1)[t_]
+        xs = self.cell_fwd(traj[t][:, D:], traj[t][:, :D], traj[t + 1][:, :D],
+                           self.ai_img_in, b['iz3'], b['igstats'],
+                           self.ai_img_out, self.ai_img_stats, si)
+        ops.stats_fwd(xs, b['u_img'][t], b['ilogit'], traj[t + 1][:, D:F],
+                      self.G, self.C, self.unimix, 0)
+    feat = traj.view(M, F + A)[:, :F]
+    (rew,) = self.head_fwd('reward', self.acts_im['reward'], feat)
+    (cont,) = self.head_fwd('cont', self.acts_im['cont'], feat)
+    tname = 'critic_target' if cfg['slow_target'] else 'critic'
+    self.tname = tname
+    if cfg['slow_target']:
+      (val,) = self.head_fwd('critic_target', self.acts_im['critic_target'], feat)
+    else:
+      raise NotImplementedError('slow_target: False')
+    ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont'],
+                         b['i_reward'], b['i_value'], b['i_cont'], b['i_weight'],
+                         b['i_ret'], H, N, cfg['discount'], cfg['return_lambda'])
+    # ---- critic update (reference agent.py:398-417)
+    HN = H * N
+    (cout,) = self.head_fwd('critic', self.acts_im['critic'], feat[:HN])
+    ops.critic_loss(cout.view(-1), b['i_ret'], b['i_weight'], b['i_crit_loss'],
+                    self.acts_im['critic'][1][0].dout.view(-1), 1.0 / (H * self.Ng))
+    self.head_bwd('critic', self.acts_im['critic'], feat[:HN])
+    self.stat('critic_loss', b['i_crit_loss'][:HN])
+    self.stat('imag_reward', b['i_reward'][:HN])
+    self.stat('imag_return', b['i_ret'][:HN])
+    self.stat('imag_value', b['i_value'])
+    self.opt_step('critic', 'critic_opt')
+
+  def update_slow(self):
+    """VFunction.update_slow (reference agent.py:444-454); host-side counter."""
+    cfg = self.cfg
+    if not cfg['slow_target']:
+      return
+    init = self.slow_updates == -1
+    if init or self.slow_updates >= cfg['slow_target_update']:
+      self.slow_updates = 0
+      mix = 1.0 if init else cfg['slow_target_fraction']
+      src, dst = self.groups['critic'], self.groups['critic_target']
+      assert src.n == dst.n and mix == 1.0, 'slow_target_fraction < 1'
+      # both arenas have the same layout: one flat copy
+      self.ops.copy2d(src.flat.view(1, -1), dst.flat.view(1, -1))
+    self.slow_updates += 1
+
+  def phase_actor(self):
+    ops, b, cfg = self.ops, self.b, self.cfg
+    N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
+    HN = H * N
+    traj, dtraj = b['traj'], b['dtraj']
+    feat = traj.view(M, F + A)[:, :F]
+    dfeat = dtraj.view(M, F + A)[:, :F]
+    ca = cfg['actor']
+    lo, hi = ca['minstd'], ca['maxstd']
+    # score with the post-update slow critic (reference agent.py:329-344)
+    (val,) = self.head_fwd('critic_target', self.acts_im['critic_target'], feat)
+    rew = self.acts_im['reward'][1][0].z
+    cont = self.acts_im['cont'][1][0].z
+    ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont'],
+                         b['i_reward'], b['i_value2'], None, None, b['i_ret2'],
+                         H, N, cfg['discount'], cfg['return_lambda'])
+    ops.sub(b['i_ret2'], b['i_value2'], b['i_diff'][:HN])
+    kr = self.stat('ret2', b['i_ret2'][:HN])
+    kd = self.stat('diff', b['i_diff'][:HN])
+    self.allreduce(self.stat_sums[kr])
+    self.allreduce(self.stat_sums[kd])
+    cnt = float(H * self.Ng)
+    impl = {'off': 0, 'mean_std': 1, 'std': 2}
+    c = cfg['retnorm']
+    ops.normalize_update(self.norm_state['ret'], self.stat_sums[kr], cnt, None,
+                         c['decay'], c['max'], impl[c['impl']], True, self.norm_os['ret'])
+    c = cfg['scorenorm']
+    ops.normalize_update(self.norm_state['score'], self.stat_sums[kd], cnt,
+                         self.norm_os['ret'][1:2], c['decay'], c['max'],
+                         impl[c['impl']], True, self.norm_os['score'])
+    ops.scalar_mul(self.sc[0:1], self.norm_os['ret'][1:2], self.norm_os['score'][1:2], 1.0)
+    c = cfg['advnorm']
+    ops.normalize_update(self.norm_state['adv'], self.stat_sums[kd], cnt,
+                         self.sc[0:1], c['decay'], c['max'], impl[c['impl']],
+                         True, self.norm_os['adv'])
+    ops.copy2d(self.norm_os['adv'].view(1, 2), self.sc[1:3].view(1, 2))
+    # entropy regulariser scale (AutoAdapt, inverse; reference agent.py:361-371)
+    if cfg['actent_norm']:
+      ent_lo, ent_div = math.log(lo), math.log(hi) - math.log(lo)
+    else:
+      ent_lo, ent_div = -0.5 * math.log(2 * math.pi * math.e), 1.0
+    os_all = self.acts_im['actor'][1][1].z
+    om_all = self.acts_im['actor'][1][0].z
+    ops.actent_stats(os_all, HN, lo, hi, ent_lo, ent_div, self.actent_sums)
+    self.allreduce(self.actent_sums)
+    c = cfg['actent']
+    if c['impl'] == 'mult':
+      ops.autoadapt_update(self.actent_scale, self.actent_sums, cnt, c['target'],
+                           0.1, c['vel'], c['min'], c['max'], True)
+    # seeds: d loss / d ret, d loss / d baseline
+    ops.actor_seed(b['i_ret2'][:HN], b['i_value2'][:HN], b['i_weight'][:HN],
+                   None, self.sc, b['i_actor_loss'][:HN], b['i_dret'][:HN],
+                   b['i_dbase'][:HN], 1.0 / cnt)
+    ops.imag_returns_bwd(b['i_dret'], b['i_dbase'], rew.view(-1), val.view(-1),
+                         cont.view(-1), b['i_value2'], b['i_ret2'],
+                         self.acts_im['reward'][1][0].dout.view(-1),
+                         self.acts_im['critic_target'][1][0].dout.view(-1),
+                         self.acts_im['cont'][1][0].dout.view(-1), H, N,
+                         cfg['discount'], cfg['return_lambda'])
+    ops.fill(dtraj, 0.0)
+    self.head_bwd('reward', self.acts_im['reward'], feat, None, dfeat, 0.0, params=False)
+    self.head_bwd('cont', self.acts_im['cont'], feat, None, dfeat, 1.0, params=False)
+    self.head_bwd('critic_target', self.acts_im['critic_target'], feat, None,
+                  dfeat, 1.0, params=False)
+    # reverse scan through the imagined world model (data gradients only)
+    zr = self.zero_rows[:N]
+    for t in reversed(range(1, H + 1)):
+      si = lambda buf, t_=t - 1: buf.view(H, N, -1)[t_]
+      ops.stats_bwd(si(self.ai_img_stats.z), None, dtraj[t][:, D:F],
+                    si(self.ai_img_stats.dout), self.G, self.C, self.unimix)
+      self.cell_bwd(dtraj[t][:, :D], None, traj[t - 1][:, :D], self.ai_img_in,
+                    b['iz3'], b['igstats'], self.ai_img_out, self.ai_img_stats,
+                    si, b['idz3'], b['idy3'], b['idh'], dtraj[t - 1][:, D:], 1.0,
+                    self.P['img_in'])
+      ops.reset_mask_bwd(b['idh'], zr, dtraj[t - 1][:, :D])
+    # policy head + entropy bonus, then the actor network (bulk)
+    dact = dtraj.view(M, F + A)[:, F:]
+    oa = self.acts_im['actor'][1]
+    ops.normal_head_bwd(om_all, os_all, b['eps'].view(M, A), dact, b['i_weight'],
+                        self.actent_scale, oa[0].dout, oa[1].dout, b['i_ent_row'],
+                        HN, lo, hi, 1.0 / (cnt * ent_div), ent_lo, ent_div)
+    self.head_bwd('actor', self.acts_im['actor'], feat)
+    self.stat('actor_loss_score', b['i_actor_loss'][:HN])
+    self.stat('actor_loss_ent', b['i_ent_row'][:HN])
+    self.opt_step('actor', 'actor_opt')
+
+  # --------------------------------------------------------------- train step
+
+  def train_step_device(self, use_carry=True):
+    """All device work of one Agent.train call (inputs already uploaded)."""
+    if not use_carry:
+      self.reset_carry()
+      use_carry = True
+    self.phase_prep()
+    self.phase_wm_fwd(use_carry)
+    self.phase_wm_bwd()
+    self.phase_imagine()
+    self.update_slow()
+    self.phase_actor()
+
+  def read_metrics(self):
+    """One device->host transfer of the statistics slabs -> metrics dict with
+    the reference's names (agent.py:184-203, 339-342, 407-415, tfutils.py
+    :208,250,266,445-446)."""
+    cfg = self.cfg
+    sums = self.stat_sums.clone()
+    maxs = self.stat_maxs.clone()
+    if self.comm is not None and self.world > 1:
+      self.comm.allreduce_sum(sums)
+      self.comm.allreduce_max(maxs)
+    sums, maxs = sums.cpu().numpy(), maxs.cpu().numpy()
+    N, H, w = self.N, self.H, self.world
+    counts = dict(imag_value=(H + 1) * N * w)
+    for k in ('critic_loss', 'imag_reward', 'imag_return', 'ret2', 'diff',
+              'actor_loss_score', 'actor_loss_ent'):
+      counts[k] = H * N * w
+    st = {}
+    for i, name in enumerate(self.stat_names):
+      n = counts.get(name, N * w)
+      mean = sums[i, 0] / n
+      var = max(sums[i, 1] / n - mean * mean, 0.0)
+      st[name] = dict(mean=mean, std=math.sqrt(var), sum=sums[i, 0],
+                      max=maxs[i, 0], min=-maxs[i, 1], absmax=maxs[i, 2],
+                      absmean=sums[i, 2] / n)
+    mets = {}
+    f = np.float32
+    ls = cfg['loss_scales']
+    wmkl = float(self.wmkl_scale.cpu()[0])
+    model_loss = 0.0
+    for name in st:
+      if name.endswith('_loss') and name not in ('critic_loss',):
+        key = name[:-5]
+        mets[f'{key}_loss_mean'] = st[name]['mean']
+        mets[f'{key}_loss_std'] = st[name]['std']
+        scale = wmkl if key == 'kl' else 1.0
+        model_loss += ls.get(key, 1.0) * scale * st[name]['mean']
+    mets['kl_loss_mean'] = wmkl * st['kl_loss']['mean']
+    mets['kl_loss_std'] = wmkl * st['kl_loss']['std']
+    mets['wmkl_mean'] = st['kl_loss']['mean']
+    mets['wmkl_std'] = st['kl_loss']['std']
+    mets['wmkl_scale_mean'] = wmkl
+    mets['wmkl_scale_std'] = 0.0
+    mets['prior_ent_mean'] = st['prior_ent']['mean']
+    mets['post_ent_mean'] = st['post_ent']['mean']
+    mets['prior_ent_min'] = st['prior_ent']['min']
+    mets['post_ent_min'] = st['post_ent']['min']
+    mets['model_loss_mean'] = model_loss
+    mets['model_loss'] = model_loss
+    for gname, pre in (('model', ''), ('critic', 'extr_'), ('actor', '')):
+      o = self.groups[gname].opt_state.cpu().numpy()
+      mets[f'{pre}{gname}_grad_norm'] = o[1]
+      mets[f'{pre}{gname}_grad_steps'] = o[0]
+      if o[2] == 0.0:
+        raise FloatingPointError(f'{gname}_norm is not finite')
+    mets['extr_critic_loss'] = st['critic_loss']['mean']
+    mets['extr_imag_reward_mean'] = st['imag_reward']['mean']
+    mets['extr_imag_reward_std'] = st['imag_reward']['std']
+    mets['extr_imag_return_mean'] = st['imag_return']['mean']
+    mets['extr_imag_return_std'] = st['imag_return']['std']
+    sc = self.sc.cpu().numpy()
+    d = st['diff']
+    mets['extr_score_mean'] = d['mean'] * sc[0]
+    mets['extr_score_std'] = d['std'] * sc[0]
+    mets['extr_score_mag'] = d['absmean'] * sc[0]
+    mets['extr_score_max'] = d['absmax'] * sc[0]
+    mets['actor_loss'] = (st['actor_loss_score']['mean'] +
+                          st['actor_loss_ent']['mean'])
+    asum = self.actent_sums.cpu().numpy()
+    cnt = H * N * w
+    A = self.A
+    emean = asum[:A].sum() / (cnt * A)
+    mets['actent_mean'] = emean
+    mets['actent_std'] = math.sqrt(max(asum[A:].sum() / (cnt * A) - emean ** 2, 0.0))
+    a = self.actent_scale.cpu().numpy()
+    mets['actent_scale_mean'] = a.mean()
+    mets['actent_scale_std'] = a.std()
+    for k in ('model_loss', 'extr_critic_loss', 'actor_loss'):
+      if not np.isfinite(mets[k]):
+        raise FloatingPointError(f'{k} is not finite')
+    return {k: np.asarray(v, f) for k, v in mets.items()}
+
+  # ----------------------------------------------------------------- export
+
+  def export_params(self):
+    out = {}
+    for g in self.groups.values():
+      for p in g.specs:
+        out[p.name] = g.p[p.name].detach().cpu().numpy().copy()
+    return out
+
+  def export_grads(self):
+    out = {}
+    for n in ('model', 'actor', 'critic'):
+      g = self.groups[n]
+      for p in g.specs:
+        out[p.name] = g.g[p.name].detach().cpu().numpy().copy()
+    return out

@@ -93,13 +93,13 @@ class RefOps:
     C.copy_(r)
 
   @staticmethod
-  def _big(big, in_scale):
+  def _big(big, in_scale, dtype):
     if big.dtype == torch.uint8:
-      return big.float() * np.float32(in_scale)
+      return big.to(dtype) * torch.tensor(in_scale, dtype=dtype)
     return big
 
   def conv_down(self, big, w, bias, small, k, in_scale=1.0):
-    x = self._big(big, in_scale).permute(0, 3, 1, 2)
+    x = self._big(big, in_scale, w.dtype).permute(0, 3, 1, 2)
     y = F.conv2d(x, w.permute(3, 2, 0, 1), stride=2).permute(0, 2, 3, 1)
     hs, ws = small.shape[1:3]
     y = y[:, :hs, :ws]
@@ -114,7 +114,7 @@ class RefOps:
     big.copy_(out + bias if bias is not None else out)
 
   def conv_wgrad(self, big, small, dw, k, in_scale=1.0, beta=0.0):
-    x = self._big(big, in_scale)
+    x = self._big(big, in_scale, small.dtype)
     n, hs, ws, cs = small.shape
     g = torch.zeros_like(dw)
     for ky in range(k):
@@ -280,7 +280,7 @@ class RefOps:
   def image_loss(self, z, img, loss, dz, coef):
     rows = z.shape[0]
     s = torch.sigmoid(z.reshape(rows, -1))
-    d = s - img.reshape(rows, -1).float() * np.float32(1.0 / 255.0)
+    d = s - img.reshape(rows, -1).to(z.dtype) * torch.tensor(1.0 / 255.0, dtype=z.dtype)
     loss.copy_((d * d).sum(-1))
     dz.copy_((coef * 2 * d * s * (1 - s)).reshape(dz.shape))
 
@@ -465,8 +465,8 @@ class RefOps:
                 clip):
     if float(opt_state[2]) == 0.0:
       return
-    norm = np.float32(float(opt_state[1]))
-    gs = np.float32(clip) / max(norm, np.float32(clip)) if clip > 0 else 1.0
+    norm = float(opt_state[1])
+    gs = clip / max(norm, clip) if clip > 0 else 1.0
     t = float(opt_state[0])
     gi = g * gs
     p[:n_decay] *= (1 - wd * lr)

@@ -1,0 +1,63 @@
+"""Shared builders for the parity tests."""
+
+import numpy as np
+import torch
+
+from daydreamer_amd import config, spec, synthetic
+
+
+def make_config(blocks=('a1_vision', 'debug'), **overrides):
+  cfgs = config.load_configs()
+  cfg = config.Config(cfgs['defaults'])
+  for b in blocks:
+    cfg = cfg.update(cfgs[b])
+  if overrides:
+    cfg = cfg.update(overrides)
+  return cfg
+
+
+def make_problem(cfg, image=64, vector=5, action=3, batch=None, length=None,
+                 seed=0, terminals=0.1, smooth=True):
+  plain = config.to_plain(cfg)
+  obs, act = synthetic.make_spaces(image, vector, action)
+  shapes = {k: v.shape for k, v in obs.items()}
+  sp = spec.build_spec(plain, shapes, action)
+  params = spec.init_params(sp, seed)
+  # non-trivial norm / bias parameters so their gradients are exercised
+  rng = np.random.RandomState(seed + 1)
+  for p in sp.params:
+    if p.init == 'ones':
+      params[p.name] = (1 + 0.1 * rng.randn(*p.shape)).astype(np.float32)
+    elif p.init == 'zeros':
+      params[p.name] = (0.1 * rng.randn(*p.shape)).astype(np.float32)
+  B = batch or plain['batch_size']
+  T = length or plain['replay_chunk']
+  data = synthetic.make_batch(obs, act, B, T, seed=seed + 2,
+                              terminals=terminals, smooth_images=smooth)
+  return plain, sp, shapes, params, data, B, T
+
+
+def forced_from_learner(L):
+  """Sample indices the learner drew, in the oracle's layout."""
+  b = L.b
+  B, T, N, H, D, F, G, C = L.B, L.T, L.N, L.H, L.D, L.F, L.G, L.C
+  post = b['post'].view(B, T, F)[:, :, D:].reshape(B, T, G, C)
+  prior = b['prior_stoch'].view(B, T, G, C)
+  img = b['traj'][1:, :, D:F].reshape(H, N, G, C)
+  return dict(
+      obs_post=post.argmax(-1).permute(1, 0, 2).cpu(),
+      obs_prior=prior.argmax(-1).permute(1, 0, 2).cpu(),
+      img=img.argmax(-1).cpu())
+
+
+def noise_from_learner(L):
+  b = L.b
+  return dict(
+      u_obs_prior=b['u_prior'].cpu().numpy(), u_obs_post=b['u_post'].cpu().numpy(),
+      u_img=b['u_img'].cpu().numpy(), eps_act=b['eps'].cpu().numpy())
+
+
+def rel_err(a, b):
+  a = np.asarray(a, np.float64)
+  b = np.asarray(b, np.float64)
+  return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

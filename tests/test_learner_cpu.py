@@ -1,0 +1,86 @@
+"""Host-logic parity on CPU: the learner's explicit forward / hand-derived
+backward (driven through the kernel restatements of oracle/ref_ops.py, in
+float64) against the autograd oracle oracle/dreamer_ref.py on the same
+minibatch, weights and noise: losses, every parameter gradient, every updated
+parameter, controller state, two consecutive steps."""
+
+import numpy as np
+import pytest
+import torch
+
+from daydreamer_amd import learner as learner_mod
+from oracle import dreamer_ref, ref_ops
+import helpers
+
+
+def run_pair(cfg, steps=2, **kw):
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, **kw)
+  ops = ref_ops.RefOps('cpu')
+  L = learner_mod.Learner(sp, ops, 'cpu', B, T, params=params, noise_seed=7,
+                          dtype=torch.float64)
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64)
+  state = None
+  out = []
+  for i in range(steps):
+    p_before = L.export_params()
+    L.upload(data)
+    L.train_step_device(use_carry=(i > 0))
+    mets = L.read_metrics()
+    noise = helpers.noise_from_learner(L)
+    forced = helpers.forced_from_learner(L)
+    _, state, omets = ag.train(data, noise, state, forced)
+    out.append((L, ag, mets, omets))
+    grads = L.export_grads()
+    for name, g in ag.last['grads'].items():
+      err = helpers.rel_err(grads[name], g.numpy())
+      assert err < 1e-6, f'step {i} grad {name}: rel err {err:.3e}'
+    newp = L.export_params()
+    for name, v in ag.export_params().items():
+      err = helpers.rel_err(newp[name], v)
+      assert err < 1e-7, f'step {i} param {name}: rel err {err:.3e}'
+    for k in ('model_loss', 'image_loss_mean', 'vector_loss_mean', 'kl_loss_mean',
+              'reward_loss_mean', 'cont_loss_mean', 'extr_critic_loss', 'actor_loss',
+              'model_grad_norm', 'extr_critic_grad_norm', 'actor_grad_norm',
+              'wmkl_scale_mean', 'actent_mean', 'actent_scale_mean',
+              'extr_score_mean', 'extr_score_std', 'extr_score_mag', 'extr_score_max',
+              'prior_ent_mean', 'post_ent_mean', 'prior_ent_min', 'post_ent_min',
+              'extr_imag_reward_mean', 'extr_imag_return_std', 'kl_loss_std',
+              'reward_loss_std', 'actent_std'):
+      if k not in omets:
+        continue
+      a, o = float(mets[k]), float(omets[k])
+      assert abs(a - o) <= 2e-6 * max(1.0, abs(o)), f'step {i} metric {k}: {a} vs {o}'
+  return out
+
+
+def test_learner_matches_oracle_vision():
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=3,
+                            replay_chunk=5, imag_horizon=4)
+  run_pair(cfg, steps=2, image=64, vector=5, action=3, terminals=0.15)
+
+
+def test_learner_matches_oracle_proprio():
+  """BASELINE configs[0] shape family: a1 block, proprio only (vector 7, A 6)."""
+  cfg = helpers.make_config(('a1', 'debug'), batch_size=4, replay_chunk=6,
+                            imag_horizon=3)
+  run_pair(cfg, steps=2, image=0, vector=7, action=6, terminals=0.1)
+
+
+def test_weight_decay_and_is_first_midsequence():
+  cfg = helpers.make_config(('a1', 'debug'), batch_size=3, replay_chunk=6,
+                            imag_horizon=2)
+  cfg = cfg.update({'model_opt.wd': 1e-2, 'actor_opt.wd': 1e-2, 'critic_opt.wd': 1e-2})
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, image=0, vector=7, action=6)
+  data['is_first'][1, 3] = True
+  data['is_first'][2, 1] = True
+  ops = ref_ops.RefOps('cpu')
+  L = learner_mod.Learner(sp, ops, 'cpu', B, T, params=params, dtype=torch.float64)
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64)
+  L.upload(data)
+  L.train_step_device(use_carry=False)
+  ag.train(data, helpers.noise_from_learner(L), None, helpers.forced_from_learner(L))
+  grads, newp = L.export_grads(), L.export_params()
+  for name, g in ag.last['grads'].items():
+    assert helpers.rel_err(grads[name], g.numpy()) < 1e-6, name
+  for name, v in ag.export_params().items():
+    assert helpers.rel_err(newp[name], v) < 1e-7, name
