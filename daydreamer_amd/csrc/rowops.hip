@@ -22,7 +22,7 @@ template <int NPL>
 __global__ void __launch_bounds__(256)
 k_ln_act_fwd(const float* __restrict__ z, long ldz, const float* __restrict__ gamma,
              const float* __restrict__ beta, float* __restrict__ out, long ldo,
-             float* __restrict__ stats, int rows, int C, int act) {
+             float* __restrict__ stats, long lds, int rows, int C, int act) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
     const float* zr = z + row * ldz;
@@ -67,7 +67,7 @@ k_ln_act_fwd(const float* __restrict__ z, long ldz, const float* __restrict__ ga
         orow[c] = act ? elu_(y) : y;
       }
     }
-    if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    if (lane == 0) { stats[row * lds] = mean; stats[row * lds + 1] = rstd; }
   }
 }
 
@@ -76,7 +76,7 @@ k_ln_act_fwd(const float* __restrict__ z, long ldz, const float* __restrict__ ga
 template <int NPL>
 __global__ void __launch_bounds__(256)
 k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
-             const float* __restrict__ out, long ldo, const float* __restrict__ stats,
+             const float* __restrict__ out, long ldo, const float* __restrict__ stats, long lds,
              const float* __restrict__ gamma, float* __restrict__ dz, long lddz,
              float* __restrict__ partials, int rows, int C, int act) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -84,7 +84,7 @@ k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__
 #pragma unroll
   for (int i = 0; i < (NPL > 0 ? NPL : 1); ++i) { pg[i] = 0.f; pb[i] = 0.f; }
   for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
-    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const float mean = stats[row * lds], rstd = stats[row * lds + 1];
     const float* dr = dout + row * ldd;
     const float* zr = z + row * ldz;
     const float* orow = out + row * ldo;
@@ -154,7 +154,7 @@ k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__
 // block, grid.y row chunks -> partials[grid.y][2][C] -------------------------
 __global__ void __launch_bounds__(256)
 k_ln_param_grad(const float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
-                const float* __restrict__ out, long ldo, const float* __restrict__ stats,
+                const float* __restrict__ out, long ldo, const float* __restrict__ stats, long lds,
                 float* __restrict__ partials, int rows, int C, int act) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -163,7 +163,7 @@ k_ln_param_grad(const float* __restrict__ dout, long ldd, const float* __restric
     for (long row = (long)blockIdx.y * 4 + rl; row < rows; row += (long)gridDim.y * 4) {
       float dy = dout[row * ldd + c];
       if (act) { float o = out[row * ldo + c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
-      float xh = (z[row * ldz + c] - stats[row * 2]) * stats[row * 2 + 1];
+      float xh = (z[row * ldz + c] - stats[row * lds]) * stats[row * lds + 1];
       a += dy * xh;
       b += dy;
     }
@@ -213,7 +213,7 @@ k_col_sum(const float* __restrict__ x, long ldx, float* __restrict__ partials, l
 __global__ void __launch_bounds__(256)
 k_gru_fwd(const float* __restrict__ z3, long ldz, const float* __restrict__ gamma,
           const float* __restrict__ beta, const float* __restrict__ h, long ldh,
-          float* __restrict__ hn, long ldn, float* __restrict__ stats, int rows, int D) {
+          float* __restrict__ hn, long ldn, float* __restrict__ stats, long lds, int rows, int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = 3 * D;
   for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
@@ -234,7 +234,7 @@ k_gru_fwd(const float* __restrict__ z3, long ldz, const float* __restrict__ gamm
       float hp = h[row * ldh + j];
       hn[row * ldn + j] = u * cand + (1.f - u) * hp;
     }
-    if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    if (lane == 0) { stats[row * lds] = mean; stats[row * lds + 1] = rstd; }
   }
 }
 
@@ -243,7 +243,7 @@ k_gru_fwd(const float* __restrict__ z3, long ldz, const float* __restrict__ gamm
 // parameter-gradient pass).
 __global__ void __launch_bounds__(256)
 k_gru_bwd(const float* __restrict__ dhn, long lddn, const float* __restrict__ z3, long ldz,
-          const float* __restrict__ stats, const float* __restrict__ gamma,
+          const float* __restrict__ stats, long lds, const float* __restrict__ gamma,
           const float* __restrict__ beta, const float* __restrict__ h, long ldh,
           float* __restrict__ dz3, long lddz, float* __restrict__ dh, long lddh,
           float* __restrict__ dy3, long lddy, int rows, int D) {
@@ -251,7 +251,7 @@ k_gru_bwd(const float* __restrict__ dhn, long lddn, const float* __restrict__ z3
   const int C = 3 * D;
   for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
     const float* zr = z3 + row * ldz;
-    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const float mean = stats[row * lds], rstd = stats[row * lds + 1];
     float* dyr = dy3 + row * lddy;
     float s1 = 0.f, s2 = 0.f;
     for (int j = lane; j < D; j += 64) {
@@ -312,13 +312,13 @@ inline int row_blocks(long rows, int cap) {
 }  // namespace
 
 extern "C" int dd_ln_act_fwd(const float* z, long ldz, const float* gamma, const float* beta,
-                             float* out, long ldo, float* stats, int rows, int C, int act,
+                             float* out, long ldo, float* stats, long lds, int rows, int C, int act,
                              void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int blocks = row_blocks(rows, 1 << 20);
   return dispatch_npl(C, [&](auto npl) {
-    k_ln_act_fwd<decltype(npl)::value><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, rows, C, act);
+    k_ln_act_fwd<decltype(npl)::value><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act);
     DD_CHECK_LAUNCH("dd_ln_act_fwd");
     return 0;
   });
@@ -334,7 +334,7 @@ extern "C" int dd_ln_bwd_parts(int rows, int C) {
 }
 
 extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
-                             const float* out, long ldo, const float* stats, const float* gamma,
+                             const float* out, long ldo, const float* stats, long lds, const float* gamma,
                              float* dz, long lddz, float* dgamma, float* dbeta, int accumulate,
                              int rows, int C, int act, float* ws, size_t ws_bytes, void* stream) {
   if (rows <= 0) return 0;
@@ -346,14 +346,14 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
   int blocks = fused ? parts : row_blocks(rows, 1 << 20);
   int rc = dispatch_npl(C, [&](auto npl) {
     k_ln_act_bwd<decltype(npl)::value><<<blocks, 256, 0, st>>>(
-        dout, ldd, z, ldz, out, ldo, stats, gamma, dz, lddz, fused ? ws : nullptr, rows, C, act);
+        dout, ldd, z, ldz, out, ldo, stats, lds, gamma, dz, lddz, fused ? ws : nullptr, rows, C, act);
     DD_CHECK_LAUNCH("dd_ln_act_bwd");
     return 0;
   });
   if (rc || !want) return rc;
   if (!fused) {
     dim3 grid((C + 63) / 64, parts);
-    k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, ws, rows, C, act);
+    k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, lds, ws, rows, C, act);
     DD_CHECK_LAUNCH("dd_ln_act_bwd(param grad)");
   }
   // partials are [parts][2][C]: gamma rows at stride 2C from ws, beta rows from ws + C.
@@ -369,7 +369,7 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
 // Parameter gradients only (bulk pass after a scan): dgamma/dbeta from stored
 // dout / out / z / stats of all steps.
 extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, long ldz,
-                                const float* out, long ldo, const float* stats,
+                                const float* out, long ldo, const float* stats, long lds,
                                 float* dgamma, float* dbeta, int accumulate, int rows, int C,
                                 int act, float* ws, size_t ws_bytes, void* stream) {
   if (rows <= 0) return 0;
@@ -378,7 +378,7 @@ extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, lon
   const int parts = (int)(chunks > 256 ? 256 : (chunks < 1 ? 1 : chunks));
   DD_REQUIRE(ws && (size_t)parts * 2 * C * sizeof(float) <= ws_bytes, "dd_ln_param_grad: workspace too small");
   dim3 grid((C + 63) / 64, parts);
-  k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, ws, rows, C, act);
+  k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, lds, ws, rows, C, act);
   DD_CHECK_LAUNCH("dd_ln_param_grad");
   const int nb = (C + 255) / 256;
   const float b = accumulate ? 1.f : 0.f;
@@ -390,23 +390,23 @@ extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, lon
 }
 
 extern "C" int dd_gru_cell_fwd(const float* z3, long ldz, const float* gamma, const float* beta,
-                               const float* h, long ldh, float* hn, long ldn, float* stats,
+                               const float* h, long ldh, float* hn, long ldn, float* stats, long lds,
                                int rows, int D, void* stream) {
   if (rows <= 0) return 0;
   k_gru_fwd<<<row_blocks(rows, 1 << 20), 256, 0, (hipStream_t)stream>>>(
-      z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, rows, D);
+      z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, D);
   DD_CHECK_LAUNCH("dd_gru_cell_fwd");
   return 0;
 }
 
 extern "C" int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
-                               const float* stats, const float* gamma, const float* beta,
+                               const float* stats, long lds, const float* gamma, const float* beta,
                                const float* h, long ldh, float* dz3, long lddz,
                                float* dh, long lddh, float* dy3, long lddy,
                                int rows, int D, void* stream) {
   if (rows <= 0) return 0;
   k_gru_bwd<<<row_blocks(rows, 1 << 20), 256, 0, (hipStream_t)stream>>>(
-      dhn, lddn, z3, ldz, stats, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, rows, D);
+      dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, rows, D);
   DD_CHECK_LAUNCH("dd_gru_cell_bwd");
   return 0;
 }

@@ -31,13 +31,13 @@ _SIGS = {
     'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
     'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
-    'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_p],
-    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
+    'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_ln_bwd_parts': [c_i, c_i],
-    'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
+    'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_col_sum': [c_p, c_l, c_p, c_f, c_l, c_i, c_p, c_z, c_p],
-    'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p],
-    'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
     'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
     'dd_cat_kl_fwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -182,7 +182,7 @@ class HipOps:
     zp, ldz = _mat(z)
     op, ldo = _mat(out)
     self._check(self.lib.dd_ln_act_fwd(
-        zp, ldz, gamma.data_ptr(), beta.data_ptr(), op, ldo, stats.data_ptr(),
+        zp, ldz, gamma.data_ptr(), beta.data_ptr(), op, ldo, *_mat(stats),
         rows, C, int(act), self.stream), 'dd_ln_act_fwd')
 
   def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
@@ -193,7 +193,7 @@ class HipOps:
     op, ldo = _mat(out)
     dzp, lddz = _mat(dz)
     self._check(self.lib.dd_ln_act_bwd(
-        dp, ldd, zp, ldz, op, ldo, stats.data_ptr(), gamma.data_ptr(), dzp,
+        dp, ldd, zp, ldz, op, ldo, *_mat(stats), gamma.data_ptr(), dzp,
         lddz, _ptr(dgamma), _ptr(dbeta), int(accumulate), rows, C, int(act),
         self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_ln_act_bwd')
 
@@ -204,7 +204,7 @@ class HipOps:
     zp, ldz = _mat(z)
     op, ldo = _mat(out) if out is not None else (0, 0)
     self._check(self.lib.dd_ln_param_grad(
-        dp, ldd, zp, ldz, op, ldo, stats.data_ptr(), dgamma.data_ptr(),
+        dp, ldd, zp, ldz, op, ldo, *_mat(stats), dgamma.data_ptr(),
         dbeta.data_ptr(), int(accumulate), rows, C, int(act),
         self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_ln_param_grad')
 
@@ -222,7 +222,7 @@ class HipOps:
     np_, ldn = _mat(hn)
     self._check(self.lib.dd_gru_cell_fwd(
         zp, ldz, gamma.data_ptr(), beta.data_ptr(), hp, ldh, np_, ldn,
-        stats.data_ptr(), rows, D, self.stream), 'dd_gru_cell_fwd')
+        *_mat(stats), rows, D, self.stream), 'dd_gru_cell_fwd')
 
   def gru_bwd(self, dhn, z3, stats, gamma, beta, h, dz3, dh, dy3):
     rows, D = h.shape
@@ -233,7 +233,7 @@ class HipOps:
     dhp, lddh = _mat(dh)
     dyp, lddy = _mat(dy3)
     self._check(self.lib.dd_gru_cell_bwd(
-        a, lda, zp, ldz, stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+        a, lda, zp, ldz, *_mat(stats), gamma.data_ptr(), beta.data_ptr(),
         hp, ldh, dzp, lddz, dhp, lddh, dyp, lddy, rows, D, self.stream),
         'dd_gru_cell_bwd')
 

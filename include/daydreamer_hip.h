@@ -63,18 +63,18 @@ int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float
 /* ---- LayerNorm(+ELU), GRU cell -------------------------------------------- */
 
 /* out = act(LN(z)*gamma+beta), eps 1e-3, population variance; act 0 none,
- * 1 elu.  stats[rows,2] = (mean, rstd).  Norm nets.py:585-602 + get_act. */
+ * 1 elu.  stats[rows,2] = (mean, rstd), row stride lds.  Norm nets.py:585-602 + get_act. */
 int dd_ln_act_fwd(const float* z, long ldz, const float* gamma, const float* beta,
-                  float* out, long ldo, float* stats, int rows, int C, int act, void* stream);
+                  float* out, long ldo, float* stats, long lds, int rows, int C, int act, void* stream);
 /* dz from dout; if dgamma != NULL also dgamma/dbeta (accumulate: += ). */
 int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
-                  const float* out, long ldo, const float* stats, const float* gamma,
+                  const float* out, long ldo, const float* stats, long lds, const float* gamma,
                   float* dz, long lddz, float* dgamma, float* dbeta, int accumulate,
                   int rows, int C, int act, float* ws, size_t ws_bytes, void* stream);
 int dd_ln_bwd_parts(int rows, int C);
 /* dgamma/dbeta only, from stored activations of all scan steps. */
 int dd_ln_param_grad(const float* dout, long ldd, const float* z, long ldz,
-                     const float* out, long ldo, const float* stats,
+                     const float* out, long ldo, const float* stats, long lds,
                      float* dgamma, float* dbeta, int accumulate, int rows, int C,
                      int act, float* ws, size_t ws_bytes, void* stream);
 
@@ -85,11 +85,11 @@ int dd_col_sum(const float* x, long ldx, float* out, float beta, long rows, int 
 /* RSSM._gru nets.py:149-160 after the [D+U,3D] matmul: LayerNorm over all 3D,
  * reset/cand/update gates, new deter.  z3 [rows,3D]; h, hn [rows,D]. */
 int dd_gru_cell_fwd(const float* z3, long ldz, const float* gamma, const float* beta,
-                    const float* h, long ldh, float* hn, long ldn, float* stats,
+                    const float* h, long ldh, float* hn, long ldn, float* stats, long lds,
                     int rows, int D, void* stream);
 /* dz3 (through LN), dh = (1-update)*dhn, dy3 = gradient at the LN output. */
 int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
-                    const float* stats, const float* gamma, const float* beta,
+                    const float* stats, long lds, const float* gamma, const float* beta,
                     const float* h, long ldh, float* dz3, long lddz,
                     float* dh, long lddh, float* dy3, long lddy,
                     int rows, int D, void* stream);

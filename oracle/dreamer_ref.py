@@ -58,7 +58,10 @@ def symexp(x):  # tfutils.py:81-82
   return torch.sign(x) * (torch.exp(torch.abs(x)) - 1)
 
 
-def sample_onehot(probs, u, forced=None, tol=1e-5):
+SAMPLE_TOL = [1e-5]  # near-boundary tolerance for forced draws (tests may widen)
+
+
+def sample_onehot(probs, u, forced=None, tol=None):
   """Inverse-CDF categorical draw (replaces tf.random.categorical,
   tfutils.py:374).  probs [..., C], u [...] in [0,1).  Returns int64 indices.
 
@@ -66,6 +69,7 @@ def sample_onehot(probs, u, forced=None, tol=1e-5):
   If `forced` is given (indices drawn by the device path from the same u), it
   is adopted wherever u lies within `tol` of a CDF boundary (float reassociation
   can legitimately flip such draws) and must otherwise agree exactly."""
+  tol = SAMPLE_TOL[0] if tol is None else tol
   cdf = torch.cumsum(probs.detach(), -1)
   thr = (u * cdf[..., -1])[..., None]
   idx = (cdf[..., :-1] <= thr).sum(-1)
@@ -73,10 +77,12 @@ def sample_onehot(probs, u, forced=None, tol=1e-5):
     forced = torch.as_tensor(forced, dtype=torch.int64)
     differ = idx != forced
     if differ.any():
-      near = (torch.abs(cdf - thr).min(-1).values < tol)
+      gap = torch.abs(cdf - thr).min(-1).values
+      near = gap < tol
       bad = differ & ~near
       assert not bad.any(), (
-          f'{int(bad.sum())} forced samples disagree outside tolerance')
+          f'{int(bad.sum())} forced samples disagree outside tolerance '
+          f'(max gap {float(gap[differ].max()):.3e}, tol {tol:.1e})')
       idx = torch.where(differ, forced, idx)
   return idx
 

@@ -422,9 +422,10 @@ class RefOps:
     above = avg > np.float32(1.0 + thres) * np.float32(target)
     if inverse:
       below, above = above, below
-    adj = torch.where(above, scale * (1 + vel),
-                      torch.where(below, scale / (1 + vel), scale))
-    scale.copy_(torch.clamp(adj, lo, hi))
+    s32 = scale.float()  # the controller state is float32 (tfutils.py:430)
+    adj = torch.where(above, s32 * np.float32(1 + vel),
+                      torch.where(below, s32 / np.float32(1 + vel), s32))
+    scale.copy_(torch.clamp(adj, np.float32(lo), np.float32(hi)))
 
   def normalize_update(self, state, sums, count, in_scale_dev, decay, maxv,
                        impl, do_update, out):

@@ -149,6 +149,29 @@ def test_ln_act(hip, ref, rows, C, act):
     close(g, c, rtol=1e-4, what=f'ln_param_grad {nm}')
 
 
+def test_ln_gru_strided_rows(hip, ref):
+  """Scan-step views of batch-major [B,T,C] buffers: every operand, including
+  the (mean, rstd) stats, is row-strided."""
+  B, T, C, D = 6, 5, 256, 64
+  z, out, stats = rnd(B, T, C, seed=1), torch.zeros(B, T, C), torch.zeros(B, T, 2)
+  gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+  dout, dz = rnd(B, T, C, seed=4), torch.zeros(B, T, C)
+  z3, h, hn, gst = rnd(B, T, 3 * D, seed=5), rnd(B, T, D, seed=6), torch.zeros(B, T, D), torch.zeros(B, T, 2)
+  g3, b3 = 1 + 0.1 * rnd(3 * D, seed=7), 0.1 * rnd(3 * D, seed=8)
+  dhn, dz3, dh, dy3 = rnd(B, T, D, seed=9), torch.zeros(B, T, 3 * D), torch.zeros(B, T, D), torch.zeros(B, T, 3 * D)
+  def fn(ops, z, out, stats, gamma, beta, dout, dz, z3, h, hn, gst, g3, b3, dhn, dz3, dh, dy3):
+    for t in range(T):
+      ops.ln_act_fwd(z[:, t], gamma, beta, out[:, t], stats[:, t], True)
+      ops.gru_fwd(z3[:, t], g3, b3, h[:, t], hn[:, t], gst[:, t])
+    for t in range(T):
+      ops.ln_act_bwd(dout[:, t], z[:, t], out[:, t], stats[:, t], gamma, dz[:, t])
+      ops.gru_bwd(dhn[:, t], z3[:, t], gst[:, t], g3, b3, h[:, t], dz3[:, t], dh[:, t], dy3[:, t])
+  res = both(hip, ref, fn, [z, out, stats, gamma, beta, dout, dz, z3, h, hn, gst, g3, b3, dhn, dz3, dh, dy3],
+             [1, 2, 6, 9, 10, 14, 15, 16])
+  for (g, c), nm in zip(res, ['out', 'stats', 'dz', 'hn', 'gstats', 'dz3', 'dh', 'dy3']):
+    close(g, c, rtol=1e-4, what=f'strided {nm}')
+
+
 def test_ln_act_views(hip, ref):
   buf, obuf = rnd(40, 600, seed=1), torch.zeros(40, 700)
   gamma, beta, stats = 1 + 0.1 * rnd(256, seed=2), 0.1 * rnd(256, seed=3), torch.zeros(40, 2)

@@ -1,0 +1,103 @@
+"""End-to-end parity on the MI355X: one and two `Learner.train_step_device`
+calls through the HIP kernels (float32) against the float64 autograd oracle on
+the same minibatch, weights and noise.  Tolerance: losses / grad norms 1e-3
+relative (north_star), gradients 2e-3 of their max (fp32 vs fp64 through
+deep LayerNorm stacks)."""
+
+import numpy as np
+import pytest
+import torch
+
+from daydreamer_amd import learner as learner_mod
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+LOSS_KEYS = ('model_loss', 'image_loss_mean', 'vector_loss_mean', 'kl_loss_mean',
+             'reward_loss_mean', 'cont_loss_mean', 'extr_critic_loss', 'actor_loss',
+             'model_grad_norm', 'extr_critic_grad_norm', 'actor_grad_norm',
+             'actent_mean', 'extr_score_std', 'prior_ent_mean', 'post_ent_mean',
+             'extr_imag_reward_mean', 'extr_imag_return_mean')
+
+
+def run(hip, cfg, steps, gtol=2e-3, **kw):
+  from oracle import dreamer_ref
+  dreamer_ref.SAMPLE_TOL[0] = 1e-3  # fp32 device logits vs fp64 oracle logits
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, **kw)
+  L = learner_mod.Learner(sp, hip, 'cuda:0', B, T, params=params, noise_seed=3)
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64)
+  state = None
+  for i in range(steps):
+    L.upload(data)
+    L.train_step_device(use_carry=(i > 0))
+    torch.cuda.synchronize()
+    mets = L.read_metrics()
+    _, state, omets = ag.train(data, helpers.noise_from_learner(L), state,
+                               helpers.forced_from_learner(L))
+    for k in LOSS_KEYS:
+      if k in omets:
+        a, o = float(mets[k]), float(omets[k])
+        assert abs(a - o) <= 1e-3 * max(abs(o), 1e-2), f'step {i} {k}: {a} vs {o}'
+    grads = L.export_grads()
+    worst = max((helpers.rel_err(grads[n], g.numpy()), n)
+                for n, g in ag.last['grads'].items())
+    assert worst[0] < gtol, f'step {i} worst grad {worst}'
+    newp = L.export_params()
+    worstp = max((helpers.rel_err(newp[n], v), n) for n, v in ag.export_params().items())
+    # Adam's first steps are sign-like: a 1e-6 gradient difference can flip lr-sized updates
+    assert worstp[0] < 5e-3, f'step {i} worst param {worstp}'
+  return L
+
+
+def test_e2e_debug_vision(hip):
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=6,
+                            imag_horizon=4)
+  run(hip, cfg, 2, image=64, vector=5, action=3, terminals=0.1)
+
+
+def test_e2e_a1_proprio(hip):
+  """BASELINE configs[0]: a1 block, proprio only, batch 16 x seq 16, horizon 5."""
+  cfg = helpers.make_config(('a1',), batch_size=16, replay_chunk=16, imag_horizon=5)
+  run(hip, cfg, 1, image=0, vector=7, action=6, terminals=0.05)
+
+
+def test_e2e_vision_small_units(hip):
+  """a1_vision geometry (64x64 image, 32x32 latent, A=16) with a short batch."""
+  cfg = helpers.make_config(('a1_vision',), batch_size=4, replay_chunk=5, imag_horizon=3)
+  run(hip, cfg, 1, image=64, vector=16, action=16, terminals=0.0)
+
+
+def test_full_size_properties(hip):
+  """BASELINE configs[1] at full size (batch 50 x seq 50 x horizon 15): the oracle
+  is too slow here, so check size-independent properties instead: finite losses,
+  one-hot latents, weights in [0,1] and non-increasing, gradient-norm
+  consistency between the flat arena and the per-tensor views."""
+  cfg = helpers.make_config(('a1_vision',))
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(
+      cfg, image=64, vector=16, action=16, terminals=0.01, smooth=False)
+  L = learner_mod.Learner(sp, hip, 'cuda:0', B, T, params=params)
+  L.upload(data)
+  L.train_step_device(use_carry=False)
+  torch.cuda.synchronize()
+  mets = L.read_metrics()
+  for k, v in mets.items():
+    assert np.isfinite(v), k
+  b = L.b
+  st = b['post'][:, L.D:].view(L.N, L.G, L.C)
+  assert torch.equal(st.sum(-1), torch.ones_like(st.sum(-1)))
+  tr = b['traj'][:, :, L.D:L.F].reshape(L.H + 1, L.N, L.G, L.C)
+  assert torch.equal(tr.sum(-1), torch.ones_like(tr.sum(-1)))
+  w = b['i_weight'].view(L.H + 1, L.N)
+  assert float(w.min()) >= 0 and float(w.max()) <= 1.0
+  assert bool((w[1:] <= w[:-1] + 1e-6).all())
+  g = L.groups['model']
+  n1 = float(torch.sqrt((g.gflat.double() ** 2).sum()))
+  assert abs(n1 - float(mets['model_grad_norm'])) <= 1e-4 * n1
+  # lambda-return fixed point: with lambda = 0 ... covered in test_hip_ops; here check
+  # ret_H-1 = r + d * v_H exactly as the recurrence defines it
+  H, N = L.H, L.N
+  r = b['i_reward'].view(H, N)[H - 1]
+  v = b['i_value'].view(H + 1, N)[H]
+  d = b['i_cont'].view(H + 1, N)[H] * plain['discount']
+  ret = b['i_ret'].view(H, N)[H - 1]
+  assert torch.allclose(ret, r + d * v, rtol=1e-5, atol=1e-5)
