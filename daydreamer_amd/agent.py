@@ -1,0 +1,334 @@
+"""`Agent`: the reference's `embodied.Agent` surface (reference
+embodied/core/base.py:1-30, implemented there by tfagent.py:22-96 +
+agent.py:15-139) on top of the MI355X learner.
+
+  Agent(obs_space, act_space, step, config)
+  .configs                      named config blocks (agent.py:18-19)
+  .dataset(generator_fn)        batches of [B,T,...] numpy (agent.py:108-121)
+  .policy(obs, state, mode)     -> ({'action': np}, state)     (agent.py:42-65)
+  .train(data, state)           -> (outs, state, metrics)      (agent.py:67-93)
+  .report(data)                 -> metrics                     (agent.py:95-106)
+  .save() / .load(data)         picklable dict (tfutils.py:116-131)
+
+Data parallelism mirrors tfagent.py:99-116: `train` receives the GLOBAL batch
+and every rank (one process per GPU, torch.distributed over RCCL) takes rows
+[rank*B/P, (rank+1)*B/P); gradients and the batch statistics feeding the
+controllers are summed over ranks.
+"""
+
+import os
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from . import config as config_mod
+from . import learner as learner_mod
+from . import spec as spec_mod
+
+
+class DistComm:
+  """Sum / max all-reduce over the data-parallel group (RCCL on GPUs)."""
+
+  def __init__(self):
+    import torch.distributed as dist
+    self.dist = dist
+    self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+  def allreduce_sum(self, t):
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+  def allreduce_max(self, t):
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+
+
+class Batcher:
+  """`batch_size` replay generators zipped into [B,T,...] numpy batches with a
+  prefetch thread (role of embodied.Prefetch, reference core/prefetch.py)."""
+
+  def __init__(self, generator_fn, batch_size, prefetch=2):
+    self._gens = [generator_fn() for _ in range(batch_size)]
+    self._queue = queue.Queue(maxsize=prefetch)
+    self._error = None
+    self._thread = threading.Thread(target=self._work, daemon=True)
+    self._thread.start()
+
+  def _work(self):
+    try:
+      while True:
+        items = [next(g) for g in self._gens]
+        batch = {k: np.stack([it[k] for it in items], 0) for k in items[0]}
+        self._queue.put(batch)
+    except Exception as e:  # surfaced on the consumer side
+      self._error = e
+      self._queue.put(None)
+
+  def __iter__(self):
+    return self
+
+  def __next__(self):
+    batch = self._queue.get()
+    if batch is None:
+      raise self._error
+    return batch
+
+
+class TrainState:
+  """Opaque recurrent state handed back to the caller (the carried posterior
+  lives in the learner's HBM buffers)."""
+
+  def __init__(self, owner):
+    self.owner = owner
+
+
+class PolicyState:
+
+  def __init__(self, latent, action):
+    self.latent, self.action = latent, action
+
+
+class Agent:
+
+  configs = config_mod.load_configs()
+
+  def __init__(self, obs_space, act_space, step, config, _ops=None,
+               _device=None, _dtype=torch.float32):
+    self.config = config
+    self.cfg = config_mod.to_plain(config)
+    self.obs_space = {k: v for k, v in obs_space.items()
+                      if not k.startswith('log_')}
+    self.act_space = act_space['action']
+    if getattr(self.act_space, 'discrete', False):
+      raise NotImplementedError(
+          'discrete action spaces (REINFORCE actor) are not implemented yet')
+    self.step = step
+    self.act_dim = int(np.prod(self.act_space.shape))
+    shapes = {k: tuple(v.shape) for k, v in self.obs_space.items()}
+    self.spec = spec_mod.build_spec(self.cfg, shapes, self.act_dim)
+    self.rank, self.world, self.comm = 0, 1, None
+    try:
+      import torch.distributed as dist
+      if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        self.comm = DistComm()
+        self.rank, self.world = self.comm.rank, self.comm.world
+    except ImportError:
+      pass
+    if _ops is None:
+      # The product path: HIP kernels or nothing.
+      from . import hipops
+      local = int(os.environ.get('LOCAL_RANK', 0))
+      self.device = torch.device(_device or f'cuda:{local}')
+      torch.cuda.set_device(self.device)
+      self.ops = hipops.HipOps(self.device)
+    else:
+      self.ops = _ops
+      self.device = torch.device(_device or 'cpu')
+    self._dtype = _dtype
+    hip = self.cfg.get('hip', {})
+    self._use_graph = bool(hip.get('graph', True)) and self.device.type == 'cuda'
+    self._noise_seed = int(hip.get('noise_seed', 0))
+    self._seed = int(self.cfg.get('seed', 0))
+    # Parameter / optimizer arenas are owned by the agent and shared by every
+    # learner instance (train, policy, report), so rebuilding for a new batch
+    # shape never loses state.
+    init = spec_mod.init_params(self.spec, self._seed)
+    self.groups = {
+        name: learner_mod.ParamGroup(self.spec.group(name), self.device,
+                                     trainable=(name != 'critic_target'),
+                                     dtype=_dtype)
+        for name in ('model', 'actor', 'critic', 'critic_target')}
+    for g in self.groups.values():
+      g.load(init)
+    self.learner = None
+    self._plan = None
+    self._train_calls = 0
+    self._policies = {}
+    self._pending_load = None
+
+  # ------------------------------------------------------------------ helpers
+
+  def _build_learner(self, batch, length):
+    assert batch % self.world == 0, (batch, self.world)  # tfagent.py:113
+    self.learner = learner_mod.Learner(
+        self.spec, self.ops, self.device, batch // self.world, length,
+        rank=self.rank, world=self.world, comm=self.comm,
+        noise_seed=self._noise_seed, dtype=self._dtype, groups=self.groups)
+    if self._pending_load is not None:
+      self._apply_load(self._pending_load)
+      self._pending_load = None
+
+  def _ensure_params(self):
+    """Parameters exist before the first train call (policy / save)."""
+    if self.learner is None:
+      self._build_learner(self.world * 1, 1)
+      self._bootstrap = True
+
+  def _shard(self, data):
+    if self.world == 1:
+      return data
+    B = len(data['is_first'])
+    per = B // self.world
+    lo = self.rank * per
+    return {k: v[lo:lo + per] for k, v in data.items()}
+
+  # ---------------------------------------------------------------------- API
+
+  def dataset(self, generator_fn):
+    return Batcher(generator_fn, self.cfg['batch_size'])
+
+  def train(self, data, state=None):
+    data = {k: np.asarray(v) for k, v in data.items()
+            if not k.startswith('log_')}
+    B, T = data['is_first'].shape[:2]
+    L = self.learner
+    if L is None or getattr(self, '_bootstrap', False) or (L.Bg, L.T) != (B, T):
+      saved = None
+      if L is not None and not getattr(self, '_bootstrap', False):
+        saved = self.save()  # controller state lives in the learner
+      self._bootstrap = False
+      self.learner = None
+      self._build_learner(B, T)
+      if saved is not None:
+        self._apply_load(saved)
+      L = self.learner
+      self._plan, self._train_calls = None, 0
+    L.upload(self._shard(data))
+    carry = isinstance(state, TrainState) and state.owner is L
+    if not carry:
+      L.reset_carry()
+    if self._use_graph and self._train_calls >= 1:
+      if self._plan is None:
+        self._plan = L.capture()
+      self._plan.replay()
+    else:
+      L.train_step_device(True)
+    self._train_calls += 1
+    metrics = L.read_metrics()
+    outs = {}
+    if 'key' in data:  # prioritized replay, agent.py:89-93
+      name = self.cfg['priority']
+      src = {'reward_loss': L.b['loss_reward'], 'cont_loss': L.b['loss_cont'],
+             'kl_loss': L.b['kl']}.get(name)
+      if src is None:
+        raise NotImplementedError(f'priority: {name}')
+      outs = {'key': data['key'],
+              'priority': src.view(L.B, L.T).cpu().numpy().copy()}
+    return outs, TrainState(L), metrics
+
+  train_step = train  # BASELINE.json names the learner step `train_step`
+
+  def policy(self, obs, state=None, mode='train'):
+    obs = {k: np.asarray(v) for k, v in obs.items() if not k.startswith('log_')}
+    n = len(obs['is_first'])
+    self._ensure_params()
+    P = self._policies.get(n)
+    if P is None:
+      P = learner_mod.Learner(
+          self.spec, self.ops, self.device, n, 1, groups=self.groups,
+          noise_seed=self._noise_seed + 1, dtype=self._dtype)
+      self._policies[n] = P
+    b = P.b
+    data = dict(obs)
+    data['is_terminal'] = obs.get('is_terminal', np.zeros(n, bool))
+    data['reward'] = obs.get('reward', np.zeros(n, np.float32))
+    if isinstance(state, PolicyState):
+      b['carry'].copy_(state.latent)
+      data['action'] = state.action
+    else:
+      P.reset_carry()
+      data['action'] = np.zeros((n, self.act_dim), np.float32)
+    P.upload({k: (v[:, None] if isinstance(v, np.ndarray) else v)
+              for k, v in data.items()})
+    if isinstance(state, PolicyState):
+      b['action'].copy_(state.action_dev)
+    noise = self.cfg['eval_noise'] if mode == 'eval' else self.cfg['expl_noise']
+    if noise:
+      raise NotImplementedError('expl_noise / eval_noise != 0')
+    act = P.policy_device(sample=(mode != 'eval'))
+    st = PolicyState(b['carry'].clone(), None)
+    st.action_dev = act.clone()
+    action = act.cpu().numpy().copy().reshape((n,) + tuple(self.act_space.shape))
+    st.action = action
+    return {'action': action}, st
+
+  def report(self, data):
+    """World-model loss metrics on a batch without updating anything
+    (WorldModel.report -> loss(data), reference agent.py:266-268).  The
+    open-loop video grids of the reference are not produced yet."""
+    data = {k: np.asarray(v) for k, v in data.items()
+            if not k.startswith('log_')}
+    B, T = data['is_first'].shape[:2]
+    key = ('report', B, T)
+    R = self._policies.get(key)
+    self._ensure_params()
+    if R is None:
+      R = learner_mod.Learner(
+          self.spec, self.ops, self.device, B, T, groups=self.groups,
+          noise_seed=self._noise_seed + 2, dtype=self._dtype)
+      self._policies[key] = R
+    R.wmkl_scale.copy_(self.learner.wmkl_scale)
+    R.upload(data)
+    R.reset_carry()
+    R.phase_prep()
+    R.phase_wm_fwd(True, training=False)
+    sums = R.stat_sums.cpu().numpy()
+    out = {}
+    n = R.N
+    for i, name in enumerate(R.stat_names):
+      out[f'{name}_mean'] = np.float32(sums[i, 0] / n)
+    return out
+
+  # ------------------------------------------------------------- checkpointing
+
+  def save(self):
+    self._ensure_params()
+    L = self.learner
+    out = {f'params/{k}': v for k, v in L.export_params().items()}
+    for gname in ('model', 'actor', 'critic'):
+      g = L.groups[gname]
+      off = 0
+      for p in g.specs:
+        out[f'opt/{gname}/m/{p.name}'] = g.m[off:off + p.size].cpu().numpy().copy().reshape(p.shape)
+        out[f'opt/{gname}/v/{p.name}'] = g.v[off:off + p.size].cpu().numpy().copy().reshape(p.shape)
+        off += p.size
+      out[f'opt/{gname}/step'] = np.asarray(g.opt_state.cpu().numpy()[0], np.int64)
+    out['state/wmkl_scale'] = L.wmkl_scale.cpu().numpy().copy()
+    out['state/actent_scale'] = L.actent_scale.cpu().numpy().copy()
+    for k, v in L.norm_state.items():
+      out[f'state/norm/{k}'] = v.cpu().numpy().copy()
+    out['state/slow_updates'] = np.asarray(L.slow_updates, np.int64)
+    out['state/noise_step'] = L.step_ctr.cpu().numpy().copy()
+    return out
+
+  def load(self, data):
+    if self.learner is None:
+      self._pending_load = dict(data)
+      self._ensure_params()
+    else:
+      self._apply_load(data)
+
+  def _apply_load(self, data):
+    L = self.learner
+    params = {k[len('params/'):]: v for k, v in data.items()
+              if k.startswith('params/')}
+    for g in L.groups.values():
+      g.load(params)
+    for gname in ('model', 'actor', 'critic'):
+      g = L.groups[gname]
+      off = 0
+      for p in g.specs:
+        for slot, buf in (('m', g.m), ('v', g.v)):
+          arr = data.get(f'opt/{gname}/{slot}/{p.name}')
+          if arr is not None:
+            buf[off:off + p.size].copy_(torch.as_tensor(np.asarray(arr)).reshape(-1))
+        off += p.size
+      if f'opt/{gname}/step' in data:
+        g.opt_state[0] = float(data[f'opt/{gname}/step'])
+    if 'state/wmkl_scale' in data:
+      L.wmkl_scale.copy_(torch.as_tensor(data['state/wmkl_scale']))
+      L.actent_scale.copy_(torch.as_tensor(data['state/actent_scale']))
+      for k in L.norm_state:
+        L.norm_state[k].copy_(torch.as_tensor(data[f'state/norm/{k}']))
+      L.slow_updates = int(data['state/slow_updates'])
+      L.step_ctr.copy_(torch.as_tensor(data['state/noise_step']))

@@ -1,0 +1,77 @@
+"""HIP-graph execution plan for the learner step.
+
+The train step is thousands of small dependent kernel launches (a T-step and an
+H-step scan); replaying them from captured HIP graphs removes the host launch
+cost.  The step is cut into graph segments at the few points that need host
+or collective work (data-parallel all-reduces, the slow-critic copy whose
+schedule is a host counter); `cut(fn)` marks such a point.  PyTorch is used only
+for its stream / graph handles.
+"""
+
+import torch
+
+
+class EagerPlan:
+  """No capture: run everything as issued (used on CPU tests and as warm-up)."""
+
+  capturing = False
+
+  def cut(self, fn):
+    fn()
+
+
+class GraphPlan:
+
+  def __init__(self, device):
+    self.device = torch.device(device)
+    self.items = []
+    self.cur = None
+    self.capturing = False
+    self.stream = torch.cuda.Stream(self.device)
+
+  def _begin(self):
+    self.cur = torch.cuda.CUDAGraph()
+    self.cur.capture_begin()
+
+  def _end(self):
+    self.cur.capture_end()
+    self.items.append(('graph', self.cur))
+    self.cur = None
+
+  def capture(self, fn):
+    """Record fn() (which issues kernels on the current stream and calls
+    cut(...) at host/collective points) without executing it."""
+    torch.cuda.synchronize(self.device)
+    self.stream.wait_stream(torch.cuda.current_stream(self.device))
+    with torch.cuda.stream(self.stream):
+      self.capturing = True
+      self._begin()
+      try:
+        fn()
+      finally:
+        self._end()
+        self.capturing = False
+    torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+  def cut(self, fn):
+    if not self.capturing:
+      fn()
+      return
+    self._end()
+    self.items.append(('eager', fn))
+    self._begin()
+
+  def replay(self):
+    cur = torch.cuda.current_stream(self.device)
+    self.stream.wait_stream(cur)
+    with torch.cuda.stream(self.stream):
+      for kind, item in self.items:
+        if kind == 'graph':
+          item.replay()
+        else:
+          item()
+    cur.wait_stream(self.stream)
+
+  @property
+  def n_graphs(self):
+    return sum(1 for k, _ in self.items if k == 'graph')

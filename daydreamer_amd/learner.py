@@ -32,6 +32,7 @@ import math
 import numpy as np
 import torch
 
+from . import graphs
 from . import spec as specs
 
 F32 = torch.float32
@@ -104,7 +105,8 @@ class Act:
 class Learner:
 
   def __init__(self, spec, ops, device, batch, length, params=None, seed=0,
-               rank=0, world=1, comm=None, noise_seed=0, dtype=F32):
+               rank=0, world=1, comm=None, noise_seed=0, dtype=F32,
+               groups=None):
     self.spec, self.ops, self.device = spec, ops, torch.device(device)
     self.dtype = dtype  # float32 in the product; tests may use float64
     self.cfg = cfg = spec.cfg
@@ -129,15 +131,18 @@ class Learner:
     for k in ('model_opt', 'actor_opt', 'critic_opt'):
       assert cfg[k]['opt'] == 'adam' and not cfg[k]['warmup']
     # ---- parameters
-    self.groups = {
-        'model': ParamGroup(s.group('model'), self.device, dtype=dtype),
-        'actor': ParamGroup(s.group('actor'), self.device, dtype=dtype),
-        'critic': ParamGroup(s.group('critic'), self.device, dtype=dtype),
-        'critic_target': ParamGroup(s.group('critic_target'), self.device,
-                                    trainable=False, dtype=dtype)}
-    init = params if params is not None else specs.init_params(s, seed)
-    for g in self.groups.values():
-      g.load(init)
+    if groups is not None:
+      self.groups = groups  # shared with another Learner (policy runner)
+    else:
+      self.groups = {
+          'model': ParamGroup(s.group('model'), self.device, dtype=dtype),
+          'actor': ParamGroup(s.group('actor'), self.device, dtype=dtype),
+          'critic': ParamGroup(s.group('critic'), self.device, dtype=dtype),
+          'critic_target': ParamGroup(s.group('critic_target'), self.device,
+                                      trainable=False, dtype=dtype)}
+      init = params if params is not None else specs.init_params(s, seed)
+      for g in self.groups.values():
+        g.load(init)
     # ---- device scalars
     self.step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
     self.wmkl_scale = torch.ones(1, dtype=dtype, device=self.device)
@@ -153,6 +158,7 @@ class Learner:
     self.stat_maxs = torch.zeros(64, 3, dtype=dtype, device=self.device)
     self.actent_sums = torch.zeros(2 * self.A, dtype=torch.float64, device=self.device)
     self.zero_rows = None
+    self.plan = graphs.EagerPlan()
     self._build_layers()
     self._build_buffers()
 
@@ -342,8 +348,9 @@ class Learner:
     return k
 
   def allreduce(self, t):
+    """Sum over data-parallel ranks (RCCL); a graph cut point."""
     if self.comm is not None and self.world > 1:
-      self.comm.allreduce_sum(t)
+      self.plan.cut(lambda: self.comm.allreduce_sum(t))
 
   def lin_fwd(self, P, A, x, sel=None):
     sel = sel or (lambda t: t)
@@ -733,7 +740,7 @@ class Learner:
       ops.philox(b['u_img'], H, N, G, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_IMG, 0)
     ops.philox(b['eps'], H + 1, N, A, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_ACT, 1)
 
-  def phase_wm_fwd(self, use_carry):
+  def phase_wm_fwd(self, use_carry=True, training=True):
     ops, b, cfg = self.ops, self.b, self.cfg
     N = self.N
     self.encoder_fwd()
@@ -756,7 +763,7 @@ class Learner:
     # AutoAdapt is updated before it is used (reference tfutils.py:441-442)
     self.allreduce(self.stat_sums[k])
     c = cfg['wmkl']
-    if c['impl'] == 'mult':
+    if c['impl'] == 'mult' and training:
       ops.autoadapt_update(self.wmkl_scale, self.stat_sums[k], float(self.Ng),
                            c['target'], 0.1, c['vel'], c['min'], c['max'], False)
     self.stat('post_ent', b['ent_post'])
@@ -940,6 +947,35 @@ class Learner:
     self.stat('actor_loss_ent', b['i_ent_row'][:HN])
     self.opt_step('actor', 'actor_opt')
 
+  # ------------------------------------------------------------------ policy
+
+  def policy_device(self, sample):
+    """Agent.policy (reference agent.py:42-65) on a [n, 1] batch held by this
+    learner: encoder, one obs_step from the carried latent, actor, then sample
+    (train / explore) or mode (eval).  The new latent replaces the carry; the
+    action is returned as a device view [n, A]."""
+    ops, b, cfg = self.ops, self.b, self.cfg
+    B, G, A, F, S = self.B, self.G, self.A, self.F, self.S
+    assert self.T == 1
+    ops.counter_add(self.step_ctr, 1)
+    ops.batch_prep(b['is_first'], b['is_terminal'], b['action'], b['first'],
+                   b['cont'], b['xin'][:, S:])
+    ops.philox(b['u_prior'], 1, B, G, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY, 0)
+    ops.philox(b['u_post'], 1, B, G, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 1, 0)
+    ops.philox(b['eps'][0], 1, B, A, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 2, 1)
+    self.encoder_fwd()
+    self.initial_fwd()
+    self.observe_fwd(True)
+    t0 = b['traj'][0]
+    ops.copy2d(b['post'], t0[:, :F])
+    sel = lambda buf: buf.view(self.H + 1, self.N, -1)[0]
+    om, os_ = self.head_fwd('actor', self.acts_im['actor'], t0[:, :F], sel)
+    ca = cfg['actor']
+    ops.normal_head_fwd(om, os_, b['eps'][0] if sample else None, t0[:, F:],
+                        ca['minstd'], ca['maxstd'])
+    ops.copy2d(b['post'], b['carry'])
+    return t0[:, F:]
+
   # --------------------------------------------------------------- train step
 
   def train_step_device(self, use_carry=True):
@@ -951,8 +987,16 @@ class Learner:
     self.phase_wm_fwd(use_carry)
     self.phase_wm_bwd()
     self.phase_imagine()
-    self.update_slow()
+    self.plan.cut(self.update_slow)
     self.phase_actor()
+
+  def capture(self):
+    """Capture the whole step into HIP graphs (after at least one eager step,
+    so lazily registered statistics slots exist)."""
+    plan = graphs.GraphPlan(self.device)
+    self.plan = plan
+    plan.capture(lambda: self.train_step_device(True))
+    return plan
 
   def read_metrics(self):
     """One device->host transfer of the statistics slabs -> metrics dict with
