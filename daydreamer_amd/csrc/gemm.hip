@@ -363,17 +363,20 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
             float alpha, float beta, float* ws, size_t ws_bytes, hipStream_t st,
             const char* name) {
   if (M <= 0 || N <= 0) return 0;
-  const bool big = (M > 64 && N > 64);
-  const int T = big ? 128 : 64;
-  const int tm = dd_ceil_div(M, T), tn = dd_ceil_div(N, T);
+  // tiles: 128x128 for large problems, 128x64 for narrow outputs, 64x64 for few rows
+  const int TMS = (M > 64) ? 128 : 64;
+  const int TNS = (M > 64 && N > 64) ? 128 : 64;
+  const int tm = dd_ceil_div(M, TMS), tn = dd_ceil_div(N, TNS);
   const long MN = (long)M * N;
   int S = pick_split((long)tm * tn, K, MN, ws ? ws_bytes : 0);
   int kps = ((dd_ceil_div(K > 0 ? K : 1, S) + BK - 1) / BK) * BK;
   S = K > 0 ? dd_ceil_div(K, kps) : 1;
   EpiMat ep{C, ldc, bias, alpha, beta, M, N, S > 1 ? ws : nullptr};
   dim3 grid(tm * tn, 1, S);
-  if (big)
+  if (TMS == 128 && TNS == 128)
     k_mfma_gemm<128, 128, AKC, BKC, AL, BL, EpiMat><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  else if (TMS == 128)
+    k_mfma_gemm<128, 64, AKC, BKC, AL, BL, EpiMat><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   else
     k_mfma_gemm<64, 64, AKC, BKC, AL, BL, EpiMat><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   DD_CHECK_LAUNCH(name);
@@ -423,34 +426,80 @@ extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w,
   return run_mat<true, false>(al, bl, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
 }
 
+// col2im for the GEMM + col2im form of the transposed conv (few output channels):
+// big[n,by,bx,cb] = bias[cb] + sum_{ky,kx : (by-ky),(bx-kx) even, in range} cols[(n,sy,sx),(ky,kx,cb)]
+__global__ void k_col2im_s2(const float* __restrict__ cols, const float* __restrict__ bias,
+                            float* __restrict__ big, long n_img, int hs, int ws_, int hb, int wb,
+                            int Cb, int k) {
+  const long total = n_img * hb * wb * Cb;
+  const int kkc = k * k * Cb;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (long)gridDim.x * blockDim.x) {
+    int cb = (int)(id % Cb); long r = id / Cb;
+    int bx = (int)(r % wb); r /= wb;
+    int by = (int)(r % hb); long n = r / hb;
+    float acc = bias ? bias[cb] : 0.f;
+    for (int ky = by & 1; ky < k; ky += 2) {
+      int sy = (by - ky) >> 1;
+      if (by < ky || sy >= hs) continue;
+      for (int kx = bx & 1; kx < k; kx += 2) {
+        int sx = (bx - kx) >> 1;
+        if (bx < kx || sx >= ws_) continue;
+        acc += cols[((n * hs + sy) * ws_ + sx) * kkc + (ky * k + kx) * Cb + cb];
+      }
+    }
+    big[id] = acc;
+  }
+}
+
 extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* bias, float* big,
                                int n_img, int hs, int ws_, int Cs, int hb, int wb, int Cb, int k,
-                               void* stream) {
+                               float* wsp, size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_up: geometry");
+  const int kkc = k * k * Cb;
+  const size_t per_img = (size_t)hs * ws_ * kkc * sizeof(float);
+  if (Cb <= 8 && wsp && ws_bytes >= 2 * per_img) {
+    // Few output channels (the image layer): an MFMA tile would be >90% padding
+    // in N.  cols = small[npix,Cs] @ W^T[Cs, k*k*Cb] (dense GEMM), then a gather.
+    const int chunk = (int)((ws_bytes / 2) / per_img);  // second half: split-K scratch
+    float* cols = wsp;
+    float* ws2 = wsp + (ws_bytes / 2) / sizeof(float);
+    for (int n0 = 0; n0 < n_img; n0 += chunk) {
+      const int nn = (n_img - n0 < chunk) ? (n_img - n0) : chunk;
+      const int M = nn * hs * ws_;
+      const float* a = small + (size_t)n0 * hs * ws_ * Cs;
+      int rc = run_mat<true, true>(MatKC{a, Cs, M, aligned16(a) && (Cs % 4 == 0)},
+                                   MatKC{w, Cs, kkc, aligned16(w) && (Cs % 4 == 0)}, M, kkc, Cs,
+                                   cols, kkc, nullptr, 1.f, 0.f, ws2, ws_bytes / 2, st,
+                                   "dd_conv2d_s2_up(cols)");
+      if (rc) return rc;
+      const long total = (long)nn * hb * wb * Cb;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 8192) blocks = 8192;
+      k_col2im_s2<<<blocks, 256, 0, st>>>(cols, bias, big + (size_t)n0 * hb * wb * Cb, nn, hs, ws_, hb, wb, Cb, k);
+      DD_CHECK_LAUNCH("dd_conv2d_s2_up(col2im)");
+    }
+    return 0;
+  }
   int vec = aligned16(small) && aligned16(w) && (Cs % 4 == 0);
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       const int nj = (hb - py + 1) / 2, ni = (wb - px + 1) / 2;  // pixels of this parity
       const int nky = (k - py + 1) / 2, nkx = (k - px + 1) / 2;  // taps of this parity
       if (nj <= 0 || ni <= 0) continue;
-      const int M = n_img * nj * ni, N = Cb, K = nky * nkx * Cs;
+      const int M = n_img * nj * ni, N = Cb;
+      const int K = (nky > 0 && nkx > 0) ? nky * nkx * Cs : 0;  // K = 0: bias only
       EpiConvUp ep{big, bias, M, nj, ni, hb, wb, Cb, py, px};
-      if (nky <= 0 || nkx <= 0) {
-        // No filter tap reaches this parity (k == 1): bias only.
-        ConvUpA al{small, M, nj, ni, hs, ws_, Cs, 1, vec};
-        ConvUpB bl{w, Cb, Cs, k, 1, py, px, vec};
-        dim3 grid(dd_ceil_div(M, 64) * dd_ceil_div(N, 64), 1, 1);
-        k_mfma_gemm<64, 64, true, true, ConvUpA, ConvUpB, EpiConvUp><<<grid, 256, 0, st>>>(al, bl, ep, 0, BK, dd_ceil_div(M, 64));
-        DD_CHECK_LAUNCH("dd_conv2d_s2_up");
-        continue;
-      }
-      ConvUpA al{small, M, nj, ni, hs, ws_, Cs, nkx, vec};
-      ConvUpB bl{w, Cb, Cs, k, nkx, py, px, vec};
-      const int kps = ((K + BK - 1) / BK) * BK;
+      ConvUpA al{small, M, nj, ni, hs, ws_, Cs, nkx > 0 ? nkx : 1, vec};
+      ConvUpB bl{w, Cb, Cs, k, nkx > 0 ? nkx : 1, py, px, vec};
+      const int kps = ((K + BK - 1) / BK) * BK + BK;
       if (M > 64 && N > 64) {
         int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 128);
         k_mfma_gemm<128, 128, true, true, ConvUpA, ConvUpB, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+      } else if (M > 64) {
+        int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 64);
+        k_mfma_gemm<128, 64, true, true, ConvUpA, ConvUpB, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
       } else {
         int tm = dd_ceil_div(M, 64), tn = dd_ceil_div(N, 64);
         k_mfma_gemm<64, 64, true, true, ConvUpA, ConvUpB, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);

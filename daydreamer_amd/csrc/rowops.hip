@@ -181,13 +181,22 @@ k_ln_param_grad(const float* __restrict__ dout, long ldd, const float* __restric
 }
 
 // out[w] = beta*out[w] + sum_p partials[p*stride + w]
-__global__ void k_col_reduce(const float* __restrict__ partials, int P, long stride, int W,
-                             float* __restrict__ out, float beta) {
-  int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= W) return;
+// block = 64 columns x 4 partial lanes (coalesced 256-B rows, 4-way split of P).
+__global__ void __launch_bounds__(256)
+k_col_reduce(const float* __restrict__ partials, int P, long stride, int W,
+             float* __restrict__ out, float beta) {
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int w = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int p = 0; p < P; ++p) s += partials[(long)p * stride + w];
-  out[w] = (beta != 0.f ? beta * out[w] : 0.f) + s;
+  if (w < W)
+    for (int p = pl; p < P; p += 4) s += partials[(long)p * stride + w];
+  __shared__ float sh[4][64];
+  sh[pl][cl] = s;
+  __syncthreads();
+  if (pl == 0 && w < W) {
+    float t = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+    out[w] = (beta != 0.f ? beta * out[w] : 0.f) + t;
+  }
 }
 
 // column sums: partials[grid.y][C]
@@ -330,7 +339,7 @@ extern "C" int dd_ln_bwd_parts(int rows, int C) {
     long chunks = (rows + 63) / 64;
     return (int)(chunks > 256 ? 256 : (chunks < 1 ? 1 : chunks));
   }
-  return row_blocks(rows, 512);
+  return row_blocks(rows, 256);
 }
 
 extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
@@ -357,7 +366,7 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
     DD_CHECK_LAUNCH("dd_ln_act_bwd(param grad)");
   }
   // partials are [parts][2][C]: gamma rows at stride 2C from ws, beta rows from ws + C.
-  const int nb = (C + 255) / 256;
+  const int nb = (C + 63) / 64;
   const float b = accumulate ? 1.f : 0.f;
   k_col_reduce<<<nb, 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, b);
   DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce gamma)");
@@ -380,7 +389,7 @@ extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, lon
   dim3 grid((C + 63) / 64, parts);
   k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, lds, ws, rows, C, act);
   DD_CHECK_LAUNCH("dd_ln_param_grad");
-  const int nb = (C + 255) / 256;
+  const int nb = (C + 63) / 64;
   const float b = accumulate ? 1.f : 0.f;
   k_col_reduce<<<nb, 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, b);
   DD_CHECK_LAUNCH("dd_ln_param_grad(reduce gamma)");
@@ -422,7 +431,7 @@ extern "C" int dd_col_sum(const float* x, long ldx, float* out, float beta, long
   dim3 grid((C + 63) / 64, parts);
   k_col_sum<<<grid, 256, 0, st>>>(x, ldx, ws, rows, C);
   DD_CHECK_LAUNCH("dd_col_sum");
-  k_col_reduce<<<(C + 255) / 256, 256, 0, st>>>(ws, parts, (long)C, C, out, beta);
+  k_col_reduce<<<(C + 63) / 64, 256, 0, st>>>(ws, parts, (long)C, C, out, beta);
   DD_CHECK_LAUNCH("dd_col_sum(reduce)");
   return 0;
 }

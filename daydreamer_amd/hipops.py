@@ -29,7 +29,7 @@ c_ull = ctypes.c_ulonglong
 _SIGS = {
     'dd_gemm_f32': [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p, c_p, c_z, c_p],
     'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
-    'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
     'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
@@ -115,13 +115,27 @@ class HipOps:
 
   name = 'hip'
 
-  def __init__(self, device='cuda:0', ws_bytes=512 << 20):
+  def __init__(self, device='cuda:0', ws_bytes=2048 << 20):
     if not torch.cuda.is_available():
       raise RuntimeError('HipOps needs a visible MI355X (no CPU fallback).')
     self.lib = load_library()
     self.device = torch.device(device)
     self.ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=self.device)
     self.ws_bytes = ws_bytes
+    self.trace = None  # list of (label, flops, start_event, end_event) when profiling
+
+  def _traced(self, label, flops, fn):
+    """Bracket one contraction launch with HIP events on the launch stream
+    (bench.py's live roofline measurement)."""
+    if self.trace is None:
+      return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(self.device))
+    rc = fn()
+    e1.record(torch.cuda.current_stream(self.device))
+    self.trace.append((label, flops, e0, e1))
+    return rc
 
   @property
   def stream(self):
@@ -142,38 +156,42 @@ class HipOps:
     a, lda = _mat(A)
     b, ldb = _mat(B)
     c, ldc = _mat(C)
-    self._check(self.lib.dd_gemm_f32(
+    self._check(self._traced('gemm', 2.0 * M * N * K, lambda: self.lib.dd_gemm_f32(
         a, b, c, M, N, K, lda, ldb, ldc, int(ta), int(tb), alpha, beta,
-        _ptr(bias), self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_gemm_f32')
+        _ptr(bias), self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_gemm_f32')
 
   def conv_down(self, big, w, bias, small, k, in_scale=1.0):
     n, hb, wb, cb = big.shape
     n2, hs, ws, cs = small.shape
     assert n == n2 and big.is_contiguous() and small.is_contiguous()
     assert tuple(w.shape) == (k, k, cb, cs) and w.is_contiguous()
-    self._check(self.lib.dd_conv2d_s2_down(
+    fl = 2.0 * n * hs * ws * k * k * cb * cs
+    self._check(self._traced('conv_down', fl, lambda: self.lib.dd_conv2d_s2_down(
         big.data_ptr(), int(big.dtype == torch.uint8), w.data_ptr(), _ptr(bias),
         small.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale,
-        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_conv2d_s2_down')
+        self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_s2_down')
 
   def conv_up(self, small, w, bias, big, k):
     n, hs, ws, cs = small.shape
     n2, hb, wb, cb = big.shape
     assert n == n2 and big.is_contiguous() and small.is_contiguous()
     assert tuple(w.shape) == (k, k, cb, cs) and w.is_contiguous()
-    self._check(self.lib.dd_conv2d_s2_up(
+    fl = 2.0 * n * hs * ws * k * k * cb * cs
+    self._check(self._traced('conv_up', fl, lambda: self.lib.dd_conv2d_s2_up(
         small.data_ptr(), w.data_ptr(), _ptr(bias), big.data_ptr(),
-        n, hs, ws, cs, hb, wb, cb, k, self.stream), 'dd_conv2d_s2_up')
+        n, hs, ws, cs, hb, wb, cb, k, self.ws.data_ptr(), self.ws_bytes,
+        self.stream)), 'dd_conv2d_s2_up')
 
   def conv_wgrad(self, big, small, dw, k, in_scale=1.0, beta=0.0):
     n, hb, wb, cb = big.shape
     n2, hs, ws, cs = small.shape
     assert n == n2 and big.is_contiguous() and small.is_contiguous()
     assert tuple(dw.shape) == (k, k, cb, cs) and dw.is_contiguous()
-    self._check(self.lib.dd_conv2d_s2_wgrad(
+    fl = 2.0 * n * hs * ws * k * k * cb * cs
+    self._check(self._traced('conv_wgrad', fl, lambda: self.lib.dd_conv2d_s2_wgrad(
         big.data_ptr(), int(big.dtype == torch.uint8), small.data_ptr(),
         dw.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale, beta,
-        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_conv2d_s2_wgrad')
+        self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_s2_wgrad')
 
   # ---- LayerNorm / GRU -------------------------------------------------------
 

@@ -55,7 +55,7 @@ int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const floa
                       float* ws, size_t ws_bytes, void* stream);
 int dd_conv2d_s2_up(const float* small, const float* w, const float* bias, float* big,
                     int n_img, int hs, int ws_, int Cs, int hb, int wb, int Cb, int k,
-                    void* stream);
+                    float* ws, size_t ws_bytes, void* stream);
 int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float* dw,
                        int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
                        float in_scale, float beta, float* ws, size_t ws_bytes, void* stream);
