@@ -162,7 +162,7 @@ def main():
     tot_t = sum(e0.elapsed_time(e1) for _, _, e0, e1 in trace) * 1e-3
     by = {}
     for lab, f, e0, e1 in trace:
-      d = by.setdefault(lab, [0, 0.0, 0.0])
+      d = by.setdefault(lab.split(' ')[0], [0, 0.0, 0.0])
       d[0] += 1
       d[1] += f
       d[2] += e0.elapsed_time(e1) * 1e-3

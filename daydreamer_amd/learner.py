@@ -154,6 +154,7 @@ class Learner:
     self.sc = torch.zeros(3, dtype=dtype, device=self.device)
     self.slow_updates = -1
     self.stat_names = []
+    self.stat_prereduced = set()  # slots already summed over ranks in-step
     self.stat_sums = torch.zeros(64, 3, dtype=torch.float64, device=self.device)
     self.stat_maxs = torch.zeros(64, 3, dtype=dtype, device=self.device)
     self.actent_sums = torch.zeros(2 * self.A, dtype=torch.float64, device=self.device)
@@ -762,6 +763,7 @@ class Learner:
     k = self.stat('kl_loss', b['kl'])
     # AutoAdapt is updated before it is used (reference tfutils.py:441-442)
     self.allreduce(self.stat_sums[k])
+    self.stat_prereduced.add(k)
     c = cfg['wmkl']
     if c['impl'] == 'mult' and training:
       ops.autoadapt_update(self.wmkl_scale, self.stat_sums[k], float(self.Ng),
@@ -882,6 +884,7 @@ class Learner:
     kd = self.stat('diff', b['i_diff'][:HN])
     self.allreduce(self.stat_sums[kr])
     self.allreduce(self.stat_sums[kd])
+    self.stat_prereduced.update((kr, kd))
     cnt = float(H * self.Ng)
     impl = {'off': 0, 'mean_std': 1, 'std': 2}
     c = cfg['retnorm']
@@ -1008,6 +1011,8 @@ class Learner:
     if self.comm is not None and self.world > 1:
       self.comm.allreduce_sum(sums)
       self.comm.allreduce_max(maxs)
+      for k in self.stat_prereduced:  # identical on every rank already
+        sums[k] /= self.world
     sums, maxs = sums.cpu().numpy(), maxs.cpu().numpy()
     N, H, w = self.N, self.H, self.world
     counts = dict(imag_value=(H + 1) * N * w)

@@ -1,0 +1,38 @@
+"""Worker for the 2-process data-parallel test (gloo on CPU)."""
+
+import os
+import sys
+import pathlib
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+
+
+def run(rank, world, port, outdir, steps):
+  import numpy as np
+  import torch
+  import torch.distributed as dist
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.set_num_threads(2)
+  import helpers
+  from daydreamer_amd import agent as agent_mod, learner as LM
+  from oracle import ref_ops
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=4, imag_horizon=3)
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(
+      cfg, image=64, vector=5, action=3, terminals=0.15)
+  per = B // world
+  shard = {k: v[rank * per:(rank + 1) * per] for k, v in data.items()}
+  L = LM.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', per, T, params=params, rank=rank,
+                 world=world, comm=agent_mod.DistComm(), noise_seed=5, dtype=torch.float64)
+  for i in range(steps):
+    L.upload(shard)
+    L.train_step_device(use_carry=(i > 0))
+    mets = L.read_metrics()
+  if rank == 0:
+    np.savez(os.path.join(outdir, 'dp.npz'), **L.export_params(),
+             **{f'metric/{k}': v for k, v in mets.items()})
+  dist.barrier()
+  dist.destroy_process_group()

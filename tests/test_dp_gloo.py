@@ -1,0 +1,45 @@
+"""Data parallelism: 2 ranks (one process each, gloo on CPU), each on its shard
+of the global batch with summed gradients / batch statistics, must reproduce the
+single-process run on the whole batch (the learner's noise is keyed by global
+row, so even the sampled latents are identical)."""
+
+import socket
+import tempfile
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+import helpers
+import dp_worker
+from daydreamer_amd import learner as LM
+
+
+def free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def test_two_ranks_equal_one():
+  from oracle import ref_ops
+  steps = 2
+  with tempfile.TemporaryDirectory() as d:
+    mp.spawn(dp_worker.run, args=(2, free_port(), d, steps), nprocs=2, join=True)
+    got = dict(np.load(f'{d}/dp.npz'))
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=4, imag_horizon=3)
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(
+      cfg, image=64, vector=5, action=3, terminals=0.15)
+  L = LM.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params, noise_seed=5,
+                 dtype=torch.float64)
+  for i in range(steps):
+    L.upload(data)
+    L.train_step_device(use_carry=(i > 0))
+    mets = L.read_metrics()
+  for name, v in L.export_params().items():
+    assert helpers.rel_err(got[name], v) < 1e-9, name
+  for k in ('model_loss', 'actor_loss', 'extr_critic_loss', 'model_grad_norm',
+            'actent_scale_mean', 'wmkl_scale_mean', 'extr_score_std'):
+    assert abs(float(got[f'metric/{k}']) - float(mets[k])) <= 1e-6 * max(1, abs(float(mets[k]))), k

@@ -1,0 +1,80 @@
+"""Golden vectors (tests/golden/debug_step.npz, made by make_golden.py from the
+float64 oracle): the oracle must reproduce them, the learner's host logic must
+match them on CPU, and the HIP path must match them on the GPU."""
+
+import importlib.util
+import pathlib
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from daydreamer_amd import learner as LM
+
+HERE = pathlib.Path(__file__).parent
+spec_ = importlib.util.spec_from_file_location('make_golden', HERE / 'golden' / 'make_golden.py')
+mg = importlib.util.module_from_spec(spec_)
+spec_.loader.exec_module(mg)
+GOLD = np.load(HERE / 'golden' / 'debug_step.npz')
+
+KEYS = ('model_loss', 'image_loss_mean', 'vector_loss_mean', 'kl_loss_mean',
+        'reward_loss_mean', 'cont_loss_mean', 'extr_critic_loss', 'actor_loss',
+        'model_grad_norm', 'extr_critic_grad_norm', 'actor_grad_norm',
+        'actent_mean', 'prior_ent_mean', 'post_ent_mean')
+
+
+def test_oracle_reproduces_golden():
+  from oracle import dreamer_ref
+  plain, sp, shapes, params, data, B, T = mg.build()
+  H = plain['imag_horizon']
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64)
+  state = None
+  for step in (1, 2):
+    noise = mg.golden_noise(B, T, H, sp.groups, sp.act_dim, step)
+    _, state, mets = ag.train(data, noise, state)
+    for k in KEYS:
+      g = float(GOLD[f's{step}/metric/{k}'])
+      assert abs(float(mets[k]) - g) <= 1e-9 * max(1, abs(g)), (step, k)
+    assert np.array_equal(ag.last['wm']['idxs']['post'].numpy(), GOLD[f's{step}/idx_post'])
+    assert np.array_equal(ag.last['traj']['idx'].numpy(), GOLD[f's{step}/idx_img'])
+
+
+def check_learner(L, data, mtol, gtol, exact_idx):
+  B, T, N, H, D, F, G, C = L.B, L.T, L.N, L.H, L.D, L.F, L.G, L.C
+  for step in (1, 2):
+    L.upload(data)
+    L.train_step_device(use_carry=(step > 1))
+    mets = L.read_metrics()
+    f = helpers.forced_from_learner(L)
+    for nm, key in (('obs_post', 'idx_post'), ('obs_prior', 'idx_prior'), ('img', 'idx_img')):
+      same = (f[nm].numpy() == GOLD[f's{step}/{key}'])
+      if exact_idx:
+        assert same.all(), (step, nm)
+      else:
+        assert same.mean() == 1.0, f'step {step}: {nm} draws differ from golden ({same.mean():.4f} equal)'
+    for k in KEYS:
+      g = float(GOLD[f's{step}/metric/{k}'])
+      assert abs(float(mets[k]) - g) <= mtol * max(abs(g), 1e-2), (step, k, float(mets[k]), g)
+    grads = L.export_grads()
+    for name, g in grads.items():
+      ref = GOLD[f's{step}/gradsum/{name}']
+      assert abs(g.astype(np.float64).sum() - ref[0]) <= gtol * max(ref[1], 1e-12), (step, name)
+    for k in ('rssm/initial_deter', 'actor/dist_out/std/kernel',
+              'reward/dist_out/out/kernel', 'rssm/obs_stats/bias'):
+      assert helpers.rel_err(grads[k], GOLD[f's{step}/grad/{k}']) < gtol * 10, (step, k)
+
+
+def test_learner_host_logic_matches_golden():
+  from oracle import ref_ops
+  plain, sp, shapes, params, data, B, T = mg.build()
+  L = LM.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params,
+                 noise_seed=mg.NOISE_SEED, dtype=torch.float64)
+  check_learner(L, data, 1e-6, 1e-6, True)
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden(hip):
+  plain, sp, shapes, params, data, B, T = mg.build()
+  L = LM.Learner(sp, hip, 'cuda:0', B, T, params=params, noise_seed=mg.NOISE_SEED)
+  check_learner(L, data, 1e-3, 1e-3, False)
