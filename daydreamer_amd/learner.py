@@ -242,7 +242,7 @@ class Learner:
     b['first'] = z(N)
     b['cont'] = z(N)
     # ---- noise
-    b['u_prior'] = z(T, B, G)
+    b['u_prior'] = z(B, T, G)      # batch-major: consumed in bulk after the scan
     b['u_post'] = z(T, B, G)
     b['u_img'] = z(max(H, 1), N, G)
     b['eps'] = z(H + 1, N, A)
@@ -558,9 +558,9 @@ class Learner:
     ops.stats_fwd(xs, None, b['init_logit'], b['init_stoch'], self.G, self.C,
                   self.unimix, 1)
 
-  def cell_fwd(self, xin, hprev, hn, A_in, z3, gstats, A_out, A_stats, sel):
-    """RSSM.img_step up to the prior statistics (reference nets.py:119-134).
-    xin [rows,S+A], hprev [rows,D] -> hn [rows,D]; returns raw stats."""
+  def core_fwd(self, xin, hprev, hn, A_in, z3, gstats, sel):
+    """RSSM.img_step up to the new deter (reference nets.py:119-130):
+    img_in Linear+LN+ELU, then the GRU cell.  xin [rows,S+A], hprev [rows,D]."""
     ops = self.ops
     x1 = self.lin_fwd(self.P['img_in'], A_in, xin, sel)
     z3v = sel(z3)
@@ -568,25 +568,34 @@ class Learner:
     ops.gemm(x1, self.P['gru_x'].W, z3v, beta=1.0)
     g = self.P['gru_h']
     ops.gru_fwd(z3v, g.gamma, g.beta, hprev, hn, sel(gstats))
-    x = hn
+
+  def prior_fwd(self, deter, A_out, A_stats, sel=None):
+    """img_out layers + img_stats on the new deter (reference nets.py:131-134);
+    returns the raw prior statistics."""
+    x = deter
     for i in range(self.n_prior):
       x = self.lin_fwd(self.P[f'img_out_{i}'], A_out[i], x, sel)
     return self.lin_fwd(self.P['img_stats'], A_stats, x, sel)
 
-  def cell_bwd(self, dhn_total, dxs, hprev, A_in, z3, gstats, A_out, A_stats,
-               sel, dz3, dy3, dh_direct, dxin, dxin_beta, dxin_P):
-    """Data-gradient backward of cell_fwd.  dhn_total [rows,D] holds the
-    gradient w.r.t. the new deter and is accumulated into in place; dxs is the
-    gradient w.r.t. the raw prior statistics (in A_stats.dout).  Outputs:
-    dz3, dy3 (GRU), dh_direct = (1-update)*dhn + dz3 @ Wg_h^T, and
-    dxin (+)= dz_in @ W_in^T restricted to dxin_P's rows."""
-    ops = self.ops
+  def prior_bwd(self, deter, ddeter, A_out, A_stats, sel=None, params=False):
+    """Backward of prior_fwd: A_stats.dout holds the gradient w.r.t. the raw
+    statistics; accumulates into ddeter (and parameter gradients if asked)."""
+    sel = sel or (lambda t: t)
     n = self.n_prior
-    ops.gemm(sel(A_stats.dout), self.P['img_stats'].W, sel(A_out[-1].dout), tb=True)
+    self.lin_bwd(self.P['img_stats'], A_stats, sel(A_out[-1].out), sel,
+                 sel(A_out[-1].dout), 0.0, params)
     for i in reversed(range(n)):
-      tgt = dhn_total if i == 0 else sel(A_out[i - 1].dout)
-      self.lin_bwd(self.P[f'img_out_{i}'], A_out[i], None, sel, tgt,
-                   1.0 if i == 0 else 0.0, params=False)
+      xin = deter if i == 0 else sel(A_out[i - 1].out)
+      tgt = ddeter if i == 0 else sel(A_out[i - 1].dout)
+      self.lin_bwd(self.P[f'img_out_{i}'], A_out[i], xin, sel, tgt,
+                   1.0 if i == 0 else 0.0, params)
+
+  def core_bwd(self, dhn_total, hprev, A_in, z3, gstats, sel, dz3, dy3,
+               dh_direct, dxin, dxin_beta, dxin_P):
+    """Data-gradient backward of core_fwd.  dhn_total [rows,D] is the gradient
+    w.r.t. the new deter.  Outputs: dz3, dy3 (GRU), dh_direct = (1-update)*dhn
+    + dz3 @ Wg_h^T, and dxin (+)= dz_in @ W_in^T restricted to dxin_P's rows."""
+    ops = self.ops
     g = self.P['gru_h']
     ops.gru_bwd(dhn_total, sel(z3), sel(gstats), g.gamma, g.beta, hprev, dz3,
                 dh_direct, dy3)
@@ -620,10 +629,8 @@ class Learner:
       xin = sel(b['xin'])
       ops.reset_mask(pd, first[:, t], b['init_deter'], hprev)
       ops.reset_mask(ps, first[:, t], b['init_stoch'], xin[:, :S])
-      xs = self.cell_fwd(xin, hprev, post[:, t, :D], self.a_img_in, b['z3'],
-                         b['gstats'], self.a_img_out, self.a_img_stats, sel)
-      ops.stats_fwd(xs, b['u_prior'][t], sel(b['prior_logit']),
-                    sel(b['prior_stoch']), self.G, self.C, self.unimix, 0)
+      self.core_fwd(xin, hprev, post[:, t, :D], self.a_img_in, b['z3'],
+                    b['gstats'], sel)
       # posterior: obs_out on concat[deter, embed]; embed part already in z
       Ao = self.a_obs_out
       ops.gemm(post[:, t, :D], self.P['obs_out_h'].W, sel(Ao.z), beta=1.0)
@@ -632,6 +639,12 @@ class Learner:
       xq = self.lin_fwd(self.P['obs_stats'], self.a_obs_stats, sel(Ao.out), sel)
       ops.stats_fwd(xq, b['u_post'][t], sel(b['post_logit']), post[:, t, D:],
                     self.G, self.C, self.unimix, 0)
+    # The prior statistics depend only on deter_t and feed nothing inside the
+    # scan (the prior sample is unused by obs_step): evaluate them for all T
+    # steps at once, off the sequential critical path.
+    xs = self.prior_fwd(b['post'][:, :D], self.a_img_out, self.a_img_stats)
+    ops.stats_fwd(xs, b['u_prior'].view(self.N, self.G), b['prior_logit'],
+                  b['prior_stoch'], self.G, self.C, self.unimix, 0)
 
   def observe_bwd(self):
     """Reverse scan.  On entry dfeat holds the heads' gradient w.r.t. every
@@ -644,42 +657,37 @@ class Learner:
     post = b['post'].view(B, T, F)
     dfeat = b['dfeat'].view(B, T, F)
     Ao, Po = self.a_obs_out, self.P['obs_out_h']
+    P = self.P
+    # prior head (KL gradient only): bulk over all steps, with parameter grads
+    ops.stats_bwd(self.a_img_stats.z, b['dprior_logit'], None,
+                  self.a_img_stats.dout, self.G, self.C, self.unimix)
+    self.prior_bwd(b['post'][:, :D], b['dfeat'][:, :D], self.a_img_out,
+                   self.a_img_stats, None, params=True)
     for t in reversed(range(T)):
       sel = bt(t)
       ddeter, dstoch = dfeat[:, t, :D], dfeat[:, t, D:]
       # posterior sample + statistics
       ops.stats_bwd(sel(self.a_obs_stats.z), sel(b['dpost_logit']), dstoch,
                     sel(self.a_obs_stats.dout), self.G, self.C, self.unimix)
-      ops.gemm(sel(self.a_obs_stats.dout), self.P['obs_stats'].W, sel(Ao.dout), tb=True)
+      ops.gemm(sel(self.a_obs_stats.dout), P['obs_stats'].W, sel(Ao.dout), tb=True)
       ops.ln_act_bwd(sel(Ao.dout), sel(Ao.z), sel(Ao.out), sel(Ao.stats),
                      Po.gamma, sel(Ao.dz), None, None, False, True)
       ops.gemm(sel(Ao.dz), Po.W, ddeter, tb=True, beta=1.0)
-      # prior statistics (KL only; the prior sample is unused downstream)
-      ops.stats_bwd(sel(self.a_img_stats.z), sel(b['dprior_logit']), None,
-                    sel(self.a_img_stats.dout), self.G, self.C, self.unimix)
-      self.cell_bwd(ddeter, None, sel(b['hprev']), self.a_img_in, b['z3'],
-                    b['gstats'], self.a_img_out, self.a_img_stats, sel,
-                    sel(b['dz3']), sel(b['dy3']), sel(b['dhprev']),
-                    sel(b['dxin_s']), 0.0, self.P['img_in_s'])
+      self.core_bwd(ddeter, sel(b['hprev']), self.a_img_in, b['z3'],
+                    b['gstats'], sel, sel(b['dz3']), sel(b['dy3']),
+                    sel(b['dhprev']), sel(b['dxin_s']), 0.0, P['img_in_s'])
       if t > 0:
         ops.reset_mask_bwd(sel(b['dhprev']), first[:, t], dfeat[:, t - 1, :D])
         ops.reset_mask_bwd(sel(b['dxin_s']), first[:, t], dfeat[:, t - 1, D:])
-    # ---- bulk parameter gradients over all T steps
+    # ---- bulk parameter gradients of the scan layers over all T steps
     m = self.groups['model']
-    P = self.P
     lnp = lambda L, A: ops.ln_param_grad(A.dout, A.z, A.out, A.stats, L.dgamma,
                                          L.dbeta, False, True)
-    As, Aq = self.a_img_stats, self.a_obs_stats
+    Aq = self.a_obs_stats
     ops.gemm(Ao.out, Aq.dout, P['obs_stats'].dW, ta=True)
     ops.col_sum(Aq.dout, P['obs_stats'].dbias)
     ops.gemm(b['post'][:, :D], Ao.dz, P['obs_out_h'].dW, ta=True)
     lnp(P['obs_out_h'], Ao)
-    ops.gemm(self.a_img_out[-1].out, As.dout, P['img_stats'].dW, ta=True)
-    ops.col_sum(As.dout, P['img_stats'].dbias)
-    for i in range(self.n_prior):
-      xin = b['post'][:, :D] if i == 0 else self.a_img_out[i - 1].out
-      ops.gemm(xin, self.a_img_out[i].dz, P[f'img_out_{i}'].dW, ta=True)
-      lnp(P[f'img_out_{i}'], self.a_img_out[i])
     ops.gemm(b['hprev'], b['dz3'], P['gru_h'].dW, ta=True)
     ops.gemm(self.a_img_in.out, b['dz3'], P['gru_x'].dW, ta=True)
     g = P['gru_h']
@@ -735,7 +743,7 @@ class Learner:
     ops.batch_prep(b['is_first'], b['is_terminal'], b['action'], b['first'],
                    b['cont'], b['xin'][:, self.S:])
     r0 = self.rank * B
-    ops.philox(b['u_prior'], T, B, G, self.Bg, r0, self.noise_seed, self.step_ctr, SITE_OBS_PRIOR, 0)
+    ops.philox(b['u_prior'], B, T, G, T, r0 * T, self.noise_seed, self.step_ctr, SITE_OBS_PRIOR, 0)
     ops.philox(b['u_post'], T, B, G, self.Bg, r0, self.noise_seed, self.step_ctr, SITE_OBS_POST, 0)
     if H > 0:
       ops.philox(b['u_img'], H, N, G, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_IMG, 0)
@@ -819,9 +827,10 @@ class Learner:
       ops.normal_head_fwd(om, os_, b['eps'][t], traj[t][:, F:], lo, hi)
       if t < H:
         si = lambda buf, t_=t: buf.view(H, N, -1)[t_]
-        xs = self.cell_fwd(traj[t][:, D:], traj[t][:, :D], traj[t + 1][:, :D],
-                           self.ai_img_in, b['iz3'], b['igstats'],
-                           self.ai_img_out, self.ai_img_stats, si)
+        self.core_fwd(traj[t][:, D:], traj[t][:, :D], traj[t + 1][:, :D],
+                      self.ai_img_in, b['iz3'], b['igstats'], si)
+        xs = self.prior_fwd(traj[t + 1][:, :D], self.ai_img_out,
+                            self.ai_img_stats, si)
         ops.stats_fwd(xs, b['u_img'][t], b['ilogit'], traj[t + 1][:, D:F],
                       self.G, self.C, self.unimix, 0)
     feat = traj.view(M, F + A)[:, :F]
@@ -934,10 +943,11 @@ class Learner:
       si = lambda buf, t_=t - 1: buf.view(H, N, -1)[t_]
       ops.stats_bwd(si(self.ai_img_stats.z), None, dtraj[t][:, D:F],
                     si(self.ai_img_stats.dout), self.G, self.C, self.unimix)
-      self.cell_bwd(dtraj[t][:, :D], None, traj[t - 1][:, :D], self.ai_img_in,
-                    b['iz3'], b['igstats'], self.ai_img_out, self.ai_img_stats,
-                    si, b['idz3'], b['idy3'], b['idh'], dtraj[t - 1][:, D:], 1.0,
-                    self.P['img_in'])
+      self.prior_bwd(None, dtraj[t][:, :D], self.ai_img_out, self.ai_img_stats,
+                     si, params=False)
+      self.core_bwd(dtraj[t][:, :D], traj[t - 1][:, :D], self.ai_img_in,
+                    b['iz3'], b['igstats'], si, b['idz3'], b['idy3'], b['idh'],
+                    dtraj[t - 1][:, D:], 1.0, self.P['img_in'])
       ops.reset_mask_bwd(b['idh'], zr, dtraj[t - 1][:, :D])
     # policy head + entropy bonus, then the actor network (bulk)
     dact = dtraj.view(M, F + A)[:, F:]
@@ -963,7 +973,7 @@ class Learner:
     ops.counter_add(self.step_ctr, 1)
     ops.batch_prep(b['is_first'], b['is_terminal'], b['action'], b['first'],
                    b['cont'], b['xin'][:, S:])
-    ops.philox(b['u_prior'], 1, B, G, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY, 0)
+    ops.philox(b['u_prior'], B, 1, G, 1, 0, self.noise_seed, self.step_ctr, SITE_POLICY, 0)
     ops.philox(b['u_post'], 1, B, G, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 1, 0)
     ops.philox(b['eps'][0], 1, B, A, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 2, 1)
     self.encoder_fwd()

@@ -32,7 +32,8 @@ def golden_noise(B, T, H, G, A, step):
   N = B * T
   f = ref_ops.philox_field
   return dict(
-      u_obs_prior=f(T, B, G, B, 0, NOISE_SEED, step, LM.SITE_OBS_PRIOR, 0),
+      # prior noise is generated batch-major (row = b*T + t)
+      u_obs_prior=np.ascontiguousarray(f(B, T, G, T, 0, NOISE_SEED, step, LM.SITE_OBS_PRIOR, 0).transpose(1, 0, 2)),
       u_obs_post=f(T, B, G, B, 0, NOISE_SEED, step, LM.SITE_OBS_POST, 0),
       u_img=f(H, N, G, N, 0, NOISE_SEED, step, LM.SITE_IMG, 0),
       eps_act=f(H + 1, N, A, N, 0, NOISE_SEED, step, LM.SITE_ACT, 1))

@@ -53,7 +53,7 @@ def forced_from_learner(L):
 def noise_from_learner(L):
   b = L.b
   return dict(
-      u_obs_prior=b['u_prior'].cpu().numpy(), u_obs_post=b['u_post'].cpu().numpy(),
+      u_obs_prior=b['u_prior'].permute(1, 0, 2).cpu().numpy(), u_obs_post=b['u_post'].cpu().numpy(),
       u_img=b['u_img'].cpu().numpy(), eps_act=b['eps'].cpu().numpy())
 
 
