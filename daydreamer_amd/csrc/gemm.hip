@@ -465,9 +465,14 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
   DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_up: geometry");
   const int kkc = k * k * Cb;
   const size_t per_img = (size_t)hs * ws_ * kkc * sizeof(float);
-  if (Cb <= 8 && wsp && ws_bytes >= 2 * per_img) {
-    // Few output channels (the image layer): an MFMA tile would be >90% padding
-    // in N.  cols = small[npix,Cs] @ W^T[Cs, k*k*Cb] (dense GEMM), then a gather.
+  // GEMM + col2im instead of the implicit parity form when (a) there are few output
+  // channels (image layer: an MFMA tile would be >90% padding in N), or (b) the
+  // column buffer is small enough (<= 1 GiB) that its HBM round trip costs less than
+  // the parity form's out-of-range taps (13-55% of its MFMA work at these sizes).
+  const size_t cols_bytes = per_img * (size_t)n_img;
+  if (wsp && ws_bytes >= 2 * per_img &&
+      (Cb <= 8 || (cols_bytes <= ((size_t)1 << 30) && cols_bytes <= ws_bytes / 2))) {
+    // cols = small[npix,Cs] @ W^T[Cs, k*k*Cb] (dense GEMM), then a gather.
     const int chunk = (int)((ws_bytes / 2) / per_img);  // second half: split-K scratch
     float* cols = wsp;
     float* ws2 = wsp + (ws_bytes / 2) / sizeof(float);

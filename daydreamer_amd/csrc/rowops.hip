@@ -150,6 +150,152 @@ k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__
   }
 }
 
+
+// ---- vectorised LayerNorm kernels: LPR lanes own one row, V float4 per lane,
+// 64/LPR rows per wave (C = 64 rows are 16 lanes wide: 4 rows per wavefront).
+template <int LPR>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR, int V>
+__global__ void __launch_bounds__(256)
+k_ln_act_fwd_v(const float* __restrict__ z, long ldz, const float* __restrict__ gamma,
+               const float* __restrict__ beta, float* __restrict__ out, long ldo,
+               float* __restrict__ stats, long lds, int rows, int C, int act) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  for (long row0 = ((long)blockIdx.x * WPB + wave) * RPW; row0 < rows;
+       row0 += (long)gridDim.x * WPB * RPW) {
+    const long row = row0 + sub;
+    const bool live = row < rows;
+    float4 x[V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = (l + LPR * i) * 4;
+      x[i] = (live && c < C) ? *reinterpret_cast<const float4*>(z + row * ldz + c)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += x[i].x + x[i].y + x[i].z + x[i].w;
+    }
+    const float mean = grp_sum<LPR>(s) / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = (l + LPR * i) * 4;
+      if (c < C) {
+        float a = x[i].x - mean, b = x[i].y - mean, d = x[i].z - mean, e = x[i].w - mean;
+        v += a * a + b * b + d * d + e * e;
+      }
+    }
+    const float rstd = rsqrtf(grp_sum<LPR>(v) / (float)C + LN_EPS);
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        int c = (l + LPR * i) * 4;
+        if (c < C) {
+          float4 g = *reinterpret_cast<const float4*>(gamma + c);
+          float4 bb = *reinterpret_cast<const float4*>(beta + c);
+          float4 y;
+          y.x = (x[i].x - mean) * rstd * g.x + bb.x;
+          y.y = (x[i].y - mean) * rstd * g.y + bb.y;
+          y.z = (x[i].z - mean) * rstd * g.z + bb.z;
+          y.w = (x[i].w - mean) * rstd * g.w + bb.w;
+          if (act) { y.x = elu_(y.x); y.y = elu_(y.y); y.z = elu_(y.z); y.w = elu_(y.w); }
+          *reinterpret_cast<float4*>(out + row * ldo + c) = y;
+        }
+      }
+      if (l == 0) { stats[row * lds] = mean; stats[row * lds + 1] = rstd; }
+    }
+  }
+}
+
+// partials layout: [gridDim.x][3][C] = (dgamma, dbeta, column sum of dz)
+template <int LPR, int V>
+__global__ void __launch_bounds__(256)
+k_ln_act_bwd_v(const float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
+               const float* __restrict__ out, long ldo, const float* __restrict__ stats, long lds,
+               const float* __restrict__ gamma, float* __restrict__ dz, long lddz,
+               float* __restrict__ partials, int rows, int C, int act) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  float4 pg[V], pb[V], pz[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    pg[i] = make_float4(0.f, 0.f, 0.f, 0.f); pb[i] = pg[i]; pz[i] = pg[i];
+  }
+  for (long row0 = ((long)blockIdx.x * WPB + wave) * RPW; row0 < rows;
+       row0 += (long)gridDim.x * WPB * RPW) {
+    const long row = row0 + sub;
+    const bool live = row < rows;
+    const float mean = live ? stats[row * lds] : 0.f, rstd = live ? stats[row * lds + 1] : 0.f;
+    float4 g[V], xh[V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = (l + LPR * i) * 4;
+      g[i] = make_float4(0.f, 0.f, 0.f, 0.f); xh[i] = g[i];
+      if (live && c < C) {
+        float4 dy = *reinterpret_cast<const float4*>(dout + row * ldd + c);
+        if (act) {
+          float4 o = *reinterpret_cast<const float4*>(out + row * ldo + c);
+          dy.x *= (o.x > 0.f ? 1.f : o.x + 1.f); dy.y *= (o.y > 0.f ? 1.f : o.y + 1.f);
+          dy.z *= (o.z > 0.f ? 1.f : o.z + 1.f); dy.w *= (o.w > 0.f ? 1.f : o.w + 1.f);
+        }
+        float4 zz = *reinterpret_cast<const float4*>(z + row * ldz + c);
+        float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+        xh[i].x = (zz.x - mean) * rstd; xh[i].y = (zz.y - mean) * rstd;
+        xh[i].z = (zz.z - mean) * rstd; xh[i].w = (zz.w - mean) * rstd;
+        g[i].x = dy.x * gm.x; g[i].y = dy.y * gm.y; g[i].z = dy.z * gm.z; g[i].w = dy.w * gm.w;
+        pg[i].x += dy.x * xh[i].x; pg[i].y += dy.y * xh[i].y; pg[i].z += dy.z * xh[i].z; pg[i].w += dy.w * xh[i].w;
+        pb[i].x += dy.x; pb[i].y += dy.y; pb[i].z += dy.z; pb[i].w += dy.w;
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+      }
+    }
+    s1 = grp_sum<LPR>(s1) / (float)C;
+    s2 = grp_sum<LPR>(s2) / (float)C;
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        int c = (l + LPR * i) * 4;
+        if (c < C) {
+          float4 r;
+          r.x = rstd * (g[i].x - s1 - xh[i].x * s2); r.y = rstd * (g[i].y - s1 - xh[i].y * s2);
+          r.z = rstd * (g[i].z - s1 - xh[i].z * s2); r.w = rstd * (g[i].w - s1 - xh[i].w * s2);
+          pz[i].x += r.x; pz[i].y += r.y; pz[i].z += r.z; pz[i].w += r.w;
+          *reinterpret_cast<float4*>(dz + row * lddz + c) = r;
+        }
+      }
+    }
+  }
+  if (partials) {
+    // combine the WPB*RPW row groups of this block through LDS
+    extern __shared__ __attribute__((aligned(16))) float shv[];  // [WPB*RPW][3][C]
+    const int slot = wave * RPW + sub;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = (l + LPR * i) * 4;
+      if (c < C) {
+        *reinterpret_cast<float4*>(&shv[((long)slot * 3 + 0) * C + c]) = pg[i];
+        *reinterpret_cast<float4*>(&shv[((long)slot * 3 + 1) * C + c]) = pb[i];
+        *reinterpret_cast<float4*>(&shv[((long)slot * 3 + 2) * C + c]) = pz[i];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * C; e += 256) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPB * RPW; ++w) a += shv[(long)w * 3 * C + e];
+      partials[(long)blockIdx.x * 3 * C + e] = a;
+    }
+  }
+}
+
 // ---- generic LN parameter gradient: thread per column, 4 row lanes per
 // block, grid.y row chunks -> partials[grid.y][2][C] -------------------------
 __global__ void __launch_bounds__(256)
@@ -312,6 +458,18 @@ int dispatch_npl(int C, F f) {
   return f(std::integral_constant<int, 0>());
 }
 
+template <typename F>
+int dispatch_vec(int C, F f) {
+  if (C <= 64) return f(std::integral_constant<int, 16>(), std::integral_constant<int, 1>());
+  if (C <= 128) return f(std::integral_constant<int, 32>(), std::integral_constant<int, 1>());
+  if (C <= 256) return f(std::integral_constant<int, 64>(), std::integral_constant<int, 1>());
+  if (C <= 512) return f(std::integral_constant<int, 64>(), std::integral_constant<int, 2>());
+  if (C <= 768) return f(std::integral_constant<int, 64>(), std::integral_constant<int, 3>());
+  return f(std::integral_constant<int, 64>(), std::integral_constant<int, 4>());
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 inline int row_blocks(long rows, int cap) {
   long b = (rows + WPB - 1) / WPB;
   if (b > cap) b = cap;
@@ -325,6 +483,17 @@ extern "C" int dd_ln_act_fwd(const float* z, long ldz, const float* gamma, const
                              void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (C % 4 == 0 && C <= 1024 && ldz % 4 == 0 && ldo % 4 == 0 && al16(z) && al16(out) &&
+      al16(gamma) && al16(beta)) {
+    return dispatch_vec(C, [&](auto lpr, auto v) {
+      constexpr int LPR = decltype(lpr)::value, V = decltype(v)::value;
+      long groups = (rows + (64 / LPR) - 1) / (64 / LPR);
+      int blocks = row_blocks(groups, 1 << 20);
+      k_ln_act_fwd_v<LPR, V><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act);
+      DD_CHECK_LAUNCH("dd_ln_act_fwd");
+      return 0;
+    });
+  }
   int blocks = row_blocks(rows, 1 << 20);
   return dispatch_npl(C, [&](auto npl) {
     k_ln_act_fwd<decltype(npl)::value><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act);
@@ -344,11 +513,36 @@ extern "C" int dd_ln_bwd_parts(int rows, int C) {
 
 extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
                              const float* out, long ldo, const float* stats, long lds, const float* gamma,
-                             float* dz, long lddz, float* dgamma, float* dbeta, int accumulate,
-                             int rows, int C, int act, float* ws, size_t ws_bytes, void* stream) {
+                             float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
+                             int accumulate, int rows, int C, int act, float* ws, size_t ws_bytes,
+                             void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool want = dgamma != nullptr;
+  const float b = accumulate ? 1.f : 0.f;
+  const int nb = (C + 63) / 64;
+  const bool vec = C % 4 == 0 && C <= 1024 && ldd % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 &&
+                   lddz % 4 == 0 && al16(dout) && al16(z) && al16(out) && al16(dz) && al16(gamma);
+  if (vec) {
+    return dispatch_vec(C, [&](auto lpr, auto v) {
+      constexpr int LPR = decltype(lpr)::value, V = decltype(v)::value;
+      constexpr int RPW = 64 / LPR;
+      long groups = (rows + RPW - 1) / RPW;
+      int blocks = want ? row_blocks(groups, 256) : row_blocks(groups, 1 << 20);
+      size_t shmem = want ? (size_t)WPB * RPW * 3 * C * sizeof(float) : 0;
+      if (want) DD_REQUIRE(ws && (size_t)blocks * 3 * C * sizeof(float) <= ws_bytes, "dd_ln_act_bwd: workspace too small");
+      k_ln_act_bwd_v<LPR, V><<<blocks, 256, shmem, st>>>(
+          dout, ldd, z, ldz, out, ldo, stats, lds, gamma, dz, lddz, want ? ws : nullptr, rows, C, act);
+      DD_CHECK_LAUNCH("dd_ln_act_bwd");
+      if (want) {
+        k_col_reduce<<<nb, 256, 0, st>>>(ws, blocks, 3L * C, C, dgamma, b);
+        k_col_reduce<<<nb, 256, 0, st>>>(ws + C, blocks, 3L * C, C, dbeta, b);
+        if (dbias_pre) k_col_reduce<<<nb, 256, 0, st>>>(ws + 2 * C, blocks, 3L * C, C, dbias_pre, b);
+        DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce)");
+      }
+      return 0;
+    });
+  }
   const int parts = dd_ln_bwd_parts(rows, C);
   if (want) DD_REQUIRE(ws && (size_t)parts * 2 * C * sizeof(float) <= ws_bytes, "dd_ln_act_bwd: workspace too small");
   const bool fused = want && C <= 1024;
@@ -366,12 +560,11 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
     DD_CHECK_LAUNCH("dd_ln_act_bwd(param grad)");
   }
   // partials are [parts][2][C]: gamma rows at stride 2C from ws, beta rows from ws + C.
-  const int nb = (C + 63) / 64;
-  const float b = accumulate ? 1.f : 0.f;
   k_col_reduce<<<nb, 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, b);
   DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce gamma)");
   k_col_reduce<<<nb, 256, 0, st>>>(ws + C, parts, 2L * C, C, dbeta, b);
   DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce beta)");
+  if (dbias_pre) return dd_col_sum(dz, lddz, dbias_pre, b, rows, C, ws, ws_bytes, stream);
   return 0;
 }
 

@@ -32,7 +32,7 @@ _SIGS = {
     'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
     'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
-    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
+    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_ln_bwd_parts': [c_i, c_i],
     'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_col_sum': [c_p, c_l, c_p, c_f, c_l, c_i, c_p, c_z, c_p],
@@ -204,7 +204,7 @@ class HipOps:
         rows, C, int(act), self.stream), 'dd_ln_act_fwd')
 
   def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
-                 dbeta=None, accumulate=False, act=True):
+                 dbeta=None, accumulate=False, act=True, dbias_pre=None):
     rows, C = z.shape
     dp, ldd = _mat(dout)
     zp, ldz = _mat(z)
@@ -212,7 +212,8 @@ class HipOps:
     dzp, lddz = _mat(dz)
     self._check(self.lib.dd_ln_act_bwd(
         dp, ldd, zp, ldz, op, ldo, *_mat(stats), gamma.data_ptr(), dzp,
-        lddz, _ptr(dgamma), _ptr(dbeta), int(accumulate), rows, C, int(act),
+        lddz, _ptr(dgamma), _ptr(dbeta), _ptr(dbias_pre), int(accumulate),
+        rows, C, int(act),
         self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_ln_act_bwd')
 
   def ln_param_grad(self, dout, z, out, stats, dgamma, dbeta,

@@ -468,8 +468,7 @@ class Learner:
                        a['out'].view(-1, C), a['stats'],
                        m.p[f'{cl.name}/norm/scale'], a['dz'].view(-1, C),
                        m.g[f'{cl.name}/norm/scale'], m.g[f'{cl.name}/norm/bias'],
-                       False, True)
-        ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
+                       False, True, m.g[f'{cl.name}/bias'])
         big = b['image'] if i == 0 else self.enc_act[i - 1]['out']
         ops.conv_wgrad(big, a['dz'], m.g[f'{cl.name}/kernel'], cl.k,
                        1.0 / 255.0 if i == 0 else 1.0)
@@ -529,8 +528,10 @@ class Learner:
                          a['out'].view(-1, C), a['stats'],
                          m.p[f'{cl.name}/norm/scale'], a['dz'].view(-1, C),
                          m.g[f'{cl.name}/norm/scale'],
-                         m.g[f'{cl.name}/norm/bias'], False, True)
-        ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
+                         m.g[f'{cl.name}/norm/bias'], False, True,
+                         m.g[f'{cl.name}/bias'])
+        else:
+          ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
         if i > 0:
           prev = self.dec_act[i - 1]
           ops.conv_wgrad(a['dz'], prev['out'], m.g[f'{cl.name}/kernel'], cl.k)

@@ -66,10 +66,13 @@ int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float
  * 1 elu.  stats[rows,2] = (mean, rstd), row stride lds.  Norm nets.py:585-602 + get_act. */
 int dd_ln_act_fwd(const float* z, long ldz, const float* gamma, const float* beta,
                   float* out, long ldo, float* stats, long lds, int rows, int C, int act, void* stream);
-/* dz from dout; if dgamma != NULL also dgamma/dbeta (accumulate: += ). */
+/* dz from dout; if dgamma != NULL also dgamma/dbeta and, if dbias_pre != NULL,
+ * the column sum of dz (gradient of a bias added before the norm, as in Conv2D
+ * nets.py:548-553); accumulate: += . */
 int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
                   const float* out, long ldo, const float* stats, long lds, const float* gamma,
-                  float* dz, long lddz, float* dgamma, float* dbeta, int accumulate,
+                  float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
+                  int accumulate,
                   int rows, int C, int act, float* ws, size_t ws_bytes, void* stream);
 int dd_ln_bwd_parts(int rows, int C);
 /* dgamma/dbeta only, from stored activations of all scan steps. */

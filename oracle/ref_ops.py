@@ -140,7 +140,7 @@ class RefOps:
     return dout
 
   def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
-                 dbeta=None, accumulate=False, act=True):
+                 dbeta=None, accumulate=False, act=True, dbias_pre=None):
     mean, rstd = stats[:, :1], stats[:, 1:2]
     dy = self._ln_dy(dout, out, act)
     xh = (z - mean) * rstd
@@ -152,6 +152,9 @@ class RefOps:
       dg, db = (dy * xh).sum(0), dy.sum(0)
       dgamma.copy_(dgamma + dg if accumulate else dg)
       dbeta.copy_(dbeta + db if accumulate else db)
+      if dbias_pre is not None:
+        dp = res.sum(0)
+        dbias_pre.copy_(dbias_pre + dp if accumulate else dp)
     dz.copy_(res)
 
   def ln_param_grad(self, dout, z, out, stats, dgamma, dbeta,

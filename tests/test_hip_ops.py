@@ -129,16 +129,17 @@ def test_conv_adjoint_large(hip):
 
 
 @pytest.mark.parametrize('rows,C,act', [(50, 256, 1), (2500, 512, 1), (1000, 64, 1),
-                                        (77, 768, 0), (33, 40, 1), (9, 1500, 1), (300, 1024, 0)])
+                                        (77, 768, 0), (33, 40, 1), (9, 1500, 1), (300, 1024, 0),
+                                        (5000, 128, 1), (3, 64, 0), (130, 42, 1)])
 def test_ln_act(hip, ref, rows, C, act):
   z, gamma, beta = rnd(rows, C, seed=1, scale=2.0), 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
   out, stats, dout = torch.zeros(rows, C), torch.zeros(rows, 2), rnd(rows, C, seed=4)
-  dz, dg, db = torch.zeros(rows, C), rnd(C, seed=5), rnd(C, seed=6)
-  def fn(ops, z, gamma, beta, out, stats, dout, dz, dg, db):
+  dz, dg, db, dbp = torch.zeros(rows, C), rnd(C, seed=5), rnd(C, seed=6), rnd(C, seed=7)
+  def fn(ops, z, gamma, beta, out, stats, dout, dz, dg, db, dbp):
     ops.ln_act_fwd(z, gamma, beta, out, stats, bool(act))
-    ops.ln_act_bwd(dout, z, out, stats, gamma, dz, dg, db, True, bool(act))
-  res = both(hip, ref, fn, [z, gamma, beta, out, stats, dout, dz, dg, db], [3, 4, 6, 7, 8])
-  for (g, c), nm in zip(res, ['out', 'stats', 'dz', 'dgamma', 'dbeta']):
+    ops.ln_act_bwd(dout, z, out, stats, gamma, dz, dg, db, True, bool(act), dbp)
+  res = both(hip, ref, fn, [z, gamma, beta, out, stats, dout, dz, dg, db, dbp], [3, 4, 6, 7, 8, 9])
+  for (g, c), nm in zip(res, ['out', 'stats', 'dz', 'dgamma', 'dbeta', 'dbias_pre']):
     close(g, c, rtol=1e-4, what=f'ln {nm}')
   dg2, db2 = torch.zeros(C), torch.zeros(C)
   def fn2(ops, z, gamma, beta, out, stats, dout, dg2, db2):
