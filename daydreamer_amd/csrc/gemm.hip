@@ -369,9 +369,14 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
             float alpha, float beta, float* ws, size_t ws_bytes, hipStream_t st,
             const char* name) {
   if (M <= 0 || N <= 0) return 0;
-  // tiles: 128x128 for large problems, 128x64 for narrow outputs, 64x64 for few rows
-  const int TMS = (M > 64) ? 128 : 64;
-  const int TNS = (M > 64 && N > 64) ? 128 : 64;
+  // tiles: 128x128 for large problems, 128x64 for narrow outputs, 64x64 for few rows;
+  // mid-size problems drop to smaller tiles until the grid covers the 256 CUs.
+  int TMS = (M > 64) ? 128 : 64;
+  int TNS = (M > 64 && N > 64) ? 128 : 64;
+  // (deep-K problems keep the big tile and get their parallelism from split-K)
+  const bool shallow = K <= 1536;
+  if (shallow && TMS == 128 && TNS == 128 && (long)dd_ceil_div(M, 128) * dd_ceil_div(N, 128) < 256) TNS = 64;
+  if (shallow && TMS == 128 && TNS == 64 && (long)dd_ceil_div(M, 128) * dd_ceil_div(N, 64) < 256) TMS = 64;
   const int tm = dd_ceil_div(M, TMS), tn = dd_ceil_div(N, TNS);
   const long MN = (long)M * N;
   int S = pick_split((long)tm * tn, K, MN, ws ? ws_bytes : 0);
