@@ -67,6 +67,15 @@ def test_e2e_vision_small_units(hip):
   run(hip, cfg, 1, image=64, vector=16, action=16, terminals=0.0)
 
 
+def test_e2e_scaled_latent(hip):
+  """BASELINE configs[4] network family (a1_scaled: deter 4096, stoch 64x64, horizon
+  20) at a tiny batch: exercises the generic (C > 1024) LayerNorm / GRU paths and the
+  64-class latent kernels against the oracle."""
+  cfg = helpers.make_config(('a1_scaled',), batch_size=2, replay_chunk=3, imag_horizon=2)
+  cfg = cfg.update({'rssm.deter': 1536})  # keeps the fp64 oracle quick; still > 1024 LN
+  run(hip, cfg, 1, image=64, vector=16, action=16, terminals=0.0)
+
+
 def test_full_size_properties(hip):
   """BASELINE configs[1] at full size (batch 50 x seq 50 x horizon 15): the oracle
   is too slow here, so check size-independent properties instead: finite losses,
