@@ -91,10 +91,17 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', 1))
   rank = int(os.environ.get('RANK', 0))
   local = int(os.environ.get('LOCAL_RANK', 0))
+  ndev = torch.cuda.device_count()
+  local = local % max(ndev, 1)  # (testing aid: several ranks may share one GPU under gloo)
+  os.environ['LOCAL_RANK'] = str(local)
   torch.cuda.set_device(local)
   if world > 1:
     import torch.distributed as dist
-    dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+    backend = os.environ.get('DD_DIST_BACKEND', 'nccl')  # nccl == RCCL on ROCm
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+    else:
+      dist.init_process_group(backend)
   assert world == args.gpus, (world, args.gpus)
 
   cfg = make_config(args.config)

@@ -892,8 +892,8 @@ class Learner:
     ops.sub(b['i_ret2'], b['i_value2'], b['i_diff'][:HN])
     kr = self.stat('ret2', b['i_ret2'][:HN])
     kd = self.stat('diff', b['i_diff'][:HN])
-    self.allreduce(self.stat_sums[kr])
-    self.allreduce(self.stat_sums[kd])
+    assert kd == kr + 1  # adjacent slots: one collective
+    self.allreduce(self.stat_sums[kr:kd + 1])
     self.stat_prereduced.update((kr, kd))
     cnt = float(H * self.Ng)
     impl = {'off': 0, 'mean_std': 1, 'std': 2}
