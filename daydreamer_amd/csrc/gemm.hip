@@ -307,7 +307,9 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   const int lk = lane >> 5, lr = lane & 31;
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
+#ifndef EXP_NOLOAD  // ablation switches (tools/gemm_exp.py), see DESIGN.md section 5
     if (t + 1 < nk) gload(kb + (t + 1) * BK);
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float af[TM], bf[TN];
@@ -321,8 +323,12 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
         for (int b = 0; b < TN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
+#ifndef EXP_NOSTORE
     if (t + 1 < nk) sstore(buf ^ 1);
+#endif
+#ifndef EXP_NOBARRIER
     __syncthreads();
+#endif
   }
 #pragma unroll
   for (int a = 0; a < TM; ++a)
