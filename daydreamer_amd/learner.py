@@ -531,7 +531,15 @@ class Learner:
                          m.g[f'{cl.name}/norm/bias'], False, True,
                          m.g[f'{cl.name}/bias'])
         else:
-          ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
+          # image layer: C = 3 columns would leave 61 of 64 column lanes idle; sum
+          # 64-pixel groups as a [rows/64, 64*C] matrix first, then fold the 64 groups.
+          px = a['dz'].numel() // C
+          if px % 64 == 0:
+            tmp = b.setdefault('bias_fold', self.zeros(64 * C))
+            ops.col_sum(a['dz'].view(px // 64, 64 * C), tmp)
+            ops.col_sum(tmp.view(64, C), m.g[f'{cl.name}/bias'])
+          else:
+            ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
         if i > 0:
           prev = self.dec_act[i - 1]
           ops.conv_wgrad(a['dz'], prev['out'], m.g[f'{cl.name}/kernel'], cl.k)
