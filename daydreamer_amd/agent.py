@@ -99,13 +99,15 @@ class Agent:
     self.obs_space = {k: v for k, v in obs_space.items()
                       if not k.startswith('log_')}
     self.act_space = act_space['action']
-    if getattr(self.act_space, 'discrete', False):
-      raise NotImplementedError(
-          'discrete action spaces (REINFORCE actor) are not implemented yet')
+    # Discrete spaces arrive one-hot encoded (embodied.wrappers.OneHotAction:
+    # float32 [n] with .discrete = True) -> 'onehot' actor trained by REINFORCE.
+    self.act_discrete = bool(getattr(self.act_space, 'discrete', False))
     self.step = step
     self.act_dim = int(np.prod(self.act_space.shape))
+    assert not self.act_discrete or len(self.act_space.shape) == 1, self.act_space
     shapes = {k: tuple(v.shape) for k, v in self.obs_space.items()}
-    self.spec = spec_mod.build_spec(self.cfg, shapes, self.act_dim)
+    self.spec = spec_mod.build_spec(self.cfg, shapes, self.act_dim,
+                                    self.act_discrete)
     self.rank, self.world, self.comm = 0, 1, None
     try:
       import torch.distributed as dist

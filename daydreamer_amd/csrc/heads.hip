@@ -237,6 +237,77 @@ __global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b,
   if (i < n) o[i] = a[i] - b[i];
 }
 
+// ---- one-hot (categorical) policy head, REINFORCE (agent.py:357-358, 372-377) ----
+// wave per row; logit [rows, A] are normalised log-probs (unimix already applied).
+// ent_out[row] = H(row) / ent_div.
+__global__ void __launch_bounds__(256)
+k_onehot_entropy(const float* __restrict__ logit, long ldl, float* __restrict__ ent_out,
+                 int rows, int A, float ent_div) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float m = -INFINITY;
+  for (int a = lane; a < A; a += 64) m = fmaxf(m, logit[r * ldl + a]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int a = lane; a < A; a += 64) s += expf(logit[r * ldl + a] - m);
+  const float lse = m + logf(wave_sum(s));
+  float h = 0.f;
+  for (int a = lane; a < A; a += 64) {
+    float ll = logit[r * ldl + a] - lse;
+    h -= expf(ll) * ll;
+  }
+  h = wave_sum(h);
+  if (lane == 0) ent_out[r] = h / ent_div;
+}
+
+// rows < rows_grad: score = ((ret - base)*sc[0] - sc[1])*sc[2];
+//   loss_pg[row]  = w * (-logp(action) * score)
+//   loss_ent[row] = w * (scale * -H/ent_div)
+//   dlogit_c = coef * w * ( -score*(onehot_c - p_c) + scale * p_c*(ll_c + H)/ent_div )
+// rows >= rows_grad: dlogit = 0.
+__global__ void __launch_bounds__(256)
+k_onehot_policy_grad(const float* __restrict__ logit, long ldl, const float* __restrict__ action,
+                     long lda, const float* __restrict__ ret, const float* __restrict__ base,
+                     const float* __restrict__ w, const float* __restrict__ sc,
+                     const float* __restrict__ scale, float* __restrict__ dlogit, long lddl,
+                     float* __restrict__ loss_pg, float* __restrict__ loss_ent, int rows,
+                     int rows_grad, int A, float coef, float ent_div) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  if (r >= rows_grad) {
+    for (int a = lane; a < A; a += 64) dlogit[r * lddl + a] = 0.f;
+    return;
+  }
+  float m = -INFINITY;
+  for (int a = lane; a < A; a += 64) m = fmaxf(m, logit[r * ldl + a]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int a = lane; a < A; a += 64) s += expf(logit[r * ldl + a] - m);
+  const float lse = m + logf(wave_sum(s));
+  float h = 0.f, lp = 0.f;
+  for (int a = lane; a < A; a += 64) {
+    float ll = logit[r * ldl + a] - lse;
+    h -= expf(ll) * ll;
+    lp += action[r * lda + a] * ll;
+  }
+  h = wave_sum(h);
+  lp = wave_sum(lp);
+  const float score = ((ret[r] - base[r]) * sc[0] - sc[1]) * sc[2];
+  const float wr = w[r], es = scale[0];
+  for (int a = lane; a < A; a += 64) {
+    float ll = logit[r * ldl + a] - lse;
+    float p = expf(ll);
+    float g = -score * (action[r * lda + a] - p) + es * p * (ll + h) / ent_div;
+    dlogit[r * lddl + a] = coef * wr * g;
+  }
+  if (lane == 0) {
+    loss_pg[r] = wr * (-lp * score);
+    loss_ent[r] = wr * (es * -(h / ent_div));
+  }
+}
+
 inline int nblk(long n, int t = 256) { return (int)((n + t - 1) / t); }
 
 }  // namespace
@@ -337,5 +408,26 @@ extern "C" int dd_sub(const float* a, const float* b, float* o, long n, void* st
   if (n <= 0) return 0;
   k_sub<<<nblk(n), 256, 0, (hipStream_t)stream>>>(a, b, o, n);
   DD_CHECK_LAUNCH("dd_sub");
+  return 0;
+}
+
+extern "C" int dd_onehot_entropy(const float* logit, long ldl, float* ent_out, int rows, int A,
+                                 float ent_div, void* stream) {
+  if (rows <= 0) return 0;
+  k_onehot_entropy<<<nblk(rows, 4), 256, 0, (hipStream_t)stream>>>(logit, ldl, ent_out, rows, A, ent_div);
+  DD_CHECK_LAUNCH("dd_onehot_entropy");
+  return 0;
+}
+
+extern "C" int dd_onehot_policy_grad(const float* logit, long ldl, const float* action, long lda,
+                                     const float* ret, const float* base, const float* w,
+                                     const float* sc, const float* scale, float* dlogit, long lddl,
+                                     float* loss_pg, float* loss_ent, int rows, int rows_grad,
+                                     int A, float coef, float ent_div, void* stream) {
+  if (rows <= 0) return 0;
+  k_onehot_policy_grad<<<nblk(rows, 4), 256, 0, (hipStream_t)stream>>>(
+      logit, ldl, action, lda, ret, base, w, sc, scale, dlogit, lddl, loss_pg, loss_ent, rows,
+      rows_grad, A, coef, ent_div);
+  DD_CHECK_LAUNCH("dd_onehot_policy_grad");
   return 0;
 }

@@ -53,6 +53,8 @@ _SIGS = {
     'dd_critic_loss': [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
     'dd_actor_seed': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
     'dd_sub': [c_p, c_p, c_p, c_l, c_p],
+    'dd_onehot_entropy': [c_p, c_l, c_p, c_i, c_i, c_f, c_p],
+    'dd_onehot_policy_grad': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p],
     'dd_philox': [c_p, c_l, c_l, c_i, c_l, c_l, c_ull, c_p, c_u, c_i, c_p],
     'dd_counter_add': [c_p, c_ull, c_p],
     'dd_reduce_stats': [c_p, c_l, c_l, c_p, c_p, c_p],
@@ -379,6 +381,25 @@ class HipOps:
         ret.data_ptr(), base.data_ptr(), w.data_ptr(), _ptr(ent_row),
         sc.data_ptr(), loss.data_ptr(), dret.data_ptr(), dbase.data_ptr(),
         ret.numel(), coef, self.stream), 'dd_actor_seed')
+
+  def onehot_entropy(self, logit, ent_out, ent_div):
+    rows, A = logit.shape
+    lp, ldl = _mat(logit)
+    self._check(self.lib.dd_onehot_entropy(
+        lp, ldl, ent_out.data_ptr(), rows, A, ent_div, self.stream),
+        'dd_onehot_entropy')
+
+  def onehot_policy_grad(self, logit, action, ret, base, w, sc, scale, dlogit,
+                         loss_pg, loss_ent, rows_grad, coef, ent_div):
+    rows, A = logit.shape
+    lp, ldl = _mat(logit)
+    ap, lda = _mat(action)
+    dp, ldd = _mat(dlogit)
+    self._check(self.lib.dd_onehot_policy_grad(
+        lp, ldl, ap, lda, ret.data_ptr(), base.data_ptr(), w.data_ptr(),
+        sc.data_ptr(), scale.data_ptr(), dp, ldd, loss_pg.data_ptr(),
+        loss_ent.data_ptr(), rows, rows_grad, A, coef, ent_div, self.stream),
+        'dd_onehot_policy_grad')
 
   def sub(self, a, b, o):
     self._check(self.lib.dd_sub(

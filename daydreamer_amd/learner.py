@@ -125,7 +125,12 @@ class Learner:
     self.unimix = float(cfg['rssm']['unimix'])
     assert len(s.dec_cnn_keys) <= 1 and len(s.enc_cnn_keys) <= 1, \
         'multiple image keys are not implemented yet'
-    assert cfg['actor_grad_cont'] == 'backprop' and cfg['critic_type'] == 'vfunction'
+    self.discrete = bool(s.act_discrete)
+    assert cfg['critic_type'] == 'vfunction'
+    if self.discrete:
+      assert cfg['actor_grad_disc'] == 'reinforce' and cfg['actor_dist_disc'] == 'onehot'
+    else:
+      assert cfg['actor_grad_cont'] == 'backprop' and cfg['actor_dist_cont'] == 'normal'
     assert cfg['actor_return'] == 'gve' and cfg['critic_return'] == 'gve'
     assert cfg['scorenorm']['impl'] in ('off', 'std')
     for k in ('model_opt', 'actor_opt', 'critic_opt'):
@@ -205,7 +210,9 @@ class Learner:
     self.heads = {
         'reward': head('reward', 'model', 'reward_head', ['dist_out/out']),
         'cont': head('cont', 'model', 'cont_head', ['dist_out/out']),
-        'actor': head('actor', 'actor', 'actor', ['dist_out/out', 'dist_out/std']),
+        'actor': head('actor', 'actor', 'actor',
+                      ['dist_out/out'] if s.act_discrete else
+                      ['dist_out/out', 'dist_out/std']),
         'critic': head('critic', 'critic', 'critic', ['dist_out/out']),
         'critic_target': head('critic_target', 'critic_target', 'critic',
                               ['dist_out/out'])}
@@ -246,6 +253,11 @@ class Learner:
     b['u_post'] = z(T, B, G)
     b['u_img'] = z(max(H, 1), N, G)
     b['eps'] = z(H + 1, N, A)
+    if self.discrete:
+      b['u_act'] = z(H + 1, N, 1)
+      b['alogit'] = z(self.M, A)      # normalised actor log-probs
+      b['dalogit'] = z(self.M, A)
+      b['ent_norm'] = z(self.M)
     # ---- encoder
     self.enc_act = []
     for cl in s.enc_convs:
@@ -756,7 +768,10 @@ class Learner:
     ops.philox(b['u_post'], T, B, G, self.Bg, r0, self.noise_seed, self.step_ctr, SITE_OBS_POST, 0)
     if H > 0:
       ops.philox(b['u_img'], H, N, G, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_IMG, 0)
-    ops.philox(b['eps'], H + 1, N, A, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_ACT, 1)
+    if self.discrete:
+      ops.philox(b['u_act'], H + 1, N, 1, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_ACT, 0)
+    else:
+      ops.philox(b['eps'], H + 1, N, A, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_ACT, 1)
 
   def phase_wm_fwd(self, use_carry=True, training=True):
     ops, b, cfg = self.ops, self.b, self.cfg
@@ -832,8 +847,13 @@ class Learner:
     la, oa = self.acts_im['actor']
     for t in range(H + 1):
       st = lambda buf, t_=t: buf.view(H + 1, N, -1)[t_]
-      om, os_ = self.head_fwd('actor', self.acts_im['actor'], traj[t][:, :F], st)
-      ops.normal_head_fwd(om, os_, b['eps'][t], traj[t][:, F:], lo, hi)
+      if self.discrete:
+        (xa,) = self.head_fwd('actor', self.acts_im['actor'], traj[t][:, :F], st)
+        ops.stats_fwd(xa, b['u_act'][t], st(b['alogit']), traj[t][:, F:], 1, A,
+                      float(ca['unimix']), 0)
+      else:
+        om, os_ = self.head_fwd('actor', self.acts_im['actor'], traj[t][:, :F], st)
+        ops.normal_head_fwd(om, os_, b['eps'][t], traj[t][:, F:], lo, hi)
       if t < H:
         si = lambda buf, t_=t: buf.view(H, N, -1)[t_]
         self.core_fwd(traj[t][:, D:], traj[t][:, :D], traj[t + 1][:, :D],
@@ -918,6 +938,51 @@ class Learner:
                          self.sc[0:1], c['decay'], c['max'], impl[c['impl']],
                          True, self.norm_os['adv'])
     ops.copy2d(self.norm_os['adv'].view(1, 2), self.sc[1:3].view(1, 2))
+    if self.discrete:
+      self._actor_reinforce(cnt)
+    else:
+      self._actor_backprop(cnt, rew, val, cont)
+    self.stat('actor_loss_score', b['i_actor_loss'][:HN])
+    self.stat('actor_loss_ent', b['i_ent_row'][:HN])
+    self.opt_step('actor', 'actor_opt')
+
+  def _actor_reinforce(self, cnt):
+    """actor_grad 'reinforce' (reference agent.py:357-358): -log pi(a) * sg(score)
+    plus the entropy regulariser (:372-377); no gradient through the rollout."""
+    ops, b, cfg = self.ops, self.b, self.cfg
+    N, H, M, A, F = self.N, self.H, self.M, self.A, self.F
+    HN = H * N
+    feat = b['traj'].view(M, F + A)[:, :F]
+    act = b['traj'].view(M, F + A)[:, F:]
+    ent_div = math.log(A) if cfg['actent_norm'] else 1.0
+    ops.onehot_entropy(b['alogit'], b['ent_norm'], ent_div)
+    k = self.stat('actent', b['ent_norm'][:HN])
+    self.allreduce(self.stat_sums[k])
+    self.stat_prereduced.add(k)
+    c = cfg['actent']
+    if c['impl'] == 'mult':
+      ops.autoadapt_update(self.actent_scale[0:1], self.stat_sums[k], cnt,
+                           c['target'], 0.1, c['vel'], c['min'], c['max'], True)
+    ops.onehot_policy_grad(b['alogit'], act, b['i_ret2'], b['i_value2'],
+                           b['i_weight'], self.sc, self.actent_scale[0:1],
+                           b['dalogit'], b['i_actor_loss'], b['i_ent_row'], HN,
+                           1.0 / cnt, ent_div)
+    oa = self.acts_im['actor'][1][0]
+    ops.stats_bwd(oa.z, b['dalogit'], None, oa.dout, 1, A,
+                  float(cfg['actor']['unimix']))
+    self.head_bwd('actor', self.acts_im['actor'], feat)
+
+  def _actor_backprop(self, cnt, rew, val, cont):
+    """actor_grad 'backprop' (reference agent.py:355-356, 361-371): gradient of
+    -score through the heads and the imagined world model down to the actions."""
+    ops, b, cfg = self.ops, self.b, self.cfg
+    N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
+    HN = H * N
+    traj, dtraj = b['traj'], b['dtraj']
+    feat = traj.view(M, F + A)[:, :F]
+    dfeat = dtraj.view(M, F + A)[:, :F]
+    ca = cfg['actor']
+    lo, hi = ca['minstd'], ca['maxstd']
     # entropy regulariser scale (AutoAdapt, inverse; reference agent.py:361-371)
     if cfg['actent_norm']:
       ent_lo, ent_div = math.log(lo), math.log(hi) - math.log(lo)
@@ -965,9 +1030,6 @@ class Learner:
                         self.actent_scale, oa[0].dout, oa[1].dout, b['i_ent_row'],
                         HN, lo, hi, 1.0 / (cnt * ent_div), ent_lo, ent_div)
     self.head_bwd('actor', self.acts_im['actor'], feat)
-    self.stat('actor_loss_score', b['i_actor_loss'][:HN])
-    self.stat('actor_loss_ent', b['i_ent_row'][:HN])
-    self.opt_step('actor', 'actor_opt')
 
   # ------------------------------------------------------------------ policy
 
@@ -991,10 +1053,16 @@ class Learner:
     t0 = b['traj'][0]
     ops.copy2d(b['post'], t0[:, :F])
     sel = lambda buf: buf.view(self.H + 1, self.N, -1)[0]
-    om, os_ = self.head_fwd('actor', self.acts_im['actor'], t0[:, :F], sel)
     ca = cfg['actor']
-    ops.normal_head_fwd(om, os_, b['eps'][0] if sample else None, t0[:, F:],
-                        ca['minstd'], ca['maxstd'])
+    if self.discrete:
+      ops.philox(b['u_act'][0], 1, B, 1, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 2, 0)
+      (xa,) = self.head_fwd('actor', self.acts_im['actor'], t0[:, :F], sel)
+      ops.stats_fwd(xa, b['u_act'][0], sel(b['alogit']), t0[:, F:], 1, A,
+                    float(ca['unimix']), 0 if sample else 1)
+    else:
+      om, os_ = self.head_fwd('actor', self.acts_im['actor'], t0[:, :F], sel)
+      ops.normal_head_fwd(om, os_, b['eps'][0] if sample else None, t0[:, F:],
+                          ca['minstd'], ca['maxstd'])
     ops.copy2d(b['post'], b['carry'])
     return t0[:, F:]
 
@@ -1036,7 +1104,7 @@ class Learner:
     N, H, w = self.N, self.H, self.world
     counts = dict(imag_value=(H + 1) * N * w)
     for k in ('critic_loss', 'imag_reward', 'imag_return', 'ret2', 'diff',
-              'actor_loss_score', 'actor_loss_ent'):
+              'actor_loss_score', 'actor_loss_ent', 'actent'):
       counts[k] = H * N * w
     st = {}
     for i, name in enumerate(self.stat_names):
@@ -1089,13 +1157,18 @@ class Learner:
     mets['extr_score_max'] = d['absmax'] * sc[0]
     mets['actor_loss'] = (st['actor_loss_score']['mean'] +
                           st['actor_loss_ent']['mean'])
-    asum = self.actent_sums.cpu().numpy()
     cnt = H * N * w
     A = self.A
-    emean = asum[:A].sum() / (cnt * A)
-    mets['actent_mean'] = emean
-    mets['actent_std'] = math.sqrt(max(asum[A:].sum() / (cnt * A) - emean ** 2, 0.0))
-    a = self.actent_scale.cpu().numpy()
+    if self.discrete:
+      mets['actent_mean'] = st['actent']['mean']
+      mets['actent_std'] = st['actent']['std']
+      a = self.actent_scale[0:1].cpu().numpy()
+    else:
+      asum = self.actent_sums.cpu().numpy()
+      emean = asum[:A].sum() / (cnt * A)
+      mets['actent_mean'] = emean
+      mets['actent_std'] = math.sqrt(max(asum[A:].sum() / (cnt * A) - emean ** 2, 0.0))
+      a = self.actent_scale.cpu().numpy()
     mets['actent_scale_mean'] = a.mean()
     mets['actent_scale_std'] = a.std()
     for k in ('model_loss', 'extr_critic_loss', 'actor_loss'):

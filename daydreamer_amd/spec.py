@@ -46,6 +46,7 @@ class ModelSpec:
   cfg: dict
   obs_shapes: dict
   act_dim: int
+  act_discrete: bool = False
   deter: int = 0
   units: int = 0
   groups: int = 0       # number of categorical latents
@@ -72,9 +73,11 @@ def _lin_limit(fan_in, fan_out, outscale=1.0):
   return float(np.sqrt(3.0 * outscale / np.mean([fan_in, fan_out])))
 
 
-def build_spec(cfg, obs_shapes, act_dim):
-  """cfg: nested plain dict; obs_shapes: name -> shape tuple."""
-  s = ModelSpec(cfg=cfg, obs_shapes=dict(obs_shapes), act_dim=act_dim)
+def build_spec(cfg, obs_shapes, act_dim, act_discrete=False):
+  """cfg: nested plain dict; obs_shapes: name -> shape tuple; act_discrete:
+  one-hot action space ('onehot' actor, reference nets.py:480-491)."""
+  s = ModelSpec(cfg=cfg, obs_shapes=dict(obs_shapes), act_dim=act_dim,
+                act_discrete=act_discrete)
   r = cfg['rssm']
   assert r['classes'], 'only the discrete latent is implemented'
   assert r['initial'] == 'learned2' and r['gru_layers'] == 1
@@ -200,7 +203,8 @@ def build_spec(cfg, obs_shapes, act_dim):
   c = cfg['actor']
   fan = trunk('actor', s.feat, c['layers'], c['units'], 'actor')
   dense_bias('actor/dist_out/out', fan, act_dim, 'actor', c['outscale'])
-  dense_bias('actor/dist_out/std', fan, act_dim, 'actor', 1.0)
+  if not act_discrete:  # the std layer exists only for 'normal' (nets.py:453-456)
+    dense_bias('actor/dist_out/std', fan, act_dim, 'actor', 1.0)
   c = cfg['critic']
   for group in ('critic', 'critic_target'):
     fan = trunk(group, s.feat, c['layers'], c['units'], group)

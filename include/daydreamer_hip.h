@@ -160,6 +160,16 @@ int dd_actor_seed(const float* ret, const float* base, const float* w, const flo
                   const float* sc, float* loss, float* dret, float* dbase, long n, float coef,
                   void* stream);
 int dd_sub(const float* a, const float* b, float* o, long n, void* stream);
+/* One-hot policy head (nets.py:480-491) trained by REINFORCE (agent.py:357-358):
+ * normalised entropy per row, and d loss / d logit of -logp(a)*sg(score) plus the
+ * entropy regulariser, with score = ((ret-base)*sc[0]-sc[1])*sc[2]. */
+int dd_onehot_entropy(const float* logit, long ldl, float* ent_out, int rows, int A,
+                      float ent_div, void* stream);
+int dd_onehot_policy_grad(const float* logit, long ldl, const float* action, long lda,
+                          const float* ret, const float* base, const float* w,
+                          const float* sc, const float* scale, float* dlogit, long lddl,
+                          float* loss_pg, float* loss_ent, int rows, int rows_grad,
+                          int A, float coef, float ent_div, void* stream);
 
 /* ---- learner state ------------------------------------------------------------- */
 

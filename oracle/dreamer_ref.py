@@ -439,12 +439,16 @@ class RefAgent:
   the Greedy behaviour with a V-function critic and a continuous 'normal'
   actor trained by backprop through the imagined rollout."""
 
-  def __init__(self, cfg, obs_shapes, act_dim, params, dtype=torch.float64):
+  def __init__(self, cfg, obs_shapes, act_dim, params, dtype=torch.float64,
+               act_discrete=False):
     """cfg: nested dict as in configs.yaml; obs_shapes: name->shape tuple of
-    the observation space (without batch dims); params: name->array."""
+    the observation space (without batch dims); params: name->array.
+    act_discrete: one-hot action space -> 'onehot' actor trained by REINFORCE
+    (actor_dist_disc / actor_grad_disc, agent.py:295-300)."""
     self.cfg = cfg
     self.dtype = dtype
     self.act_dim = act_dim
+    self.discrete = act_discrete
     self.p = {k: torch.tensor(np.asarray(v), dtype=dtype).requires_grad_(
         not k.startswith('critic_target/')) for k, v in params.items()}
     enc, dec = cfg['encoder'], cfg['decoder']
@@ -472,7 +476,9 @@ class RefAgent:
     self.advnorm = Normalize(**cfg['advnorm'])      # agent.py:301
     self.retnorm = Normalize(**cfg['retnorm'])      # agent.py:302-303
     self.scorenorm = Normalize(**cfg['scorenorm'])  # agent.py:304-305
-    self.actent = AutoAdapt((act_dim,), **cfg['actent'], inverse=True)
+    # agent.py:306-308: per-dimension scale for continuous, scalar for discrete
+    self.actent = AutoAdapt(() if act_discrete else (act_dim,), **cfg['actent'],
+                            inverse=True)
     self.slow_updates = -1  # agent.py:393
     self.last = {}
 
@@ -539,6 +545,13 @@ class RefAgent:
     x = mlp_trunk(self.p, 'actor', feat.reshape(-1, feat.shape[-1]),
                   c['layers'], c['act'], c['norm'])
     out = linear(self.p, 'actor/dist_out/out', x)
+    if self.discrete:  # nets.py:480-491 'onehot' with unimix
+      logit = out.reshape(lead + (self.act_dim,))
+      if c['unimix']:
+        probs = torch.softmax(logit, -1)
+        probs = (1 - c['unimix']) * probs + c['unimix'] / self.act_dim
+        logit = torch.log(probs)
+      return logit, None
     std = linear(self.p, 'actor/dist_out/std', x)
     lo, hi = c['minstd'], c['maxstd']
     mean = torch.tanh(out).reshape(lead + (self.act_dim,))
@@ -609,18 +622,23 @@ class RefAgent:
     """agent.py:234-261 with the policy of ImagActorCritic.train
     (agent.py:319-320): actor(sg(latent)).sample()."""
     sg = lambda s: {k: v.detach() for k, v in s.items()}
-    def policy(state, eps):
+    def policy(state, eps, t):
       mean, std = self.actor(feat_of(sg(state)))
+      if self.discrete:  # OneHotDist.sample (straight-through), tfutils.py:368-382
+        f = None if forced is None else forced['act'][t]
+        a, _ = onehot_straight_through(mean, noise['u_act'][t], f)
+        return a, (mean, mean)
       return mean + std * eps, (mean, std)
+    eps_all = noise.get('eps_act', [None] * (horizon + 1))
     states, actions, dists, idxs = [start], [], [], []
-    action, d = policy(start, noise['eps_act'][0])
+    action, d = policy(start, eps_all[0], 0)
     actions.append(action)
     dists.append(d)
     state = start
     for t in range(horizon):
       f = None if forced is None else forced['img'][t]
       state, idx = self.rssm.img_step(state, action, noise['u_img'][t], f)
-      action, d = policy(state, noise['eps_act'][t + 1])
+      action, d = policy(state, eps_all[t + 1], t + 1)
       states.append(state)
       actions.append(action)
       dists.append(d)
@@ -722,19 +740,30 @@ class RefAgent:
     metrics['extr_score_mag'] = score.abs().mean().detach()
     metrics['extr_score_max'] = score.abs().max().detach()
     score = self.advnorm(score * 1.0)
-    # ---- ImagActorCritic.loss, agent.py:351-381 ('backprop')
+    # ---- ImagActorCritic.loss, agent.py:351-381
     mean, std = self.actor(feat_of(
         {k: traj[k].detach() for k in ('deter', 'stoch')}))
-    loss = -score
-    ent = (0.5 * math.log(2 * math.pi * math.e) + torch.log(std))[:-1]
     ca = cfg['actor']
-    if cfg['actent_norm']:  # :364-367, minent/maxent nets.py:466-467
-      lo = 0.5 * math.log(2 * math.pi * math.e) + math.log(ca['minstd'])
-      hi = 0.5 * math.log(2 * math.pi * math.e) + math.log(ca['maxstd'])
-      ent = (ent - lo) / (hi - lo)
-    ent_loss, mets = self.actent(ent)
-    metrics.update({f'actent_{k}': v.detach() for k, v in mets.items()})
-    loss = loss + ent_loss.sum(-1)
+    if self.discrete:  # 'reinforce', agent.py:357-358; entropy :372-377
+      logp = (traj['action'].detach() * torch.log_softmax(mean, -1)).sum(-1)
+      loss = -logp[:-1] * score.detach()
+      ll = torch.log_softmax(mean, -1)
+      ent = -(torch.exp(ll) * ll).sum(-1)[:-1]
+      if cfg['actent_norm']:  # minent 0, maxent log(A), nets.py:489-490
+        ent = (ent - 0.0) / (math.log(self.act_dim) - 0.0)
+      ent_loss, mets = self.actent(ent)
+      metrics.update({f'actent_{k}': v.detach() for k, v in mets.items()})
+      loss = loss + ent_loss
+    else:  # 'backprop', agent.py:355-356; entropy :361-371
+      loss = -score
+      ent = (0.5 * math.log(2 * math.pi * math.e) + torch.log(std))[:-1]
+      if cfg['actent_norm']:  # :364-367, minent/maxent nets.py:466-467
+        lo = 0.5 * math.log(2 * math.pi * math.e) + math.log(ca['minstd'])
+        hi = 0.5 * math.log(2 * math.pi * math.e) + math.log(ca['maxstd'])
+        ent = (ent - lo) / (hi - lo)
+      ent_loss, mets = self.actent(ent)
+      metrics.update({f'actent_{k}': v.detach() for k, v in mets.items()})
+      loss = loss + ent_loss.sum(-1)
     loss = loss * traj['weight'].detach()[:-1]
     actor_loss = loss.mean()
     actor_names = [k for k in self.p if k.startswith('actor/')]
@@ -765,7 +794,13 @@ class RefAgent:
         latent, action, embed, obs['is_first'], up, u)
     latent = {k: v.detach() for k, v in latent.items()}
     mean, std = self.actor(feat_of(latent))
-    if mode == 'eval':
+    if self.discrete:
+      if mode == 'eval':
+        action = onehot_mode(mean)
+      else:
+        ua = torch.tensor(np.asarray(noise['u_act']), dtype=self.dtype)
+        action, _ = onehot_straight_through(mean, ua)
+    elif mode == 'eval':
       action = mean  # Normal.mode()
     else:
       eps = torch.tensor(np.asarray(noise['eps']), dtype=self.dtype)

@@ -393,6 +393,27 @@ class RefOps:
     dret.copy_(g.reshape(dret.shape))
     dbase.copy_((-g).reshape(dbase.shape))
 
+  def onehot_entropy(self, logit, ent_out, ent_div):
+    ll = torch.log_softmax(logit, -1)
+    ent_out.copy_(-(torch.exp(ll) * ll).sum(-1) / ent_div)
+
+  def onehot_policy_grad(self, logit, action, ret, base, w, sc, scale, dlogit,
+                         loss_pg, loss_ent, rows_grad, coef, ent_div):
+    n = rows_grad
+    ll = torch.log_softmax(logit[:n], -1)
+    p = torch.exp(ll)
+    h = -(p * ll).sum(-1, keepdim=True)
+    lp = (action[:n] * ll).sum(-1)
+    score = ((ret.reshape(-1)[:n] - base.reshape(-1)[:n]) * sc[0] - sc[1]) * sc[2]
+    wv = w.reshape(-1)[:n]
+    es = scale.reshape(-1)[0]
+    g = -score[:, None] * (action[:n] - p) + es * p * (ll + h) / ent_div
+    out = torch.zeros_like(logit)
+    out[:n] = coef * wv[:, None] * g
+    dlogit.copy_(out)
+    loss_pg[:n] = wv * (-lp * score)
+    loss_ent[:n] = wv * (es * -(h[:, 0] / ent_div))
+
   def sub(self, a, b, o):
     o.copy_((a.reshape(-1)[:o.numel()] - b.reshape(-1)[:o.numel()]
              ).reshape(o.shape))

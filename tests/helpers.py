@@ -17,11 +17,11 @@ def make_config(blocks=('a1_vision', 'debug'), **overrides):
 
 
 def make_problem(cfg, image=64, vector=5, action=3, batch=None, length=None,
-                 seed=0, terminals=0.1, smooth=True):
+                 seed=0, terminals=0.1, smooth=True, discrete=False):
   plain = config.to_plain(cfg)
   obs, act = synthetic.make_spaces(image, vector, action)
   shapes = {k: v.shape for k, v in obs.items()}
-  sp = spec.build_spec(plain, shapes, action)
+  sp = spec.build_spec(plain, shapes, action, discrete)
   params = spec.init_params(sp, seed)
   # non-trivial norm / bias parameters so their gradients are exercised
   rng = np.random.RandomState(seed + 1)
@@ -34,6 +34,9 @@ def make_problem(cfg, image=64, vector=5, action=3, batch=None, length=None,
   T = length or plain['replay_chunk']
   data = synthetic.make_batch(obs, act, B, T, seed=seed + 2,
                               terminals=terminals, smooth_images=smooth)
+  if discrete:  # one-hot actions as embodied.wrappers.OneHotAction delivers them
+    idx = np.random.RandomState(seed + 3).randint(0, action, (B, T))
+    data['action'] = np.eye(action, dtype=np.float32)[idx]
   return plain, sp, shapes, params, data, B, T
 
 
@@ -44,7 +47,11 @@ def forced_from_learner(L):
   post = b['post'].view(B, T, F)[:, :, D:].reshape(B, T, G, C)
   prior = b['prior_stoch'].view(B, T, G, C)
   img = b['traj'][1:, :, D:F].reshape(H, N, G, C)
+  extra = {}
+  if L.discrete:
+    extra['act'] = b['traj'][:, :, F:].argmax(-1).cpu()
   return dict(
+      **extra,
       obs_post=post.argmax(-1).permute(1, 0, 2).cpu(),
       obs_prior=prior.argmax(-1).permute(1, 0, 2).cpu(),
       img=img.argmax(-1).cpu())
@@ -52,7 +59,11 @@ def forced_from_learner(L):
 
 def noise_from_learner(L):
   b = L.b
+  extra = {}
+  if L.discrete:
+    extra['u_act'] = b['u_act'][..., 0].cpu().numpy()
   return dict(
+      **extra,
       u_obs_prior=b['u_prior'].permute(1, 0, 2).cpu().numpy(), u_obs_post=b['u_post'].cpu().numpy(),
       u_img=b['u_img'].cpu().numpy(), eps_act=b['eps'].cpu().numpy())
 

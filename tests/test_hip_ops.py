@@ -324,6 +324,23 @@ def test_critic_actor_seed(hip, ref):
     close(g, c, rtol=1e-5, what='actor_seed')
 
 
+def test_onehot_policy(hip, ref):
+  rows, A, n = 300, 6, 200
+  logit = torch.log_softmax(rnd(rows, A, seed=1), -1)
+  act = torch.nn.functional.one_hot(torch.randint(0, A, (rows,), generator=torch.Generator().manual_seed(2)), A).float()
+  wide = torch.zeros(rows, A + 10); wide[:, 3:3 + A] = act
+  ret, base, w = rnd(n, seed=3), rnd(rows, seed=4), torch.rand(rows)
+  sc, scale = torch.tensor([1.2, 0.1, 0.8]), torch.tensor([0.3])
+  ent, dl, lpg, lent = torch.zeros(rows), torch.zeros(rows, A), torch.zeros(n), torch.zeros(n)
+  ed = float(np.log(A))
+  def fn(ops, logit, wide, ret, base, w, sc, scale, ent, dl, lpg, lent):
+    ops.onehot_entropy(logit, ent, ed)
+    ops.onehot_policy_grad(logit, wide[:, 3:3 + A], ret, base, w, sc, scale, dl, lpg, lent, n, 0.01, ed)
+  res = both(hip, ref, fn, [logit, wide, ret, base, w, sc, scale, ent, dl, lpg, lent], [7, 8, 9, 10])
+  for (g, c), nm in zip(res, ['ent', 'dlogit', 'loss_pg', 'loss_ent']):
+    close(g, c, rtol=2e-5, what=f'onehot {nm}')
+
+
 def test_philox(hip, ref):
   step = torch.tensor([12345], dtype=torch.int64)
   for kind, cols in ((0, 32), (1, 16), (0, 7), (1, 6)):

@@ -18,7 +18,8 @@ def run_pair(cfg, steps=2, **kw):
   ops = ref_ops.RefOps('cpu')
   L = learner_mod.Learner(sp, ops, 'cpu', B, T, params=params, noise_seed=7,
                           dtype=torch.float64)
-  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64)
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64,
+                            act_discrete=sp.act_discrete)
   state = None
   out = []
   for i in range(steps):
@@ -64,6 +65,15 @@ def test_learner_matches_oracle_proprio():
   cfg = helpers.make_config(('a1', 'debug'), batch_size=4, replay_chunk=6,
                             imag_horizon=3)
   run_pair(cfg, steps=2, image=0, vector=7, action=6, terminals=0.1)
+
+
+def test_learner_matches_oracle_discrete():
+  """xarm / ur5 style: one-hot action space -> 'onehot' actor with REINFORCE."""
+  cfg = helpers.make_config(('xarm', 'debug'), batch_size=3, replay_chunk=5,
+                            imag_horizon=4)
+  cfg = cfg.update({'encoder.mlp_keys': 'vector', 'decoder.mlp_keys': 'vector',
+                    'encoder.cnn_keys': 'image', 'decoder.cnn_keys': 'image'})
+  run_pair(cfg, steps=2, image=64, vector=5, action=6, terminals=0.15, discrete=True)
 
 
 def test_weight_decay_and_is_first_midsequence():

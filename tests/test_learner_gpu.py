@@ -25,7 +25,8 @@ def run(hip, cfg, steps, gtol=2e-3, **kw):
   dreamer_ref.SAMPLE_TOL[0] = 1e-3  # fp32 device logits vs fp64 oracle logits
   plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, **kw)
   L = learner_mod.Learner(sp, hip, 'cuda:0', B, T, params=params, noise_seed=3)
-  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64)
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64,
+                            act_discrete=sp.act_discrete)
   state = None
   for i in range(steps):
     L.upload(data)
@@ -65,6 +66,15 @@ def test_e2e_vision_small_units(hip):
   """a1_vision geometry (64x64 image, 32x32 latent, A=16) with a short batch."""
   cfg = helpers.make_config(('a1_vision',), batch_size=4, replay_chunk=5, imag_horizon=3)
   run(hip, cfg, 1, image=64, vector=16, action=16, terminals=0.0)
+
+
+def test_e2e_xarm_discrete(hip):
+  """BASELINE configs[2] family: xarm block (deter 512), 64x64 image + proprio,
+  one-hot 6-way action -> 'onehot' actor trained by REINFORCE."""
+  cfg = helpers.make_config(('xarm',), batch_size=4, replay_chunk=5, imag_horizon=3)
+  cfg = cfg.update({'encoder.mlp_keys': 'vector', 'decoder.mlp_keys': 'vector',
+                    'encoder.cnn_keys': 'image', 'decoder.cnn_keys': 'image'})
+  run(hip, cfg, 2, image=64, vector=20, action=6, terminals=0.05, discrete=True)
 
 
 def test_e2e_scaled_latent(hip):
