@@ -12,16 +12,20 @@
 
 namespace {
 
-// loss[row] = sum_p (sigmoid(z) - x/255)^2 ; dz = coef * 2 (s - x) s (1 - s)
+// loss[row] = sum over pixels and channels [c0,c1) of (sigmoid(z) - x/255)^2 ;
+// dz = coef * 2 (s - x) s (1 - s) on those channels (others untouched).
 __global__ void __launch_bounds__(256)
 k_image_loss(const float* __restrict__ z, const unsigned char* __restrict__ img,
-             float* __restrict__ loss, float* __restrict__ dz, long P, float coef) {
+             float* __restrict__ loss, float* __restrict__ dz, long P, int ctot, int c0, int c1,
+             float coef) {
   const long row = blockIdx.x;
   const float* zr = z + row * P;
   const unsigned char* ir = img + row * P;
   float* dr = dz + row * P;
   float acc = 0.f;
+  const bool all = (c0 == 0 && c1 == ctot);
   for (long p = threadIdx.x; p < P; p += 256) {
+    if (!all) { int c = (int)(p % ctot); if (c < c0 || c >= c1) continue; }
     float s = sigmoidf_(zr[p]);
     float d = s - (float)ir[p] * (1.f / 255.f);
     acc += d * d;
@@ -313,9 +317,9 @@ inline int nblk(long n, int t = 256) { return (int)((n + t - 1) / t); }
 }  // namespace
 
 extern "C" int dd_image_loss(const float* z, const unsigned char* img, float* loss, float* dz,
-                             int rows, long P, float coef, void* stream) {
+                             int rows, long P, int ctot, int c0, int c1, float coef, void* stream) {
   if (rows <= 0) return 0;
-  k_image_loss<<<rows, 256, 0, (hipStream_t)stream>>>(z, img, loss, dz, P, coef);
+  k_image_loss<<<rows, 256, 0, (hipStream_t)stream>>>(z, img, loss, dz, P, ctot, c0, c1, coef);
   DD_CHECK_LAUNCH("dd_image_loss");
   return 0;
 }

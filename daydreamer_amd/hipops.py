@@ -42,7 +42,7 @@ _SIGS = {
     'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
     'dd_cat_kl_fwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     'dd_cat_kl_bwd': [c_p, c_l, c_p, c_l, c_p, c_f, c_f, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
-    'dd_image_loss': [c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_p],
+    'dd_image_loss': [c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_i, c_f, c_p],
     'dd_mse_loss': [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     'dd_scalar_loss': [c_p, c_p, c_p, c_p, c_l, c_f, c_i, c_p],
     'dd_normal_head_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_f, c_p],
@@ -301,13 +301,15 @@ class HipOps:
 
   # ---- losses / imagination scalars -------------------------------------------
 
-  def image_loss(self, z, img, loss, dz, coef):
+  def image_loss(self, z, img, loss, dz, coef, c0=0, c1=None):
     rows = z.shape[0]
     P = z[0].numel()
+    ctot = z.shape[-1]
+    c1 = ctot if c1 is None else c1
     assert z.is_contiguous() and img.is_contiguous() and img.dtype == torch.uint8
     self._check(self.lib.dd_image_loss(
         z.data_ptr(), img.data_ptr(), loss.data_ptr(), dz.data_ptr(), rows, P,
-        coef, self.stream), 'dd_image_loss')
+        ctot, c0, c1, coef, self.stream), 'dd_image_loss')
 
   def mse_loss(self, pred, tgt, loss, dpred, coef):
     rows, D = pred.shape

@@ -123,8 +123,10 @@ class Learner:
     self.D, self.U, self.S, self.A = s.deter, s.units, s.stoch, s.act_dim
     self.G, self.C, self.F = s.groups, s.classes, s.feat
     self.unimix = float(cfg['rssm']['unimix'])
-    assert len(s.dec_cnn_keys) <= 1 and len(s.enc_cnn_keys) <= 1, \
-        'multiple image keys are not implemented yet'
+    # several image keys (e.g. image|depth) are concatenated on the channel axis
+    # (reference nets.py:220, 274); encoder and decoder must agree on the set
+    assert not s.dec_convs or list(s.dec_cnn_keys) == list(s.enc_cnn_keys), \
+        (list(s.dec_cnn_keys), s.enc_cnn_keys)
     self.discrete = bool(s.act_discrete)
     assert cfg['critic_type'] == 'vfunction'
     if self.discrete:
@@ -318,7 +320,7 @@ class Learner:
         d.update(out=z(*shp), stats=z(N * cl.h_big * cl.h_big, 2), dout=z(*shp))
       self.dec_act.append(d)
     if s.dec_convs:
-      b['loss_image'] = z(N)
+      b['loss_image'] = {k: z(N) for k in s.dec_cnn_keys}
       c0 = s.dec_convs[0]
       b['bias_tiled'] = z(c0.k * c0.k * c0.c_big)
       b['dbias_tiled'] = z(c0.k * c0.k * c0.c_big)
@@ -513,9 +515,12 @@ class Learner:
                          a['stats'], True)
           x = a['out']
       last = self.dec_act[-1]
-      scale = self.cfg['loss_scales'].get(list(s.dec_cnn_keys)[0], 1.0)
-      ops.image_loss(last['z'], b['image'], b['loss_image'], last['dz'],
-                     scale / self.Ng)
+      c0 = 0
+      for key, shp in s.dec_cnn_keys.items():
+        scale = self.cfg['loss_scales'].get(key, 1.0)
+        ops.image_loss(last['z'], b['image'], b['loss_image'][key], last['dz'],
+                       scale / self.Ng, c0, c0 + shp[2])
+        c0 += shp[2]
     if s.dec_mlp_keys:
       outs = self.head_fwd('dec_mlp', self.acts_wm['dec_mlp'], feat)
       for (k, v), o, A in zip(s.dec_mlp_keys.items(), outs,
@@ -743,7 +748,8 @@ class Learner:
         t = t.to(dtype)
       dst.copy_(t.reshape(dst.shape).to(dev, non_blocking=True))
     if s.enc_cnn_keys:
-      put(b['image'], data[s.enc_cnn_keys[0]])
+      imgs = [np.asarray(data[k]) for k in s.enc_cnn_keys]
+      put(b['image'], imgs[0] if len(imgs) == 1 else np.concatenate(imgs, -1))
     if s.enc_mlp_keys:
       cols = []
       for k in s.enc_mlp_keys:
@@ -804,8 +810,8 @@ class Learner:
     self.stat('prior_ent', b['ent_prior'])
     self.stat('reward_loss', b['loss_reward'])
     self.stat('cont_loss', b['loss_cont'])
-    if self.spec.dec_convs:
-      self.stat('image_loss', b['loss_image'])
+    for kk in (self.spec.dec_cnn_keys if self.spec.dec_convs else ()):
+      self.stat(f'{kk}_loss', b['loss_image'][kk])
     for kk in self.spec.dec_mlp_keys:
       self.stat(f'{kk}_loss', b['loss_vec'][kk])
 

@@ -124,9 +124,11 @@ int dd_cat_kl_bwd(const float* post, long ldp, const float* prior, long ldq,
 
 /* ---- losses and imagination scalars --------------------------------------------- */
 
-/* sigmoid + MSEDist(sum) against u8 image/255: nets.py:325, tfutils.py:320-329. */
+/* sigmoid + MSEDist(sum) against u8 image/255: nets.py:325, tfutils.py:320-329.
+ * Channels [c0,c1) of ctot: one call per image key of the channel-concatenated
+ * decoder output (nets.py:274-277). */
 int dd_image_loss(const float* z, const unsigned char* img, float* loss, float* dz,
-                  int rows, long P, float coef, void* stream);
+                  int rows, long P, int ctot, int c0, int c1, float coef, void* stream);
 int dd_mse_loss(const float* pred, long ldp, const float* tgt, long ldt, float* loss,
                 float* dpred, long lddp, int rows, int D, float coef, void* stream);
 /* kind 0 SymlogDist tfutils.py:347-356; kind 1 Bernoulli(logits) nets.py:469-471 */

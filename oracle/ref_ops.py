@@ -280,12 +280,14 @@ class RefOps:
 
   # ---- losses / imagination scalars ---------------------------------------------
 
-  def image_loss(self, z, img, loss, dz, coef):
+  def image_loss(self, z, img, loss, dz, coef, c0=0, c1=None):
+    c1 = z.shape[-1] if c1 is None else c1
+    zz = z[..., c0:c1]
     rows = z.shape[0]
-    s = torch.sigmoid(z.reshape(rows, -1))
-    d = s - img.reshape(rows, -1).to(z.dtype) * torch.tensor(1.0 / 255.0, dtype=z.dtype)
-    loss.copy_((d * d).sum(-1))
-    dz.copy_((coef * 2 * d * s * (1 - s)).reshape(dz.shape))
+    s = torch.sigmoid(zz)
+    d = s - img[..., c0:c1].to(z.dtype) * torch.tensor(1.0 / 255.0, dtype=z.dtype)
+    loss.copy_((d * d).reshape(rows, -1).sum(-1))
+    dz[..., c0:c1] = coef * 2 * d * s * (1 - s)
 
   def mse_loss(self, pred, tgt, loss, dpred, coef):
     e = pred - tgt

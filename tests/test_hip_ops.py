@@ -256,6 +256,10 @@ def test_losses(hip, ref):
              [z, img, loss, dz], [2, 3])
   for g, c in res:
     close(g, c, rtol=1e-5, what='image_loss')
+  res = both(hip, ref, lambda ops, z, img, loss, dz: ops.image_loss(z, img, loss, dz, 0.01, 1, 3),
+             [z, img, loss, dz], [2, 3])
+  for g, c in res:
+    close(g, c, rtol=1e-5, what='image_loss channel range')
   pred, tgt, dp = rnd(rows, 19, seed=3), rnd(rows, 19, seed=4), torch.zeros(rows, 19)
   res = both(hip, ref, lambda ops, pred, tgt, loss, dp: ops.mse_loss(pred, tgt, loss, dp, 0.3),
              [pred, tgt, loss, dp], [2, 3])

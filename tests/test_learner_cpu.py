@@ -76,6 +76,38 @@ def test_learner_matches_oracle_discrete():
   run_pair(cfg, steps=2, image=64, vector=5, action=6, terminals=0.15, discrete=True)
 
 
+def test_learner_matches_oracle_image_and_depth():
+  """xarm observation layout: image (3 ch) + depth (1 ch) concatenated on the
+  channel axis in encoder and decoder, separate per-key losses."""
+  import numpy as np
+  from daydreamer_amd import config, spec, synthetic
+  cfg = helpers.make_config(('xarm', 'debug'), batch_size=2, replay_chunk=4,
+                            imag_horizon=2)
+  cfg = cfg.update({'encoder.mlp_keys': 'vector', 'decoder.mlp_keys': 'vector'})
+  plain = config.to_plain(cfg)
+  obs, act = synthetic.make_spaces(64, 5, 6)
+  obs = {'image': obs['image'], 'depth': synthetic.Space(np.uint8, (64, 64, 1)),
+         **{k: v for k, v in obs.items() if k != 'image'}}
+  shapes = {k: v.shape for k, v in obs.items()}
+  sp = spec.build_spec(plain, shapes, 6, True)
+  params = spec.init_params(sp, 0)
+  data = synthetic.make_batch(obs, act, 2, 4, seed=3, smooth_images=False)
+  data['action'] = np.eye(6, dtype=np.float32)[np.random.RandomState(0).randint(0, 6, (2, 4))]
+  L = learner_mod.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', 2, 4, params=params,
+                          dtype=torch.float64)
+  ag = dreamer_ref.RefAgent(plain, shapes, 6, params, torch.float64, act_discrete=True)
+  L.upload(data)
+  L.train_step_device(use_carry=False)
+  mets = L.read_metrics()
+  _, _, omets = ag.train(data, helpers.noise_from_learner(L), None,
+                         helpers.forced_from_learner(L))
+  for k in ('image_loss_mean', 'depth_loss_mean', 'model_loss', 'actor_loss'):
+    assert abs(float(mets[k]) - float(omets[k])) <= 2e-6 * max(1, abs(float(omets[k]))), k
+  grads = L.export_grads()
+  for name, g in ag.last['grads'].items():
+    assert helpers.rel_err(grads[name], g.numpy()) < 1e-6, name
+
+
 def test_weight_decay_and_is_first_midsequence():
   cfg = helpers.make_config(('a1', 'debug'), batch_size=3, replay_chunk=6,
                             imag_horizon=2)
