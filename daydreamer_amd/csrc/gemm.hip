@@ -226,7 +226,11 @@ struct EpiConvUp {
 // Main loop.
 // ---------------------------------------------------------------------------
 
-template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int BK = (BM >= 128 && BN >= 128) ? BKBIG : 16>
+// ST = global->register prefetch distance in k-tiles.  Few-tile problems (64x64 tiles,
+// about one workgroup per CU) are latency-bound on the global loads of the next k-tile;
+// keeping ST tiles in flight in registers hides that without needing more workgroups.
+template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int BK = 16,
+          int ST = (BM == 64 && BN == 64) ? 4 : 1>
 __global__ void __launch_bounds__(256, 2)
 k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   // row pitch of the k-major LDS tiles: +1 spreads the scalar transposing stores of a
@@ -253,9 +257,9 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float ra[NA][4], rb[NB][4];
+  float ra_[ST][NA][4], rb_[ST][NB][4];
 
-  auto gload = [&](int k0) {
+  auto gload = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4]) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int id = tid + i * 256;
@@ -269,7 +273,7 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       else     bl.load4(n0 + (id % (BN / 4)) * 4, k0 + id / (BN / 4), ke, rb[i]);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int id = tid + i * 256;
@@ -299,36 +303,44 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   };
 
   const int nk = (ke - kb + BK - 1) / BK;
-  if (nk > 0) {
-    gload(kb);
-    sstore(0);
-  }
+  // prologue: tiles 0..ST-1 in flight, tile 0 staged into LDS
+#pragma unroll
+  for (int s = 0; s < ST; ++s)
+    if (s < nk) gload(kb + s * BK, ra_[s], rb_[s]);
+  if (nk > 0) sstore(0, ra_[0], rb_[0]);
   __syncthreads();
   const int lk = lane >> 5, lr = lane & 31;
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
+  for (int t0 = 0; t0 < nk; t0 += ST) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      const int t = t0 + s;
+      if (t < nk) {
+        const int buf = t & 1;
 #ifndef EXP_NOLOAD  // ablation switches (tools/gemm_exp.py), see DESIGN.md section 5
-    if (t + 1 < nk) gload(kb + (t + 1) * BK);
+        // register slot s held tile t (already in LDS): refill it with tile t + ST
+        if (t + ST < nk) gload(kb + (t + ST) * BK, ra_[s], rb_[s]);
 #endif
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float af[TM], bf[TN];
+        for (int kk = 0; kk < BK; kk += 2) {
+          float af[TM], bf[TN];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = As[buf][(kk + lk) * PA + wm0 + a * 32 + lr];
+          for (int a = 0; a < TM; ++a) af[a] = As[buf][(kk + lk) * PA + wm0 + a * 32 + lr];
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bf[b] = Bs[buf][(kk + lk) * PB + wn0 + b * 32 + lr];
+          for (int b = 0; b < TN; ++b) bf[b] = Bs[buf][(kk + lk) * PB + wn0 + b * 32 + lr];
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+          for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-    }
+            for (int b = 0; b < TN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
 #ifndef EXP_NOSTORE
-    if (t + 1 < nk) sstore(buf ^ 1);
+        if (t + 1 < nk) sstore(buf ^ 1, ra_[(s + 1) % ST], rb_[(s + 1) % ST]);
 #endif
 #ifndef EXP_NOBARRIER
-    __syncthreads();
+        __syncthreads();
 #endif
+      }
+    }
   }
 #pragma unroll
   for (int a = 0; a < TM; ++a)
