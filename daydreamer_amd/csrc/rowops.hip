@@ -401,13 +401,15 @@ k_gru_bwd(const float* __restrict__ dhn, long lddn, const float* __restrict__ z3
           const float* __restrict__ stats, long lds, const float* __restrict__ gamma,
           const float* __restrict__ beta, const float* __restrict__ h, long ldh,
           float* __restrict__ dz3, long lddz, float* __restrict__ dh, long lddh,
-          float* __restrict__ dy3, long lddy, int rows, int D) {
+          float* __restrict__ dy3, long lddy, float* __restrict__ zx, long ldzx, int U,
+          int rows, int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = 3 * D;
   for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
     const float* zr = z3 + row * ldz;
     const float mean = stats[row * lds], rstd = stats[row * lds + 1];
     float* dyr = dy3 + row * lddy;
+    if (zx) for (int j = lane; j < U; j += 64) zx[row * ldzx + j] = 0.f;
     float s1 = 0.f, s2 = 0.f;
     for (int j = lane; j < D; j += 64) {
       float xr = (zr[j] - mean) * rstd, xc = (zr[D + j] - mean) * rstd,
@@ -605,10 +607,10 @@ extern "C" int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, lon
                                const float* stats, long lds, const float* gamma, const float* beta,
                                const float* h, long ldh, float* dz3, long lddz,
                                float* dh, long lddh, float* dy3, long lddy,
-                               int rows, int D, void* stream) {
+                               float* zx, long ldzx, int U, int rows, int D, void* stream) {
   if (rows <= 0) return 0;
   k_gru_bwd<<<row_blocks(rows, 1 << 20), 256, 0, (hipStream_t)stream>>>(
-      dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, rows, D);
+      dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows, D);
   DD_CHECK_LAUNCH("dd_gru_cell_bwd");
   return 0;
 }

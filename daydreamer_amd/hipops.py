@@ -37,7 +37,7 @@ _SIGS = {
     'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_col_sum': [c_p, c_l, c_p, c_f, c_l, c_i, c_p, c_z, c_p],
     'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
-    'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
     'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
     'dd_cat_kl_fwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -245,7 +245,7 @@ class HipOps:
         zp, ldz, gamma.data_ptr(), beta.data_ptr(), hp, ldh, np_, ldn,
         *_mat(stats), rows, D, self.stream), 'dd_gru_cell_fwd')
 
-  def gru_bwd(self, dhn, z3, stats, gamma, beta, h, dz3, dh, dy3):
+  def gru_bwd(self, dhn, z3, stats, gamma, beta, h, dz3, dh, dy3, zero=None):
     rows, D = h.shape
     a, lda = _mat(dhn)
     zp, ldz = _mat(z3)
@@ -253,9 +253,12 @@ class HipOps:
     dzp, lddz = _mat(dz3)
     dhp, lddh = _mat(dh)
     dyp, lddy = _mat(dy3)
+    zxp, ldzx = _mat(zero) if zero is not None else (0, 0)
+    U = zero.shape[1] if zero is not None else 0
     self._check(self.lib.dd_gru_cell_bwd(
         a, lda, zp, ldz, *_mat(stats), gamma.data_ptr(), beta.data_ptr(),
-        hp, ldh, dzp, lddz, dhp, lddh, dyp, lddy, rows, D, self.stream),
+        hp, ldh, dzp, lddz, dhp, lddh, dyp, lddy, zxp, ldzx, U, rows, D,
+        self.stream),
         'dd_gru_cell_bwd')
 
   # ---- categorical latent -----------------------------------------------------

@@ -91,15 +91,17 @@ class Lin:
 class Act:
   """Activations (and their gradients) of one Lin in one row space."""
 
-  def __init__(self, L, rows, units, norm, grads=True):
+  def __init__(self, L, rows, units, norm, grads=True, out=None, dout=None):
+    """out / dout may be column slices of a wider buffer (concat-free inputs
+    of the next layer)."""
     self.z = L.zeros(rows, units)
     if norm:
-      self.out = L.zeros(rows, units)
+      self.out = out if out is not None else L.zeros(rows, units)
       self.stats = L.zeros(rows, 2)
       if grads:
         self.dz = L.zeros(rows, units)
     if grads:
-      self.dout = L.zeros(rows, units)
+      self.dout = dout if dout is not None else L.zeros(rows, units)
 
 
 class Learner:
@@ -186,6 +188,7 @@ class Learner:
       P[f'enc/mlp/dense{i}'] = Lin(m, f'enc/mlp/dense{i}', True)
     P['img_in'] = Lin(m, 'rssm/img_in', True)
     P['img_in_s'] = Lin(m, 'rssm/img_in', True, rows=(0, S))
+    P['gru'] = Lin(m, 'rssm/gru_out', True)
     P['gru_h'] = Lin(m, 'rssm/gru_out', True, rows=(0, D))
     P['gru_x'] = Lin(m, 'rssm/gru_out', True, rows=(D, D + self.U))
     self.n_prior = cfg['rssm']['prior_layers']
@@ -274,14 +277,18 @@ class Learner:
                                        if s.enc_mlp_keys else 0)]
     # ---- observe scan (batch-major [B,T,...] buffers)
     b['post'] = z(N, F)            # [deter | stoch] of the posterior
-    b['hprev'] = z(N, D)
+    # GRU input [deter_prev | img_in output] and its gradient as one buffer each:
+    # the cell's matmul is a single K = D+U GEMM in both directions
+    b['gin'] = z(N, D + U)
+    b['dgin'] = z(N, D + U)
+    b['hprev'] = b['gin'][:, :D]
     b['xin'] = z(N, S + A)
-    self.a_img_in = Act(self, N, U, True)
+    self.a_img_in = Act(self, N, U, True, out=b['gin'][:, D:], dout=b['dgin'][:, D:])
     b['z3'] = z(N, 3 * D)
     b['gstats'] = z(N, 2)
     b['dz3'] = z(N, 3 * D)
     b['dy3'] = z(N, 3 * D)
-    b['dhprev'] = z(N, D)
+    b['dhprev'] = b['dgin'][:, :D]
     b['dxin_s'] = z(N, S)
     self.a_img_out = [Act(self, N, U, True) for _ in range(self.n_prior)]
     self.a_img_stats = Act(self, N, S, False)
@@ -584,14 +591,17 @@ class Learner:
     ops.stats_fwd(xs, None, b['init_logit'], b['init_stoch'], self.G, self.C,
                   self.unimix, 1)
 
-  def core_fwd(self, xin, hprev, hn, A_in, z3, gstats, sel):
+  def core_fwd(self, xin, hprev, hn, A_in, z3, gstats, sel, gin=None):
     """RSSM.img_step up to the new deter (reference nets.py:119-130):
     img_in Linear+LN+ELU, then the GRU cell.  xin [rows,S+A], hprev [rows,D]."""
     ops = self.ops
     x1 = self.lin_fwd(self.P['img_in'], A_in, xin, sel)
     z3v = sel(z3)
-    ops.gemm(hprev, self.P['gru_h'].W, z3v)
-    ops.gemm(x1, self.P['gru_x'].W, z3v, beta=1.0)
+    if gin is not None:  # hprev and x1 are adjacent column blocks of gin
+      ops.gemm(sel(gin), self.P['gru'].W, z3v)
+    else:
+      ops.gemm(hprev, self.P['gru_h'].W, z3v)
+      ops.gemm(x1, self.P['gru_x'].W, z3v, beta=1.0)
     g = self.P['gru_h']
     ops.gru_fwd(z3v, g.gamma, g.beta, hprev, hn, sel(gstats))
 
@@ -617,16 +627,21 @@ class Learner:
                    1.0 if i == 0 else 0.0, params)
 
   def core_bwd(self, dhn_total, hprev, A_in, z3, gstats, sel, dz3, dy3,
-               dh_direct, dxin, dxin_beta, dxin_P):
+               dh_direct, dxin, dxin_beta, dxin_P, dgin=None):
     """Data-gradient backward of core_fwd.  dhn_total [rows,D] is the gradient
     w.r.t. the new deter.  Outputs: dz3, dy3 (GRU), dh_direct = (1-update)*dhn
     + dz3 @ Wg_h^T, and dxin (+)= dz_in @ W_in^T restricted to dxin_P's rows."""
     ops = self.ops
     g = self.P['gru_h']
-    ops.gru_bwd(dhn_total, sel(z3), sel(gstats), g.gamma, g.beta, hprev, dz3,
-                dh_direct, dy3)
-    ops.gemm(dz3, self.P['gru_h'].W, dh_direct, tb=True, beta=1.0)
-    ops.gemm(dz3, self.P['gru_x'].W, sel(A_in.dout), tb=True)
+    if dgin is not None:  # [dh | dx1] in one buffer, one GEMM
+      ops.gru_bwd(dhn_total, sel(z3), sel(gstats), g.gamma, g.beta, hprev, dz3,
+                  dh_direct, dy3, zero=sel(A_in.dout))
+      ops.gemm(dz3, self.P['gru'].W, sel(dgin), tb=True, beta=1.0)
+    else:
+      ops.gru_bwd(dhn_total, sel(z3), sel(gstats), g.gamma, g.beta, hprev, dz3,
+                  dh_direct, dy3)
+      ops.gemm(dz3, self.P['gru_h'].W, dh_direct, tb=True, beta=1.0)
+      ops.gemm(dz3, self.P['gru_x'].W, sel(A_in.dout), tb=True)
     self.lin_bwd(self.P['img_in'], A_in, None, sel, None, params=False)
     ops.gemm(sel(A_in.dz), dxin_P.W, dxin, tb=True, beta=dxin_beta)
 
@@ -656,7 +671,7 @@ class Learner:
       ops.reset_mask(pd, first[:, t], b['init_deter'], hprev)
       ops.reset_mask(ps, first[:, t], b['init_stoch'], xin[:, :S])
       self.core_fwd(xin, hprev, post[:, t, :D], self.a_img_in, b['z3'],
-                    b['gstats'], sel)
+                    b['gstats'], sel, gin=b['gin'])
       # posterior: obs_out on concat[deter, embed]; embed part already in z
       Ao = self.a_obs_out
       ops.gemm(post[:, t, :D], self.P['obs_out_h'].W, sel(Ao.z), beta=1.0)
@@ -701,7 +716,8 @@ class Learner:
       ops.gemm(sel(Ao.dz), Po.W, ddeter, tb=True, beta=1.0)
       self.core_bwd(ddeter, sel(b['hprev']), self.a_img_in, b['z3'],
                     b['gstats'], sel, sel(b['dz3']), sel(b['dy3']),
-                    sel(b['dhprev']), sel(b['dxin_s']), 0.0, P['img_in_s'])
+                    sel(b['dhprev']), sel(b['dxin_s']), 0.0, P['img_in_s'],
+                    dgin=b['dgin'])
       if t > 0:
         ops.reset_mask_bwd(sel(b['dhprev']), first[:, t], dfeat[:, t - 1, :D])
         ops.reset_mask_bwd(sel(b['dxin_s']), first[:, t], dfeat[:, t - 1, D:])
@@ -714,8 +730,7 @@ class Learner:
     ops.col_sum(Aq.dout, P['obs_stats'].dbias)
     ops.gemm(b['post'][:, :D], Ao.dz, P['obs_out_h'].dW, ta=True)
     lnp(P['obs_out_h'], Ao)
-    ops.gemm(b['hprev'], b['dz3'], P['gru_h'].dW, ta=True)
-    ops.gemm(self.a_img_in.out, b['dz3'], P['gru_x'].dW, ta=True)
+    ops.gemm(b['gin'], b['dz3'], P['gru'].dW, ta=True)
     g = P['gru_h']
     ops.ln_param_grad(b['dy3'], b['z3'], None, b['gstats'], g.dgamma, g.dbeta,
                       False, False)

@@ -90,12 +90,14 @@ int dd_col_sum(const float* x, long ldx, float* out, float beta, long rows, int 
 int dd_gru_cell_fwd(const float* z3, long ldz, const float* gamma, const float* beta,
                     const float* h, long ldh, float* hn, long ldn, float* stats, long lds,
                     int rows, int D, void* stream);
-/* dz3 (through LN), dh = (1-update)*dhn, dy3 = gradient at the LN output. */
+/* dz3 (through LN), dh = (1-update)*dhn, dy3 = gradient at the LN output.
+ * zx (NULL ok): a [rows,U] region to zero-fill, so that one beta=1 GEMM can
+ * then accumulate dz3 @ W^T into the adjacent [dh | dx] buffer. */
 int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
                     const float* stats, long lds, const float* gamma, const float* beta,
                     const float* h, long ldh, float* dz3, long lddz,
                     float* dh, long lddh, float* dy3, long lddy,
-                    int rows, int D, void* stream);
+                    float* zx, long ldzx, int U, int rows, int D, void* stream);
 
 /* ---- categorical latent ------------------------------------------------------ */
 

@@ -183,7 +183,7 @@ class RefOps:
     stats[:, 0] = mean[:, 0]
     stats[:, 1] = rstd[:, 0]
 
-  def gru_bwd(self, dhn, z3, stats, gamma, beta, h, dz3, dh, dy3):
+  def gru_bwd(self, dhn, z3, stats, gamma, beta, h, dz3, dh, dy3, zero=None):
     D = h.shape[1]
     mean, rstd = stats[:, :1], stats[:, 1:2]
     xh = (z3 - mean) * rstd
@@ -202,6 +202,8 @@ class RefOps:
     s2 = (g * xh).mean(-1, keepdim=True)
     res = rstd * (g - s1 - xh * s2)
     dh.copy_(dhv)
+    if zero is not None:
+      zero.zero_()
     dy3.copy_(dy)
     dz3.copy_(res)
 
