@@ -17,6 +17,7 @@
 // Split-K (deterministic: slabs in a caller workspace + a reduce pass) gives
 // small-M / huge-K problems enough workgroups to cover 256 CUs.
 #include "dd_common.h"
+#include <type_traits>
 #include "../../include/daydreamer_hip.h"
 
 namespace {
@@ -31,9 +32,21 @@ namespace {
 // along the operand's contiguous axis: KC = (r, k..k+3), RC = (r..r+3, k).
 // ---------------------------------------------------------------------------
 
+// F = true is the branch-free fast path (16-byte aligned, ld, R and K multiples of
+// 4): out-of-range rows are clamped (they only feed masked outputs), the K tail is zeroed
+// by a select.  Ablation: bounds-check branches in the loaders cost ~15% of GEMM time.
+template <bool F>
 struct MatKC {  // op(X)[r][k] = p[r*ld + k]
   const float* p; long ld; int R; int vec;
+  template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if constexpr (F) {
+      const int rr = min(r, R - 1), kk = FULL ? k : min(k, kend - 4);
+      float4 t = *reinterpret_cast<const float4*>(p + (long)rr * ld + kk);
+      const bool ok = FULL || k < kend;
+      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+      return;
+    }
     if (r < R) {
       const float* q = p + (long)r * ld + k;
       if (vec && k + 3 < kend) {
@@ -49,9 +62,18 @@ struct MatKC {  // op(X)[r][k] = p[r*ld + k]
   }
 };
 
+template <bool F>
 struct MatRC {  // op(X)[r][k] = p[k*ld + r]
   const float* p; long ld; int R; int vec;
+  template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if constexpr (F) {
+      const int rr = min(r, R - 4), kk = FULL ? k : min(k, kend - 1);
+      float4 t = *reinterpret_cast<const float4*>(p + (long)kk * ld + rr);
+      const bool ok = FULL || k < kend;
+      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+      return;
+    }
     if (k < kend) {
       const float* q = p + (long)k * ld + r;
       if (vec && r + 3 < R) {
@@ -71,10 +93,23 @@ __device__ __forceinline__ float cvt(float x, float) { return x; }
 __device__ __forceinline__ float cvt(unsigned char x, float s) { return (float)x * s; }
 
 // conv "down": rows = output pixels (n,sy,sx), k = (ky, kx*Cb + cb).
-template <typename T>
+template <typename T, bool F>
 struct ConvDownA {
   const T* big; int npix, hs, ws, hb, wb, Cb, kwc; float scale; int vec;
+  template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if constexpr (F) {  // branch-free: clamp the pixel, zero the K tail
+      const int rr = min(r, npix - 1), kk = FULL ? k : min(k, kend - 4);
+      int n = rr / (hs * ws); int rem = rr - n * hs * ws;
+      int sy = rem / ws; int sx = rem - sy * ws;
+      int ky = kk / kwc; int o = kk - ky * kwc;
+      const float* q = reinterpret_cast<const float*>(big) +
+          (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o;
+      float4 t = *reinterpret_cast<const float4*>(q);
+      const bool ok = FULL || k < kend;
+      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+      return;
+    }
     if (r >= npix) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
     int n = r / (hs * ws); int rem = r - n * hs * ws;
     int sy = rem / ws; int sx = rem - sy * ws;
@@ -102,9 +137,24 @@ struct ConvDownA {
 
 // conv "up", one output-parity class: rows = class pixels (n,j,i), output
 // pixel (2j+py, 2i+px); k = (tap=(m,mx), cs) with source pixel (j-m, i-mx).
+template <bool F>
 struct ConvUpA {
   const float* small; int npix, nj, ni, hs, ws, Cs, nkx; int vec;
+  template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if constexpr (F) {  // branch-free: clamp pixel / tap source, zero by select
+      const int rr = min(r, npix - 1), kk = FULL ? k : min(k, kend - 4);
+      int n = rr / (nj * ni); int rem = rr - n * nj * ni;
+      int j = rem / ni; int i = rem - j * ni;
+      int tap = kk / Cs; int c = kk - tap * Cs;
+      int m = tap / nkx; int mx = tap - m * nkx;
+      int sy = j - m, sx = i - mx;
+      const bool ok = (FULL || k < kend) && sy >= 0 && sy < hs && sx >= 0 && sx < ws;
+      sy = min(max(sy, 0), hs - 1); sx = min(max(sx, 0), ws - 1);
+      float4 t = *reinterpret_cast<const float4*>(small + (((long)n * hs + sy) * ws + sx) * Cs + c);
+      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+      return;
+    }
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (r >= npix || k >= kend) return;
     int n = r / (nj * ni); int rem = r - n * nj * ni;
@@ -133,9 +183,21 @@ struct ConvUpA {
 };
 
 // conv "up" filter operand: B[k=(tap,cs)][n=cb] = W[ky][kx][cb][cs].
+template <bool F>
 struct ConvUpB {
   const float* w; int Cb, Cs, kw, nkx, py, px; int vec;
+  template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if constexpr (F) {
+      const int rr = min(r, Cb - 1), kk = FULL ? k : min(k, kend - 4);
+      int tap = kk / Cs; int c = kk - tap * Cs;
+      int m = tap / nkx; int mx = tap - m * nkx;
+      int ky = py + 2 * m, kx = px + 2 * mx;
+      float4 t = *reinterpret_cast<const float4*>(w + (((long)ky * kw + kx) * Cb + rr) * Cs + c);
+      const bool ok = FULL || k < kend;
+      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+      return;
+    }
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (r >= Cb || k >= kend) return;
     if (vec) {
@@ -161,10 +223,23 @@ struct ConvUpB {
 
 // filter gradient: rows r = (ky, kx*Cb + cb) (contiguous in runs of kw*Cb),
 // k = small-side pixel (n,sy,sx).
-template <typename T>
+template <typename T, bool F>
 struct ConvWgradA {
   const T* big; int hs, ws, hb, wb, Cb, kwc, R; float scale; int vec;
+  template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    if constexpr (F) {  // branch-free (R % 4 == 0): clamp, zero the K tail by select
+      const int rr = min(r, R - 4), kk = FULL ? k : min(k, kend - 1);
+      int n = kk / (hs * ws); int rem = kk - n * hs * ws;
+      int sy = rem / ws; int sx = rem - sy * ws;
+      int ky = rr / kwc; int o = rr - ky * kwc;
+      const float* q = reinterpret_cast<const float*>(big) +
+          (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o;
+      float4 t = *reinterpret_cast<const float4*>(q);
+      const bool ok = FULL || k < kend;
+      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+      return;
+    }
     if (k >= kend) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
     int n = k / (hs * ws); int rem = k - n * hs * ws;
     int sy = rem / ws; int sx = rem - sy * ws;
@@ -259,19 +334,25 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 
   float ra_[ST][NA][4], rb_[ST][NB][4];
 
-  auto gload = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4]) {
+  auto gload_t = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4], auto full) {
+    constexpr bool FULL = decltype(full)::value;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int id = tid + i * 256;
-      if (AKC) al.load4(m0 + id / KQ, k0 + (id % KQ) * 4, ke, ra[i]);
-      else     al.load4(m0 + (id % (BM / 4)) * 4, k0 + id / (BM / 4), ke, ra[i]);
+      if (AKC) al.template load4<FULL>(m0 + id / KQ, k0 + (id % KQ) * 4, ke, ra[i]);
+      else     al.template load4<FULL>(m0 + (id % (BM / 4)) * 4, k0 + id / (BM / 4), ke, ra[i]);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int id = tid + i * 256;
-      if (BKC) bl.load4(n0 + id / KQ, k0 + (id % KQ) * 4, ke, rb[i]);
-      else     bl.load4(n0 + (id % (BN / 4)) * 4, k0 + id / (BN / 4), ke, rb[i]);
+      if (BKC) bl.template load4<FULL>(n0 + id / KQ, k0 + (id % KQ) * 4, ke, rb[i]);
+      else     bl.template load4<FULL>(n0 + (id % (BN / 4)) * 4, k0 + id / (BN / 4), ke, rb[i]);
     }
+  };
+  // interior k-tiles take the path without any K-tail handling (wave-uniform branch)
+  auto gload = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4]) {
+    if (k0 + BK <= ke) gload_t(k0, ra, rb, std::true_type());
+    else gload_t(k0, ra, rb, std::false_type());
   };
   auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
 #pragma unroll
@@ -427,14 +508,25 @@ extern "C" int dd_gemm_f32(const float* A, const float* B, float* C, int M, int 
   hipStream_t st = (hipStream_t)stream;
   int va = aligned16(A) && (lda % 4 == 0);
   int vb = aligned16(B) && (ldb % 4 == 0);
+  // fast (branch-free) loaders: the float4 axis must be a multiple of 4 (K for a
+  // k-contiguous operand, the row count for a row-contiguous one); both operands or none
+  const bool fa = va && (transA ? (M % 4 == 0 && M >= 4) : (K % 4 == 0 && K >= 4));
+  const bool fb = vb && (transB ? (K % 4 == 0 && K >= 4) : (N % 4 == 0 && N >= 4));
   const char* nm = "dd_gemm_f32";
-  if (!transA && !transB)
-    return run_mat<true, false>(MatKC{A, lda, M, va}, MatRC{B, ldb, N, vb}, M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm);
-  if (!transA && transB)
-    return run_mat<true, true>(MatKC{A, lda, M, va}, MatKC{B, ldb, N, vb}, M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm);
-  if (transA && !transB)
-    return run_mat<false, false>(MatRC{A, lda, M, va}, MatRC{B, ldb, N, vb}, M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm);
-  return run_mat<false, true>(MatRC{A, lda, M, va}, MatKC{B, ldb, N, vb}, M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm);
+#define DD_RUN(AKC, BKC, AT, BT, FF)                                                        \
+  return run_mat<AKC, BKC>(AT<FF>{A, lda, M, va}, BT<FF>{B, ldb, N, vb}, M, N, K, C, ldc,   \
+                           bias, alpha, beta, ws, ws_bytes, st, nm)
+  if (fa && fb) {
+    if (!transA && !transB) DD_RUN(true, false, MatKC, MatRC, true);
+    if (!transA && transB) DD_RUN(true, true, MatKC, MatKC, true);
+    if (transA && !transB) DD_RUN(false, false, MatRC, MatRC, true);
+    DD_RUN(false, true, MatRC, MatKC, true);
+  }
+  if (!transA && !transB) DD_RUN(true, false, MatKC, MatRC, false);
+  if (!transA && transB) DD_RUN(true, true, MatKC, MatKC, false);
+  if (transA && !transB) DD_RUN(false, false, MatRC, MatRC, false);
+  DD_RUN(false, true, MatRC, MatKC, false);
+#undef DD_RUN
 }
 
 extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const float* bias,
@@ -445,14 +537,18 @@ extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w,
   DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_down: geometry");
   const int M = n_img * hs * ws_, N = Cs, K = k * k * Cb;
   const int kwc = k * Cb;
-  MatRC bl{w, Cs, Cs, aligned16(w) && (Cs % 4 == 0)};
+  const int vb = aligned16(w) && (Cs % 4 == 0);
   if (big_is_u8) {
-    ConvDownA<unsigned char> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 0};
-    return run_mat<true, false>(al, bl, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+    ConvDownA<unsigned char, false> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 0};
+    return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
   }
-  int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
-  ConvDownA<float> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec};
-  return run_mat<true, false>(al, bl, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+  const int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
+  if (vec && vb) {
+    ConvDownA<float, true> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec};
+    return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+  }
+  ConvDownA<float, false> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec};
+  return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
 }
 
 // col2im for the GEMM + col2im form of the transposed conv (few output channels):
@@ -503,10 +599,13 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
       const int nn = (n_img - n0 < chunk) ? (n_img - n0) : chunk;
       const int M = nn * hs * ws_;
       const float* a = small + (size_t)n0 * hs * ws_ * Cs;
-      int rc = run_mat<true, true>(MatKC{a, Cs, M, aligned16(a) && (Cs % 4 == 0)},
-                                   MatKC{w, Cs, kkc, aligned16(w) && (Cs % 4 == 0)}, M, kkc, Cs,
-                                   cols, kkc, nullptr, 1.f, 0.f, ws2, ws_bytes / 2, st,
-                                   "dd_conv2d_s2_up(cols)");
+      const int vc = aligned16(a) && aligned16(w) && (Cs % 4 == 0);
+      int rc = vc ? run_mat<true, true>(MatKC<true>{a, Cs, M, 1}, MatKC<true>{w, Cs, kkc, 1}, M, kkc,
+                                        Cs, cols, kkc, nullptr, 1.f, 0.f, ws2, ws_bytes / 2, st,
+                                        "dd_conv2d_s2_up(cols)")
+                  : run_mat<true, true>(MatKC<false>{a, Cs, M, 0}, MatKC<false>{w, Cs, kkc, 0}, M,
+                                        kkc, Cs, cols, kkc, nullptr, 1.f, 0.f, ws2, ws_bytes / 2, st,
+                                        "dd_conv2d_s2_up(cols)");
       if (rc) return rc;
       const long total = (long)nn * hb * wb * Cb;
       int blocks = (int)((total + 255) / 256);
@@ -516,31 +615,37 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
     }
     return 0;
   }
-  int vec = aligned16(small) && aligned16(w) && (Cs % 4 == 0);
-  for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
-      const int nj = (hb - py + 1) / 2, ni = (wb - px + 1) / 2;  // pixels of this parity
-      const int nky = (k - py + 1) / 2, nkx = (k - px + 1) / 2;  // taps of this parity
-      if (nj <= 0 || ni <= 0) continue;
-      const int M = n_img * nj * ni, N = Cb;
-      const int K = (nky > 0 && nkx > 0) ? nky * nkx * Cs : 0;  // K = 0: bias only
-      EpiConvUp ep{big, bias, M, nj, ni, hb, wb, Cb, py, px};
-      ConvUpA al{small, M, nj, ni, hs, ws_, Cs, nkx > 0 ? nkx : 1, vec};
-      ConvUpB bl{w, Cb, Cs, k, nkx > 0 ? nkx : 1, py, px, vec};
-      const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
-      if (M > 64 && N > 64) {
-        int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 128);
-        k_mfma_gemm<128, 128, true, true, ConvUpA, ConvUpB, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
-      } else if (M > 64) {
-        int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 64);
-        k_mfma_gemm<128, 64, true, true, ConvUpA, ConvUpB, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
-      } else {
-        int tm = dd_ceil_div(M, 64), tn = dd_ceil_div(N, 64);
-        k_mfma_gemm<64, 64, true, true, ConvUpA, ConvUpB, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  const int vec = aligned16(small) && aligned16(w) && (Cs % 4 == 0);
+  auto launch = [&](auto fast) -> int {
+    constexpr bool FF = decltype(fast)::value;
+    using AT = ConvUpA<FF>;
+    using BT = ConvUpB<FF>;
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        const int nj = (hb - py + 1) / 2, ni = (wb - px + 1) / 2;  // pixels of this parity
+        const int nky = (k - py + 1) / 2, nkx = (k - px + 1) / 2;  // taps of this parity
+        if (nj <= 0 || ni <= 0) continue;
+        const int M = n_img * nj * ni, N = Cb;
+        const int K = (nky > 0 && nkx > 0) ? nky * nkx * Cs : 0;  // K = 0: bias only
+        EpiConvUp ep{big, bias, M, nj, ni, hb, wb, Cb, py, px};
+        AT al{small, M, nj, ni, hs, ws_, Cs, nkx > 0 ? nkx : 1, vec};
+        BT bl{w, Cb, Cs, k, nkx > 0 ? nkx : 1, py, px, vec};
+        const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
+        if (M > 64 && N > 64) {
+          int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 128);
+          k_mfma_gemm<128, 128, true, true, AT, BT, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+        } else if (M > 64) {
+          int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 64);
+          k_mfma_gemm<128, 64, true, true, AT, BT, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+        } else {
+          int tm = dd_ceil_div(M, 64), tn = dd_ceil_div(N, 64);
+          k_mfma_gemm<64, 64, true, true, AT, BT, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+        }
+        DD_CHECK_LAUNCH("dd_conv2d_s2_up");
       }
-      DD_CHECK_LAUNCH("dd_conv2d_s2_up");
-    }
-  return 0;
+    return 0;
+  };
+  return vec ? launch(std::true_type()) : launch(std::false_type());
 }
 
 extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float* dw,
@@ -551,12 +656,16 @@ extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* s
   DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_wgrad: geometry");
   const int M = k * k * Cb, N = Cs, K = n_img * hs * ws_;
   const int kwc = k * Cb;
-  MatRC bl{small, Cs, Cs, aligned16(small) && (Cs % 4 == 0)};
+  const int vb = aligned16(small) && (Cs % 4 == 0);
   if (big_is_u8) {
-    ConvWgradA<unsigned char> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 0};
-    return run_mat<false, false>(al, bl, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+    ConvWgradA<unsigned char, false> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 0};
+    return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
   }
-  int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
-  ConvWgradA<float> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec};
-  return run_mat<false, false>(al, bl, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+  const int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
+  if (vec && vb) {
+    ConvWgradA<float, true> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec};
+    return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+  }
+  ConvWgradA<float, false> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec};
+  return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
 }
