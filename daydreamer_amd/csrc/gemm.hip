@@ -89,6 +89,28 @@ struct MatRC {  // op(X)[r][k] = p[k*ld + r]
   }
 };
 
+// Division by a launch-constant via multiply-high (valid for dividends < 2^31): the
+// gather loaders decode (image, y, x) / (tap, channel) from linear indices every load,
+// and a 32-bit integer division costs ~25 VALU instructions on gfx950.
+struct FastDiv {
+  unsigned mul, shr, d;
+  __host__ __device__ FastDiv() : mul(0), shr(0), d(1) {}
+  __host__ explicit FastDiv(int dd) {
+    d = (unsigned)(dd < 1 ? 1 : dd);
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    shr = l;
+  }
+  __device__ __forceinline__ int div(int n) const {
+    return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr);
+  }
+  __device__ __forceinline__ void divmod(int n, int& q, int& r) const {
+    q = div(n);
+    r = n - q * (int)d;
+  }
+};
+
 __device__ __forceinline__ float cvt(float x, float) { return x; }
 __device__ __forceinline__ float cvt(unsigned char x, float s) { return (float)x * s; }
 
@@ -96,13 +118,15 @@ __device__ __forceinline__ float cvt(unsigned char x, float s) { return (float)x
 template <typename T, bool F>
 struct ConvDownA {
   const T* big; int npix, hs, ws, hb, wb, Cb, kwc; float scale; int vec;
+  FastDiv d_hw, d_w, d_kwc;
   template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
     if constexpr (F) {  // branch-free: clamp the pixel, zero the K tail
       const int rr = min(r, npix - 1), kk = FULL ? k : min(k, kend - 4);
-      int n = rr / (hs * ws); int rem = rr - n * hs * ws;
-      int sy = rem / ws; int sx = rem - sy * ws;
-      int ky = kk / kwc; int o = kk - ky * kwc;
+      int n, rem, sy, sx, ky, o;
+      d_hw.divmod(rr, n, rem);
+      d_w.divmod(rem, sy, sx);
+      d_kwc.divmod(kk, ky, o);
       const float* q = reinterpret_cast<const float*>(big) +
           (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o;
       float4 t = *reinterpret_cast<const float4*>(q);
@@ -140,14 +164,16 @@ struct ConvDownA {
 template <bool F>
 struct ConvUpA {
   const float* small; int npix, nj, ni, hs, ws, Cs, nkx; int vec;
+  FastDiv d_ji, d_i, d_cs, d_nkx;
   template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
     if constexpr (F) {  // branch-free: clamp pixel / tap source, zero by select
       const int rr = min(r, npix - 1), kk = FULL ? k : min(k, kend - 4);
-      int n = rr / (nj * ni); int rem = rr - n * nj * ni;
-      int j = rem / ni; int i = rem - j * ni;
-      int tap = kk / Cs; int c = kk - tap * Cs;
-      int m = tap / nkx; int mx = tap - m * nkx;
+      int n, rem, j, i, tap, c, m, mx;
+      d_ji.divmod(rr, n, rem);
+      d_i.divmod(rem, j, i);
+      d_cs.divmod(kk, tap, c);
+      d_nkx.divmod(tap, m, mx);
       int sy = j - m, sx = i - mx;
       const bool ok = (FULL || k < kend) && sy >= 0 && sy < hs && sx >= 0 && sx < ws;
       sy = min(max(sy, 0), hs - 1); sx = min(max(sx, 0), ws - 1);
@@ -186,12 +212,14 @@ struct ConvUpA {
 template <bool F>
 struct ConvUpB {
   const float* w; int Cb, Cs, kw, nkx, py, px; int vec;
+  FastDiv d_cs, d_nkx;
   template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
     if constexpr (F) {
       const int rr = min(r, Cb - 1), kk = FULL ? k : min(k, kend - 4);
-      int tap = kk / Cs; int c = kk - tap * Cs;
-      int m = tap / nkx; int mx = tap - m * nkx;
+      int tap, c, m, mx;
+      d_cs.divmod(kk, tap, c);
+      d_nkx.divmod(tap, m, mx);
       int ky = py + 2 * m, kx = px + 2 * mx;
       float4 t = *reinterpret_cast<const float4*>(w + (((long)ky * kw + kx) * Cb + rr) * Cs + c);
       const bool ok = FULL || k < kend;
@@ -226,13 +254,15 @@ struct ConvUpB {
 template <typename T, bool F>
 struct ConvWgradA {
   const T* big; int hs, ws, hb, wb, Cb, kwc, R; float scale; int vec;
+  FastDiv d_hw, d_w, d_kwc;
   template <bool FULL = false>
   __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
     if constexpr (F) {  // branch-free (R % 4 == 0): clamp, zero the K tail by select
       const int rr = min(r, R - 4), kk = FULL ? k : min(k, kend - 1);
-      int n = kk / (hs * ws); int rem = kk - n * hs * ws;
-      int sy = rem / ws; int sx = rem - sy * ws;
-      int ky = rr / kwc; int o = rr - ky * kwc;
+      int n, rem, sy, sx, ky, o;
+      d_hw.divmod(kk, n, rem);
+      d_w.divmod(rem, sy, sx);
+      d_kwc.divmod(rr, ky, o);
       const float* q = reinterpret_cast<const float*>(big) +
           (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o;
       float4 t = *reinterpret_cast<const float4*>(q);
@@ -288,10 +318,12 @@ struct EpiMat {
 
 struct EpiConvUp {
   float* big; const float* bias; int npix, nj, ni, hb, wb, Cb, py, px;
+  FastDiv d_ji, d_i;
   __device__ __forceinline__ void operator()(int m, int n, float v) const {
     if (m >= npix || n >= Cb) return;
-    int img = m / (nj * ni); int rem = m - img * nj * ni;
-    int j = rem / ni; int i = rem - j * ni;
+    int img, rem, j, i;
+    d_ji.divmod(m, img, rem);
+    d_i.divmod(rem, j, i);
     long a = (((long)img * hb + 2 * j + py) * wb + 2 * i + px) * Cb + n;
     big[a] = bias ? v + bias[n] : v;
   }
@@ -539,15 +571,15 @@ extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w,
   const int kwc = k * Cb;
   const int vb = aligned16(w) && (Cs % 4 == 0);
   if (big_is_u8) {
-    ConvDownA<unsigned char, false> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 0};
+    ConvDownA<unsigned char, false> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 0, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
     return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
   }
   const int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
   if (vec && vb) {
-    ConvDownA<float, true> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec};
+    ConvDownA<float, true> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
     return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
   }
-  ConvDownA<float, false> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec};
+  ConvDownA<float, false> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
   return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
 }
 
@@ -627,9 +659,9 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
         if (nj <= 0 || ni <= 0) continue;
         const int M = n_img * nj * ni, N = Cb;
         const int K = (nky > 0 && nkx > 0) ? nky * nkx * Cs : 0;  // K = 0: bias only
-        EpiConvUp ep{big, bias, M, nj, ni, hb, wb, Cb, py, px};
-        AT al{small, M, nj, ni, hs, ws_, Cs, nkx > 0 ? nkx : 1, vec};
-        BT bl{w, Cb, Cs, k, nkx > 0 ? nkx : 1, py, px, vec};
+        EpiConvUp ep{big, bias, M, nj, ni, hb, wb, Cb, py, px, FastDiv(nj * ni), FastDiv(ni)};
+        AT al{small, M, nj, ni, hs, ws_, Cs, nkx > 0 ? nkx : 1, vec, FastDiv(nj * ni), FastDiv(ni), FastDiv(Cs), FastDiv(nkx > 0 ? nkx : 1)};
+        BT bl{w, Cb, Cs, k, nkx > 0 ? nkx : 1, py, px, vec, FastDiv(Cs), FastDiv(nkx > 0 ? nkx : 1)};
         const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
         if (M > 64 && N > 64) {
           int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 128);
@@ -658,14 +690,14 @@ extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* s
   const int kwc = k * Cb;
   const int vb = aligned16(small) && (Cs % 4 == 0);
   if (big_is_u8) {
-    ConvWgradA<unsigned char, false> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 0};
+    ConvWgradA<unsigned char, false> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 0, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
     return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
   }
   const int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
   if (vec && vb) {
-    ConvWgradA<float, true> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec};
+    ConvWgradA<float, true> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
     return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
   }
-  ConvWgradA<float, false> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec};
+  ConvWgradA<float, false> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
   return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
 }
