@@ -31,7 +31,9 @@ class GraphPlan:
 
   def _begin(self):
     self.cur = torch.cuda.CUDAGraph()
-    self.cur.capture_begin()
+    # thread_local: the RCCL watchdog thread of torch.distributed may touch the
+    # device while this thread captures
+    self.cur.capture_begin(capture_error_mode='thread_local')
 
   def _end(self):
     self.cur.capture_end()
