@@ -123,8 +123,11 @@ class Agent:
       self.device = torch.device(_device or f'cuda:{local}')
       torch.cuda.set_device(self.device)
       self.ops = hipops.HipOps(self.device)
+      # second launch context (own scratch workspace) for the side stream
+      self.ops2 = hipops.HipOps(self.device, ws_bytes=1024 << 20)
     else:
       self.ops = _ops
+      self.ops2 = None
       self.device = torch.device(_device or 'cpu')
     self._dtype = _dtype
     hip = self.cfg.get('hip', {})
@@ -155,7 +158,8 @@ class Agent:
     self.learner = learner_mod.Learner(
         self.spec, self.ops, self.device, batch // self.world, length,
         rank=self.rank, world=self.world, comm=self.comm,
-        noise_seed=self._noise_seed, dtype=self._dtype, groups=self.groups)
+        noise_seed=self._noise_seed, dtype=self._dtype, groups=self.groups,
+        ops2=self.ops2)
     if self._pending_load is not None:
       self._apply_load(self._pending_load)
       self._pending_load = None

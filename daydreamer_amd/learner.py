@@ -27,6 +27,7 @@ Design (MI355X-first):
 `ops` is the kernel backend (daydreamer_amd.hipops.HipOps in the product).
 """
 
+import contextlib
 import math
 
 import numpy as np
@@ -108,8 +109,14 @@ class Learner:
 
   def __init__(self, spec, ops, device, batch, length, params=None, seed=0,
                rank=0, world=1, comm=None, noise_seed=0, dtype=F32,
-               groups=None):
+               groups=None, ops2=None):
     self.spec, self.ops, self.device = spec, ops, torch.device(device)
+    # ops2: a second kernel-launch context with its own scratch workspace, used on
+    # a side HIP stream to overlap weight-gradient contractions with the
+    # latency-bound reverse scan (None: everything runs in program order)
+    self.ops2 = ops2
+    self.side_stream = (torch.cuda.Stream(self.device)
+                        if ops2 is not None and self.device.type == 'cuda' else None)
     self.dtype = dtype  # float32 in the product; tests may use float64
     self.cfg = cfg = spec.cfg
     self.B, self.T = batch, length
@@ -329,6 +336,7 @@ class Learner:
     if s.dec_convs:
       b['loss_image'] = {k: z(N) for k in s.dec_cnn_keys}
       c0 = s.dec_convs[0]
+      b['bias_fold'] = z(64 * s.dec_convs[-1].c_big)
       b['bias_tiled'] = z(c0.k * c0.k * c0.c_big)
       b['dbias_tiled'] = z(c0.k * c0.k * c0.c_big)
     # ---- imagination (time-major [H+1, N, ...])
@@ -369,6 +377,18 @@ class Learner:
     self.ops.reduce_stats(x, self.stat_sums[k], self.stat_maxs[k])
     return k
 
+  def fork(self):
+    """Context: the body runs on the side stream, ordered after everything issued
+    so far on the main stream (capturable: becomes a parallel graph branch)."""
+    if self.side_stream is None:
+      return contextlib.nullcontext()
+    self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
+    return torch.cuda.stream(self.side_stream)
+
+  def join(self):
+    if self.side_stream is not None:
+      torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+
   def allreduce(self, t):
     """Sum over data-parallel ranks (RCCL); a graph cut point."""
     if self.comm is not None and self.world > 1:
@@ -383,9 +403,12 @@ class Learner:
     self.ops.ln_act_fwd(zv, P.gamma, P.beta, sel(A.out), sel(A.stats), True)
     return sel(A.out)
 
-  def lin_bwd(self, P, A, x, sel=None, dx=None, dx_beta=0.0, params=True):
+  def lin_bwd(self, P, A, x, sel=None, dx=None, dx_beta=0.0, params=True,
+              defer=None):
     """Gradient w.r.t. the layer output is in A.dout.  Writes parameter
-    gradients (params=True, bulk over the selected rows) and dx."""
+    gradients (params=True, bulk over the selected rows) and dx.  With a
+    `defer` list the weight / bias gradient contractions are queued as
+    closures f(ops) instead of being launched (they only need dz)."""
     sel = sel or (lambda t: t)
     ops = self.ops
     if P.norm:
@@ -396,9 +419,15 @@ class Learner:
     else:
       dz = sel(A.dout)
       if params:
-        ops.col_sum(dz, P.dbias)
+        if defer is not None:
+          defer.append(lambda o, dz=dz, P=P: o.col_sum(dz, P.dbias))
+        else:
+          ops.col_sum(dz, P.dbias)
     if params:
-      ops.gemm(x, dz, P.dW, ta=True)
+      if defer is not None:
+        defer.append(lambda o, x=x, dz=dz, P=P: o.gemm(x, dz, P.dW, ta=True))
+      else:
+        ops.gemm(x, dz, P.dW, ta=True)
     if dx is not None:
       ops.gemm(dz, P.W, dx, tb=True, beta=dx_beta)
     return dz
@@ -409,7 +438,7 @@ class Learner:
     return x
 
   def mlp_bwd(self, layers, acts, x0, sel=None, dx=None, dx_beta=0.0,
-              params=True):
+              params=True, defer=None):
     """Backward through a DenseLN stack; the top layer's A.dout must hold the
     incoming gradient.  x0 is the stack input."""
     sel = sel or (lambda t: t)
@@ -417,7 +446,7 @@ class Learner:
       xin = x0 if i == 0 else sel(acts[i - 1].out)
       tgt = dx if i == 0 else sel(acts[i - 1].dout)
       self.lin_bwd(layers[i], acts[i], xin, sel, tgt,
-                   dx_beta if i == 0 else 0.0, params)
+                   dx_beta if i == 0 else 0.0, params, defer)
 
   def head_fwd(self, name, acts, x, sel=None):
     layers, outs = self.heads[name]
@@ -426,7 +455,7 @@ class Learner:
     return [self.lin_fwd(P, A, h, sel) for P, A in zip(outs, oa)]
 
   def head_bwd(self, name, acts, x, sel=None, dx=None, dx_beta=0.0,
-               params=True):
+               params=True, defer=None):
     """Output-layer gradients must be in the out-acts' .dout."""
     sel = sel or (lambda t: t)
     layers, outs = self.heads[name]
@@ -434,8 +463,8 @@ class Learner:
     top = sel(la[-1].out)
     for j, (P, A) in enumerate(zip(outs, oa)):
       self.lin_bwd(P, A, top, sel, sel(la[-1].dout), 0.0 if j == 0 else 1.0,
-                   params)
-    self.mlp_bwd(layers, la, x, sel, dx, dx_beta, params)
+                   params, defer)
+    self.mlp_bwd(layers, la, x, sel, dx, dx_beta, params, defer)
 
   # ----------------------------------------------------------------- encoder
 
@@ -536,12 +565,14 @@ class Learner:
         ops.mse_loss(o, b['vec_tgt'][k], b['loss_vec'][k], A.dout,
                      scale / self.Ng)
 
-  def decoder_bwd(self, feat, dfeat, beta):
+  def decoder_bwd(self, feat, dfeat, beta, defer=None):
     s, ops, b = self.spec, self.ops, self.b
     m = self.groups['model']
     N = self.N
+    run = (lambda f: defer.append(f)) if defer is not None else (lambda f: f(ops))
     if s.dec_mlp_keys:
-      self.head_bwd('dec_mlp', self.acts_wm['dec_mlp'], feat, None, dfeat, beta)
+      self.head_bwd('dec_mlp', self.acts_wm['dec_mlp'], feat, None, dfeat, beta,
+                    defer=defer)
       beta = 1.0
     if s.dec_convs:
       for i in reversed(range(len(s.dec_convs))):
@@ -555,27 +586,33 @@ class Learner:
                          m.g[f'{cl.name}/norm/bias'], False, True,
                          m.g[f'{cl.name}/bias'])
         else:
-          # image layer: C = 3 columns would leave 61 of 64 column lanes idle; sum
-          # 64-pixel groups as a [rows/64, 64*C] matrix first, then fold the 64 groups.
-          px = a['dz'].numel() // C
-          if px % 64 == 0:
-            tmp = b.setdefault('bias_fold', self.zeros(64 * C))
-            ops.col_sum(a['dz'].view(px // 64, 64 * C), tmp)
-            ops.col_sum(tmp.view(64, C), m.g[f'{cl.name}/bias'])
-          else:
-            ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
+          run(lambda o, a=a, C=C, cl=cl: self._image_bias_grad(o, a, C, cl))
         if i > 0:
           prev = self.dec_act[i - 1]
-          ops.conv_wgrad(a['dz'], prev['out'], m.g[f'{cl.name}/kernel'], cl.k)
+          run(lambda o, a=a, prev=prev, cl=cl: o.conv_wgrad(
+              a['dz'], prev['out'], m.g[f'{cl.name}/kernel'], cl.k))
           ops.conv_down(a['dz'], m.p[f'{cl.name}/kernel'], None, prev['dout'],
                         cl.k)
         else:
           kk = cl.k * cl.k
           dzv = a['dz'].view(N, -1)
-          ops.gemm(dzv, feat, m.g[f'{cl.name}/kernel'].view(kk * C, self.F),
-                   ta=True)
+          run(lambda o, dzv=dzv, cl=cl, kk=kk, C=C: o.gemm(
+              dzv, feat, m.g[f'{cl.name}/kernel'].view(kk * C, self.F), ta=True))
           ops.gemm(dzv, m.p[f'{cl.name}/kernel'].view(kk * C, self.F), dfeat,
                    beta=beta)
+
+  def _image_bias_grad(self, ops, a, C, cl):
+    """Bias gradient of the image layer: C = 3 columns would leave 61 of 64
+    column lanes idle; sum 64-pixel groups as a [rows/64, 64*C] matrix first,
+    then fold the 64 groups."""
+    m = self.groups['model']
+    px = a['dz'].numel() // C
+    if px % 64 == 0:
+      tmp = self.b['bias_fold']
+      ops.col_sum(a['dz'].view(px // 64, 64 * C), tmp)
+      ops.col_sum(tmp.view(64, C), m.g[f'{cl.name}/bias'])
+    else:
+      ops.col_sum(a['dz'].view(-1, C), m.g[f'{cl.name}/bias'])
 
   # ------------------------------------------------------------------- RSSM
 
@@ -834,25 +871,35 @@ class Learner:
     ops, b, cfg = self.ops, self.b, self.cfg
     feat, dfeat = b['post'], b['dfeat']
     gh = cfg['grad_heads']
+    # Heads / decoder: the data-gradient chain (-> dfeat) runs first on the main
+    # stream; their weight-gradient contractions only need the dz buffers and are
+    # queued, then issued on the side stream so the MFMA-heavy filter gradients
+    # overlap the latency-bound reverse scan below.
+    defer = [] if self.ops2 is not None else None
     beta = 0.0
     for name in ('reward', 'cont'):
       flow = name in gh
       self.head_bwd(name, self.acts_wm[name], feat, None,
-                    dfeat if flow else None, beta)
+                    dfeat if flow else None, beta, defer=defer)
       if flow:
         beta = 1.0
     if 'decoder' in gh:
-      self.decoder_bwd(feat, dfeat, beta)
+      self.decoder_bwd(feat, dfeat, beta, defer)
     else:
       if beta == 0.0:
         ops.fill(dfeat, 0.0)
       tmp = self.b.setdefault('dfeat_sink', self.zeros(self.N, self.F))
-      self.decoder_bwd(feat, tmp, 0.0)
+      self.decoder_bwd(feat, tmp, 0.0, defer)
     ops.kl_bwd(b['post_logit'], b['prior_logit'], self.wmkl_scale,
                cfg['loss_scales'].get('kl', 1.0) / self.Ng, cfg['wmkl_balance'],
                b['dpost_logit'], b['dprior_logit'], self.G, self.C)
+    if defer:
+      with self.fork():
+        for f in defer:
+          f(self.ops2)
     self.observe_bwd()
     self.encoder_bwd()
+    self.join()
     self.opt_step('model', 'model_opt')
     # carry the last posterior to the next call (reference agent.py:211)
     post = b['post'].view(self.B, self.T, self.F)

@@ -13,11 +13,12 @@ from oracle import dreamer_ref, ref_ops
 import helpers
 
 
-def run_pair(cfg, steps=2, **kw):
+def run_pair(cfg, steps=2, side=False, **kw):
   plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, **kw)
   ops = ref_ops.RefOps('cpu')
   L = learner_mod.Learner(sp, ops, 'cpu', B, T, params=params, noise_seed=7,
-                          dtype=torch.float64)
+                          dtype=torch.float64,
+                          ops2=ref_ops.RefOps('cpu') if side else None)
   ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64,
                             act_discrete=sp.act_discrete)
   state = None
@@ -58,6 +59,14 @@ def test_learner_matches_oracle_vision():
   cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=3,
                             replay_chunk=5, imag_horizon=4)
   run_pair(cfg, steps=2, image=64, vector=5, action=3, terminals=0.15)
+
+
+def test_learner_deferred_weight_grads():
+  """Same check with the weight-gradient contractions queued for the side
+  launch context (the GPU runs them on a second stream)."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=2,
+                            replay_chunk=4, imag_horizon=2)
+  run_pair(cfg, steps=1, side=True, image=64, vector=5, action=3, terminals=0.1)
 
 
 def test_learner_matches_oracle_proprio():

@@ -20,11 +20,12 @@ LOSS_KEYS = ('model_loss', 'image_loss_mean', 'vector_loss_mean', 'kl_loss_mean'
              'extr_imag_reward_mean', 'extr_imag_return_mean')
 
 
-def run(hip, cfg, steps, gtol=2e-3, **kw):
+def run(hip, cfg, steps, gtol=2e-3, kw_side=None, **kw):
   from oracle import dreamer_ref
   dreamer_ref.SAMPLE_TOL[0] = 1e-3  # fp32 device logits vs fp64 oracle logits
   plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, **kw)
-  L = learner_mod.Learner(sp, hip, 'cuda:0', B, T, params=params, noise_seed=3)
+  L = learner_mod.Learner(sp, hip, 'cuda:0', B, T, params=params, noise_seed=3,
+                          ops2=kw_side)
   ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64,
                             act_discrete=sp.act_discrete)
   state = None
@@ -54,6 +55,16 @@ def test_e2e_debug_vision(hip):
   cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=6,
                             imag_horizon=4)
   run(hip, cfg, 2, image=64, vector=5, action=3, terminals=0.1)
+
+
+def test_e2e_side_stream(hip):
+  """Weight-gradient contractions on the side HIP stream (second launch context
+  with its own workspace), overlapping the reverse scan: same parity bar."""
+  from daydreamer_amd import hipops
+  side = hipops.HipOps('cuda:0', ws_bytes=256 << 20)
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=6,
+                            imag_horizon=4)
+  run(hip, cfg, 2, kw_side=side, image=64, vector=5, action=3, terminals=0.1)
 
 
 def test_e2e_a1_proprio(hip):
