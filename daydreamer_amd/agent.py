@@ -259,9 +259,10 @@ class Agent:
     return {'action': action}, st
 
   def report(self, data):
-    """World-model loss metrics on a batch without updating anything
-    (WorldModel.report -> loss(data), reference agent.py:266-268).  The
-    open-loop video grids of the reference are not produced yet."""
+    """WorldModel.report (reference agent.py:266-282): world-model loss metrics
+    on the batch without updating anything, plus per image key the open-loop
+    video grid `openl_<key>` = [truth | reconstruction(5 steps)+open-loop
+    prediction | error] for the first 6 sequences, shape [T, 3H, 6W, C]."""
     data = {k: np.asarray(v) for k, v in data.items()
             if not k.startswith('log_')}
     B, T = data['is_first'].shape[:2]
@@ -283,6 +284,20 @@ class Agent:
     n = R.N
     for i, name in enumerate(R.stat_names):
       out[f'{name}_mean'] = np.float32(sums[i, 0] / n)
+    ctx = 5
+    if self.spec.dec_convs and T > ctx and R.H * R.N >= (T - ctx) * B:
+      z = R.openloop_device(ctx).cpu().numpy()[:6]
+      model = 1.0 / (1.0 + np.exp(-z.astype(np.float64)))
+      c0 = 0
+      for k, shp in self.spec.dec_cnn_keys.items():
+        truth = data[k][:6].astype(np.float64) / 255.0
+        m = model[..., c0:c0 + shp[2]]
+        c0 += shp[2]
+        error = (m - truth + 1) / 2
+        video = np.concatenate([truth, m, error], 2)        # [B,T,3H,W,C]
+        b_, t_, h_, w_, c_ = video.shape
+        out[f'openl_{k}'] = video.transpose(1, 2, 0, 3, 4).reshape(
+            t_, h_, b_ * w_, c_).astype(np.float32)         # tfutils.video_grid
     return out
 
   # ------------------------------------------------------------- checkpointing

@@ -1099,6 +1099,39 @@ class Learner:
                         HN, lo, hi, 1.0 / (cnt * ent_div), ent_lo, ent_div)
     self.head_bwd('actor', self.acts_im['actor'], feat)
 
+  # ------------------------------------------------------------------ report
+
+  def openloop_device(self, ctx):
+    """WorldModel.report's open-loop prediction (reference agent.py:266-282):
+    after observe_fwd on this learner's batch, keep the posterior for the first
+    `ctx` steps and roll the prior forward with the recorded actions for the
+    rest (RSSM.imagine, nets.py:78-86); decode everything.  Returns the decoder's
+    pre-sigmoid image tensor [B, T, H, W, C] (device)."""
+    ops, b = self.ops, self.b
+    B, T, D, S, A, F = self.B, self.T, self.D, self.S, self.A, self.F
+    assert self.H * self.N >= (T - ctx) * B and self.spec.dec_convs
+    post = b['post'].view(B, T, F)
+    feat = b.setdefault('report_feat', self.zeros(B, T, F))
+    ops.copy2d(b['post'], feat.view(B * T, F))
+    act = b['action'].view(B, T, A)
+    tr = b['traj'].view(-1, F + A)          # scratch rows: [deter | stoch | action]
+    state = tr[:B]
+    ops.copy2d(post[:, ctx - 1], state[:, :F])
+    for i, t in enumerate(range(ctx, T)):
+      nxt = tr[(i + 1) * B:(i + 2) * B]
+      ops.copy2d(act[:, t], state[:, F:])
+      si = lambda buf, i_=i: buf[i_ * B:(i_ + 1) * B]
+      self.core_fwd(state[:, D:], state[:, :D], nxt[:, :D], self.ai_img_in,
+                    b['iz3'], b['igstats'], si)
+      xs = self.prior_fwd(nxt[:, :D], self.ai_img_out, self.ai_img_stats, si)
+      ops.stats_fwd(xs, b['u_img'].view(-1, self.G)[i * B:(i + 1) * B],
+                    b['ilogit'][:B], nxt[:, D:F], self.G, self.C, self.unimix, 0)
+      ops.copy2d(nxt[:, :F], feat[:, t])
+      state = nxt
+    self.decoder_fwd(feat.view(B * T, F))
+    z = self.dec_act[-1]['z']
+    return z.view(B, T, *z.shape[1:])
+
   # ------------------------------------------------------------------ policy
 
   def policy_device(self, sample):

@@ -135,3 +135,29 @@ def test_weight_decay_and_is_first_midsequence():
     assert helpers.rel_err(grads[name], g.numpy()) < 1e-6, name
   for name, v in ag.export_params().items():
     assert helpers.rel_err(newp[name], v) < 1e-7, name
+
+
+def test_report_open_loop_grid():
+  """Agent.report: loss metrics + the open-loop video grid layout of
+  WorldModel.report (reference agent.py:276-281, tfutils.video_grid)."""
+  import numpy as np
+  from daydreamer_amd import agent as agent_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=7, replay_chunk=8,
+                            imag_horizon=3)
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  ag = agent_mod.Agent(obs, act, None, cfg, _ops=ref_ops.RefOps('cpu'), _device='cpu')
+  data = synthetic.make_batch(obs, act, 7, 8, seed=1, smooth_images=True)
+  before = ag.save()
+  rep = ag.report(data)
+  after = ag.save()
+  for k in before:  # report must not change any state
+    assert np.array_equal(np.asarray(before[k]), np.asarray(after[k])), k
+  v = rep['openl_image']
+  assert v.shape == (8, 3 * 64, 6 * 64, 3) and v.dtype == np.float32
+  truth = data['image'][:6].astype(np.float32) / 255.0          # [6,T,H,W,C]
+  grid_truth = truth.transpose(1, 2, 0, 3, 4).reshape(8, 64, 6 * 64, 3)
+  assert np.allclose(v[:, :64], grid_truth, atol=1e-6)
+  model, error = v[:, 64:128], v[:, 128:]
+  assert model.min() > 0 and model.max() < 1
+  assert np.allclose(error, (model - grid_truth + 1) / 2, atol=1e-6)
+  assert np.isfinite(rep['image_loss_mean'])
