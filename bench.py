@@ -174,12 +174,21 @@ def main():
       d[1] += f
       d[2] += e0.elapsed_time(e1) * 1e-3
     step_flops = tot_f
+    # algorithmic bytes (operands read once, result written once), from the labels
+    alg_bytes = sum(int(lab.rsplit(' B', 1)[1]) for lab, _, _, _ in trace)
+    pmc = None
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
+    if os.path.exists(pmc_path):
+      pmc = json.load(open(pmc_path))
     ach = tot_f / tot_t / 1e12
     roof = dict(
         bound='mfma',
         kernel='k_mfma_gemm<*> (fp32 MFMA GEMM + implicit-GEMM conv, incl. split-K reduce)',
         achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        traffic=None if pmc is None else pmc['bytes_per_launch'],
+        traffic_source=None if pmc is None else pmc['source'],
+        algorithmic_bytes_per_launch=round(alg_bytes / len(trace)),
         launches=len(trace), avg_launch_us=round(1e6 * tot_t / len(trace), 2),
         flops_per_launch=tot_f / len(trace),
         kernel_time_ms_per_step=round(1e3 * tot_t, 2),

@@ -158,7 +158,7 @@ class HipOps:
     a, lda = _mat(A)
     b, ldb = _mat(B)
     c, ldc = _mat(C)
-    self._check(self._traced(f'gemm {M}x{N}x{K} ta{int(ta)} tb{int(tb)}', 2.0 * M * N * K, lambda: self.lib.dd_gemm_f32(
+    self._check(self._traced(f'gemm {M}x{N}x{K} ta{int(ta)} tb{int(tb)} B{4 * (M * K + K * N + M * N)}', 2.0 * M * N * K, lambda: self.lib.dd_gemm_f32(
         a, b, c, M, N, K, lda, ldb, ldc, int(ta), int(tb), alpha, beta,
         _ptr(bias), self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_gemm_f32')
 
@@ -168,7 +168,7 @@ class HipOps:
     assert n == n2 and big.is_contiguous() and small.is_contiguous()
     assert tuple(w.shape) == (k, k, cb, cs) and w.is_contiguous()
     fl = 2.0 * n * hs * ws * k * k * cb * cs
-    self._check(self._traced(f'conv_down n{n} {hb}x{cb}->{hs}x{cs} k{k}', fl, lambda: self.lib.dd_conv2d_s2_down(
+    self._check(self._traced(f'conv_down n{n} {hb}x{cb}->{hs}x{cs} k{k} B{big.numel() * big.element_size() + 4 * (small.numel() + w.numel())}', fl, lambda: self.lib.dd_conv2d_s2_down(
         big.data_ptr(), int(big.dtype == torch.uint8), w.data_ptr(), _ptr(bias),
         small.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale,
         self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_s2_down')
@@ -179,7 +179,7 @@ class HipOps:
     assert n == n2 and big.is_contiguous() and small.is_contiguous()
     assert tuple(w.shape) == (k, k, cb, cs) and w.is_contiguous()
     fl = 2.0 * n * hs * ws * k * k * cb * cs
-    self._check(self._traced(f'conv_up n{n} {hs}x{cs}->{hb}x{cb} k{k}', fl, lambda: self.lib.dd_conv2d_s2_up(
+    self._check(self._traced(f'conv_up n{n} {hs}x{cs}->{hb}x{cb} k{k} B{4 * (big.numel() + small.numel() + w.numel())}', fl, lambda: self.lib.dd_conv2d_s2_up(
         small.data_ptr(), w.data_ptr(), _ptr(bias), big.data_ptr(),
         n, hs, ws, cs, hb, wb, cb, k, self.ws.data_ptr(), self.ws_bytes,
         self.stream)), 'dd_conv2d_s2_up')
@@ -190,7 +190,7 @@ class HipOps:
     assert n == n2 and big.is_contiguous() and small.is_contiguous()
     assert tuple(dw.shape) == (k, k, cb, cs) and dw.is_contiguous()
     fl = 2.0 * n * hs * ws * k * k * cb * cs
-    self._check(self._traced(f'conv_wgrad n{n} {hb}x{cb},{hs}x{cs} k{k}', fl, lambda: self.lib.dd_conv2d_s2_wgrad(
+    self._check(self._traced(f'conv_wgrad n{n} {hb}x{cb},{hs}x{cs} k{k} B{big.numel() * big.element_size() + 4 * (small.numel() + dw.numel())}', fl, lambda: self.lib.dd_conv2d_s2_wgrad(
         big.data_ptr(), int(big.dtype == torch.uint8), small.data_ptr(),
         dw.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale, beta,
         self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_s2_wgrad')

@@ -131,3 +131,37 @@ def test_full_size_properties(hip):
   d = b['i_cont'].view(H + 1, N)[H] * plain['discount']
   ret = b['i_ret'].view(H, N)[H - 1]
   assert torch.allclose(ret, r + d * v, rtol=1e-5, atol=1e-5)
+
+
+def test_full_size_parity_vs_oracle(hip):
+  """BASELINE configs[1] at FULL size (batch 50 x seq 50 x horizon 15, 64x64 image,
+  deter 256, 32x32 latent, 16-dim action): one complete train step on the HIP path
+  against the float64 oracle on the same minibatch, weights and noise (~1 min of
+  host time for the oracle).  Tolerances as north_star: losses / grad norms 1e-3
+  relative; gradients 5e-3 of their max at this depth and row count."""
+  import torch
+  from oracle import dreamer_ref
+  torch.set_num_threads(16)
+  dreamer_ref.SAMPLE_TOL[0] = 1e-3
+  cfg = helpers.make_config(('a1_vision',))
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(
+      cfg, image=64, vector=16, action=16, terminals=0.01, smooth=True)
+  assert (B, T, plain['imag_horizon']) == (50, 50, 15)
+  L = learner_mod.Learner(sp, hip, 'cuda:0', B, T, params=params, noise_seed=9)
+  L.upload(data)
+  L.train_step_device(use_carry=False)
+  torch.cuda.synchronize()
+  mets = L.read_metrics()
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64)
+  _, _, omets = ag.train(data, helpers.noise_from_learner(L), None,
+                         helpers.forced_from_learner(L))
+  for k in LOSS_KEYS:
+    if k in omets:
+      a, o = float(mets[k]), float(omets[k])
+      assert abs(a - o) <= 1e-3 * max(abs(o), 1e-2), f'{k}: {a} vs {o}'
+  grads = L.export_grads()
+  worst = max((helpers.rel_err(grads[n], g.numpy()), n)
+              for n, g in ag.last['grads'].items())
+  assert worst[0] < 5e-3, f'worst grad {worst}'
+  print('full-size parity: model_loss', float(mets['model_loss']), 'vs', float(omets['model_loss']),
+        'worst grad rel err', worst)

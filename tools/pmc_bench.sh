@@ -1,0 +1,26 @@
+#!/bin/bash
+# HBM traffic of the contraction kernels during bench.py (separate --pmc passes, as
+# MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  PYTHONPATH=$GRAFT_REPO_ROOT timeout 300 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o b --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 3 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
+done
+python - <<PY
+import csv, glob, collections, re
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"/tmp/pmc_{c}/**/*counter_collection*.csv", recursive=True)
+    if not f: print("no output for", c); continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != c: continue
+        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        key = "k_mfma_gemm" if "k_mfma_gemm" in name else ("k_splitk_reduce" if "splitk" in name else ("k_col2im" if "col2im" in name else "other"))
+        agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
+    res[c] = agg
+print("counter,kernel_class,dispatches,sum_KiB,avg_KiB_per_launch")
+for c, agg in res.items():
+    for k, (n, v) in agg.items():
+        print(f"{c},{k},{n},{v:.1f},{v/n:.2f}")
+PY
