@@ -17,6 +17,8 @@
 // Split-K (deterministic: slabs in a caller workspace + a reduce pass) gives
 // small-M / huge-K problems enough workgroups to cover 256 CUs.
 #include "dd_common.h"
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "../../include/daydreamer_hip.h"
 
@@ -507,7 +509,18 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
   // (deep-K problems keep the big tile and get their parallelism from split-K)
   const bool shallow = K <= 1536;
   if (shallow && TMS == 128 && TNS == 128 && (long)dd_ceil_div(M, 128) * dd_ceil_div(N, 128) < 256) TNS = 64;
-  if (shallow && TMS == 128 && TNS == 64 && (long)dd_ceil_div(M, 128) * dd_ceil_div(N, 64) < 256) TMS = 64;
+  // (measured on 2500-row problems: 64x64 wins up to ~500 128x64-tiles for K <= 768,
+  // 128x64 wins for deeper K unless it leaves most CUs idle)
+  if (shallow && TMS == 128 && TNS == 64 &&
+      (long)dd_ceil_div(M, 128) * dd_ceil_div(N, 64) < (K > 768 ? 128 : 512)) TMS = 64;
+  {  // experimentation hook: DD_FORCE_TILE=128x128|128x64|64x64
+    static const char* force = getenv("DD_FORCE_TILE");
+    if (force && M > 64) {
+      if (!strcmp(force, "128x128")) { TMS = 128; TNS = 128; }
+      else if (!strcmp(force, "128x64")) { TMS = 128; TNS = 64; }
+      else if (!strcmp(force, "64x64")) { TMS = 64; TNS = 64; }
+    }
+  }
   const int tm = dd_ceil_div(M, TMS), tn = dd_ceil_div(N, TNS);
   const long MN = (long)M * N;
   int S = pick_split((long)tm * tn, K, MN, ws ? ws_bytes : 0);
