@@ -489,7 +489,10 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // Split-K factor: enough workgroups to cover the chip, bounded by K and the
 // caller's workspace.
 int pick_split(long tiles, int K, long MN, size_t ws_bytes) {
-  if (tiles >= 192 || K < 128) return 1;
+  static const int min_tiles = getenv("DD_SPLIT_MIN_TILES") ? atoi(getenv("DD_SPLIT_MIN_TILES")) : 192;
+  if (tiles >= min_tiles || K < 128) return 1;
+  // measured (2500x256xK): with >= 100 tiles a short K loop beats split + reduce
+  if (tiles >= 100 && K <= 384) return 1;
   long s = (512 + tiles - 1) / tiles;
   long maxs = K / 64;
   if (s > maxs) s = maxs;
