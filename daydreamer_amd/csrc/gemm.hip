@@ -493,8 +493,10 @@ int pick_split(long tiles, int K, long MN, size_t ws_bytes) {
   if (tiles >= min_tiles || K < 128) return 1;
   // measured (2500x256xK): with >= 100 tiles a short K loop beats split + reduce
   if (tiles >= 100 && K <= 384) return 1;
-  long s = (512 + tiles - 1) / tiles;
-  long maxs = K / 64;
+  static const int kmin = getenv("DD_SPLIT_KMIN") ? atoi(getenv("DD_SPLIT_KMIN")) : 64;
+  static const int target = getenv("DD_SPLIT_TARGET") ? atoi(getenv("DD_SPLIT_TARGET")) : 512;
+  long s = (target + tiles - 1) / tiles;
+  long maxs = K / kmin;
   if (s > maxs) s = maxs;
   while (s > 1 && (size_t)s * MN * sizeof(float) > ws_bytes) --s;
   return (int)(s < 1 ? 1 : s);
