@@ -165,3 +165,32 @@ def test_full_size_parity_vs_oracle(hip):
   assert worst[0] < 5e-3, f'worst grad {worst}'
   print('full-size parity: model_loss', float(mets['model_loss']), 'vs', float(omets['model_loss']),
         'worst grad rel err', worst)
+
+
+def test_training_reduces_loss_through_agent(hip):
+  """Through the public Agent API with HIP-graph replay: 40 train steps on a
+  fixed small batch must reduce the world-model loss, keep every metric finite,
+  advance all three optimizers, and policy() must keep working while training."""
+  import numpy as np
+  from daydreamer_amd import agent as agent_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=8, replay_chunk=8,
+                            imag_horizon=5)
+  cfg = cfg.update({'model_opt.lr': 1e-3})
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  ag = agent_mod.Agent(obs, act, None, cfg)
+  data = synthetic.make_batch(obs, act, 8, 8, seed=4, smooth_images=True)
+  state, first, last = None, None, None
+  for i in range(40):
+    _, state, mets = ag.train(data, state)
+    assert all(np.isfinite(v) for v in mets.values()), i
+    first = first if first is not None else float(mets['model_loss'])
+    last = float(mets['model_loss'])
+  assert ag._plan is not None and ag._plan.n_graphs >= 2   # replayed from HIP graphs
+  assert last < 0.9 * first, (first, last)
+  assert float(mets['model_grad_steps']) == 40 and float(mets['actor_grad_steps']) == 40
+  o = {'image': np.zeros((1, 64, 64, 3), np.uint8), 'vector': np.zeros((1, 5), np.float32),
+       'reward': np.zeros(1, np.float32), 'is_first': np.array([True]),
+       'is_last': np.zeros(1, bool), 'is_terminal': np.zeros(1, bool)}
+  a, st = ag.policy(o, None, 'train')
+  a2, st = ag.policy({**o, 'is_first': np.array([False])}, st, 'eval')
+  assert a['action'].shape == (1, 3) and np.isfinite(a2['action']).all()
