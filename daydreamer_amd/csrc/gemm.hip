@@ -469,6 +469,249 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       }
 }
 
+// ---------------------------------------------------------------------------
+// Split-bf16 main loop: fp32 operands decomposed exactly into three bf16 terms
+// (x = hi + mid + lo, 8 significand bits each, by truncation), products on the bf16
+// matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the rate of the fp32 MFMA), fp32
+// accumulation.  NP = 6 keeps every cross term down to 2^-16 relative (hi*hi, hi*mid,
+// mid*hi, mid*mid, hi*lo, lo*hi): what is dropped is below 2^-22 of a product, i.e.
+// fp32-level accuracy at 16/6 the fp32-MFMA peak.  NP = 3 (hi*hi, hi*mid, mid*hi) is an
+// experiment switch only (2^-15 relative, reduced precision; never the default).
+//
+// LDS: three bit-planes per operand, laid out by the operand's contiguous axis so that
+// both the stores and the fragment reads are wide and conflict-free:
+//   k-contiguous operand   plane[koct][row] = 16-byte slot of 8 consecutive k; a staged
+//                          float4 (row, 4 k) is one ds_write_b64, the MFMA operand (row
+//                          l&31, k-octet l>>5) one ds_read_b128;
+//   row-contiguous operand plane[k][row] bf16; a staged float4 (4 rows, k) is one
+//                          ds_write_b64, the MFMA operand two ds_read_b64_tr_b16 (the
+//                          gfx950 LDS transpose read: a 16-lane group reads a 4(k) x 16(row)
+//                          block, lane i receives row i's four k).
+// Strides are padded to 64 mod 256 bytes (koct / k rows land on different bank quarters).
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
+
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __float_as_uint(x) & 0xFFFF0000u;
+  const float r1 = x - __uint_as_float(h);          // exact
+  m = __float_as_uint(r1) & 0xFFFF0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m));     // exact, <= 8 significant bits
+}
+// bf16(even) | bf16(odd) << 16 from the top halves of two words
+__device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) {
+  return __builtin_amdgcn_perm(odd, even, 0x07060302u);
+}
+
+template <int BX, bool KC, int BK>
+struct PlaneS3 {
+  // bytes per k-octet (KC) / per k (RC); the pad staggers bank quarters
+  static constexpr int STR = KC ? BX * 16 + (BK == 16 ? 64 : 32) : BX * 2 + 64;
+  static constexpr int BYTES = KC ? (BK / 8) * STR : BK * STR;
+  // float4 units staged per thread: KC chunks (row, 4 k); RC patches (4 rows, 2 k) = 2 units
+  static constexpr int UNITS = BX * BK / 4;            // float4s per tile
+  static constexpr int WORK = KC ? UNITS : UNITS / 2;  // chunks / patches per tile
+  static constexpr int N = (WORK >= 256 ? WORK / 256 : 1) * (KC ? 1 : 2);
+  static constexpr int ACTIVE = WORK >= 256 ? 256 : WORK;  // threads that stage
+  // unit u of thread tid -> (row, k) of its first element
+  static __device__ __forceinline__ void coord(int tid, int u, int& r, int& k) {
+    if constexpr (KC) {
+      const int id = tid + u * 256;
+      r = id / (BK / 4); k = (id % (BK / 4)) * 4;
+    } else {  // patch = units (2p, 2p+1): same rows, k and k+1
+      const int pp = tid + (u >> 1) * 256;
+      const int kp = pp / (BX / 4);
+      r = (pp % (BX / 4)) * 4; k = 2 * kp + (u & 1);
+    }
+  }
+  // staged float4 -> one 8-byte store per plane
+  template <int NPL>
+  static __device__ __forceinline__ void store(unsigned char* base, const float (&v)[4], int r, int k) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3(v[j], h[j], m[j], l[j]);
+    const int o = KC ? (k >> 3) * STR + r * 16 + (k & 4) * 2 : k * STR + r * 2;
+    *reinterpret_cast<uint2*>(base + o) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
+    *reinterpret_cast<uint2*>(base + BYTES + o) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
+    if (NPL == 3)
+      *reinterpret_cast<uint2*>(base + 2 * BYTES + o) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+  }
+  // MFMA operand of the 32-row block starting at row0, k-step ks (16 k each), this lane
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane, int row0, int ks, int lane) {
+    const int lk = lane >> 5;
+    if constexpr (KC) {
+      uint4 q = *reinterpret_cast<const uint4*>(plane + (2 * ks + lk) * STR + (row0 + (lane & 31)) * 16);
+      return __builtin_bit_cast(bf16x8, q);
+    } else {
+      const int i = lane & 15, g = (lane >> 4) & 1;
+      const unsigned char* p = plane + (16 * ks + 8 * lk + (i >> 2)) * STR + (row0 + 16 * g + 4 * (i & 3)) * 2;
+      typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+      bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p));
+      bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p + 4 * STR));
+      uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+      return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+    }
+  }
+};
+
+template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int NP = 6, int BK = 16>
+__global__ void __launch_bounds__(256, 2)
+k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
+  constexpr int NPL = NP == 3 ? 2 : 3;     // planes kept
+  using LA = PlaneS3<BM, AKC, BK>;
+  using LB = PlaneS3<BN, BKC, BK>;
+  __shared__ __attribute__((aligned(16))) unsigned char As[2][NPL * LA::BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NPL * LB::BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+  const int kb = blockIdx.z * kps;
+  const int ke = min(K, kb + kps);
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  constexpr int NA = LA::N, NB = LB::N;
+  const bool a_on = LA::ACTIVE >= 256 || tid < LA::ACTIVE;
+  const bool b_on = LB::ACTIVE >= 256 || tid < LB::ACTIVE;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float ra[NA][4], rb[NB][4];
+
+  auto gload = [&](int k0, auto full) {
+    constexpr bool FULL = decltype(full)::value;
+    if (a_on) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        int r, k; LA::coord(tid, u, r, k);
+        al.template load4<FULL>(m0 + r, k0 + k, ke, ra[u]);
+      }
+    }
+    if (b_on) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        int r, k; LB::coord(tid, u, r, k);
+        bl.template load4<FULL>(n0 + r, k0 + k, ke, rb[u]);
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+    if (a_on) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        int r, k; LA::coord(tid, u, r, k);
+        LA::template store<NPL>(As[buf], ra[u], r, k);
+      }
+    }
+    if (b_on) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        int r, k; LB::coord(tid, u, r, k);
+        LB::template store<NPL>(Bs[buf], rb[u], r, k);
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[TM][NPL], bf[TN][NPL];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, ks, lane);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, ks, lane);
+      // product (pa, pb) of the bit-planes, smallest terms first; consecutive MFMAs go
+      // to different accumulators
+      constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
+#pragma unroll
+      for (int q = (NP == 6 ? 0 : 3); q < 6; ++q)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // k-tiles 0..nfull-1 are whole, tile nfull (if any) is the K tail.  The steady-state
+  // loop has exactly one code path (whole-tile prefetch): with the tail variant inside
+  // it the register allocator shares load destinations between the variants and the
+  // hardware then waits for the prefetch before the MFMAs instead of after them.
+  const int nfull = (ke - kb) / BK, nk = (ke - kb + BK - 1) / BK;
+  if (nk > 0) {
+    if (nfull > 0) gload(kb, std::true_type());
+    else gload(kb, std::false_type());
+    sstore(0);
+  }
+  __syncthreads();
+  int t = 0;
+  for (; t + 1 < nfull; ++t) {
+    gload(kb + (t + 1) * BK, std::true_type());
+    // keep the prefetch issued ahead of the MFMA block (the scheduler otherwise sinks the
+    // loads next to their first use, i.e. behind the MFMAs, and exposes their latency)
+    __builtin_amdgcn_sched_barrier(0);
+    compute(t & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    sstore((t & 1) ^ 1);
+    __syncthreads();
+  }
+  if (t + 1 < nk) {
+    gload(kb + (t + 1) * BK, std::false_type());
+    compute(t & 1);
+    sstore((t & 1) ^ 1);
+    __syncthreads();
+    ++t;
+  }
+  if (t < nk) compute(t & 1);
+
+  const int lk = lane >> 5, lr = lane & 31;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        int col = n0 + wn0 + b * 32 + lr;
+        ep(row, col, acc[a][b][r]);
+      }
+}
+
+// 0 = native fp32 MFMA, 6 = split-bf16 with six products (fp32-level accuracy),
+// 3 = split-bf16 with three products (experiment only: reduced precision).
+int g_gemm_mode = -1;
+inline int gemm_mode() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("DD_GEMM_MODE");
+    g_gemm_mode = e ? atoi(e) : 6;
+  }
+  return g_gemm_mode;
+}
+
+// launch the main loop for one tile shape in the selected arithmetic mode
+template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP>
+void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps, int tm) {
+  const int mode = (BM == 64 && BN == 64) ? 0 : gemm_mode();
+  if constexpr (BM == 64 && BN == 64) {
+    k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  } else {
+    if (mode == 6)
+      k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+    else if (mode == 3)
+      k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 3><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+    else
+      k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  }
+}
+
 __global__ void k_splitk_reduce(const float* __restrict__ slab, int S, long MN, int N,
                                 float* C, long ldc, const float* bias, float alpha, float beta) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN;
@@ -534,11 +777,11 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
   EpiMat ep{C, ldc, bias, alpha, beta, M, N, S > 1 ? ws : nullptr};
   dim3 grid(tm * tn, 1, S);
   if (TMS == 128 && TNS == 128)
-    k_mfma_gemm<128, 128, AKC, BKC, AL, BL, EpiMat><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+    launch_tile<128, 128, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
   else if (TMS == 128)
-    k_mfma_gemm<128, 64, AKC, BKC, AL, BL, EpiMat><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+    launch_tile<128, 64, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
   else
-    k_mfma_gemm<64, 64, AKC, BKC, AL, BL, EpiMat><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+    launch_tile<64, 64, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
   DD_CHECK_LAUNCH(name);
   if (S > 1) {
     int blocks = (int)((MN + 255) / 256);
@@ -550,6 +793,13 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
 }
 
 }  // namespace
+
+extern "C" int dd_gemm_set_mode(int mode) {
+  const int prev = gemm_mode();
+  DD_REQUIRE(mode == 0 || mode == 3 || mode == 6, "dd_gemm_set_mode: mode must be 0, 3 or 6");
+  g_gemm_mode = mode;
+  return prev;
+}
 
 extern "C" int dd_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                            long lda, long ldb, long ldc, int transA, int transB,
@@ -683,13 +933,13 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
         const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
         if (M > 64 && N > 64) {
           int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 128);
-          k_mfma_gemm<128, 128, true, true, AT, BT, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+          launch_tile<128, 128, true, true>(dim3(tm * tn, 1, 1), st, al, bl, ep, K, kps, tm);
         } else if (M > 64) {
           int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 64);
-          k_mfma_gemm<128, 64, true, true, AT, BT, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+          launch_tile<128, 64, true, true>(dim3(tm * tn, 1, 1), st, al, bl, ep, K, kps, tm);
         } else {
           int tm = dd_ceil_div(M, 64), tn = dd_ceil_div(N, 64);
-          k_mfma_gemm<64, 64, true, true, AT, BT, EpiConvUp><<<dim3(tm * tn, 1, 1), 256, 0, st>>>(al, bl, ep, K, kps, tm);
+          launch_tile<64, 64, true, true>(dim3(tm * tn, 1, 1), st, al, bl, ep, K, kps, tm);
         }
         DD_CHECK_LAUNCH("dd_conv2d_s2_up");
       }

@@ -38,6 +38,14 @@ int dd_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                 float alpha, float beta, const float* bias,
                 float* ws, size_t ws_bytes, void* stream);
 
+/* Arithmetic of the 128-row tiles of every contraction below: 6 (default) = fp32
+ * operands split exactly into three bf16 terms, six cross products on the bf16 matrix
+ * pipe with fp32 accumulation (fp32-level accuracy); 0 = native fp32 MFMA;
+ * 3 = three products (experiment: ~2^-15 relative, reduced precision).  Also settable
+ * with the environment variable DD_GEMM_MODE before the first call.  Returns the
+ * previous mode. */
+int dd_gemm_set_mode(int mode);
+
 /* Stride-2 VALID convolution family over NHWC tensors.  "big" is the
  * full-resolution side [n,hb,wb,Cb], "small" the downsampled side
  * [n,hs,ws,Cs], filter w[k,k,Cb,Cs] (= tf.nn.conv2d's [kh,kw,in,out] for the
