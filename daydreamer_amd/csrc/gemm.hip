@@ -321,6 +321,7 @@ struct EpiMat {
 struct EpiConvUp {
   float* big; const float* bias; int npix, nj, ni, hb, wb, Cb, py, px;
   FastDiv d_ji, d_i;
+
   __device__ __forceinline__ void operator()(int m, int n, float v) const {
     if (m >= npix || n >= Cb) return;
     int img, rem, j, i;
@@ -554,7 +555,8 @@ struct PlaneS3 {
   }
 };
 
-template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int NP = 6, int BK = 16>
+template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int NP = 6, int BK = 16,
+          int ST = 1, bool IL = false>
 __global__ void __launch_bounds__(256, 2)
 k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   constexpr int NPL = NP == 3 ? 2 : 3;     // planes kept
@@ -581,9 +583,9 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float ra[NA][4], rb[NB][4];
+  float ra_[ST][NA][4], rb_[ST][NB][4];
 
-  auto gload = [&](int k0, auto full) {
+  auto gload = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4], auto full) {
     constexpr bool FULL = decltype(full)::value;
     if (a_on) {
 #pragma unroll
@@ -600,7 +602,11 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       }
     }
   };
-  auto sstore = [&](int buf) {
+  auto gload_rt = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4]) {
+    if (k0 + BK <= ke) gload(k0, ra, rb, std::true_type());
+    else gload(k0, ra, rb, std::false_type());
+  };
+  auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
     if (a_on) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
@@ -641,36 +647,55 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
     }
   };
 
-  // k-tiles 0..nfull-1 are whole, tile nfull (if any) is the K tail.  The steady-state
-  // loop has exactly one code path (whole-tile prefetch): with the tail variant inside
-  // it the register allocator shares load destinations between the variants and the
-  // hardware then waits for the prefetch before the MFMAs instead of after them.
+  // k-tiles 0..nfull-1 are whole, tile nfull (if any) is the K tail.  ST tiles are in
+  // flight in registers (slot = tile % ST), tile t+1 is staged into LDS while tile t is
+  // multiplied.  The steady-state loop has exactly one code path (whole-tile prefetch):
+  // with the tail variant inside it the register allocator shares load destinations
+  // between the variants and the hardware then waits for the prefetch before the MFMAs
+  // instead of after them.
   const int nfull = (ke - kb) / BK, nk = (ke - kb + BK - 1) / BK;
-  if (nk > 0) {
-    if (nfull > 0) gload(kb, std::true_type());
-    else gload(kb, std::false_type());
-    sstore(0);
-  }
+#pragma unroll
+  for (int s_ = 0; s_ < ST; ++s_)
+    if (s_ < nk) gload_rt(kb + s_ * BK, ra_[s_], rb_[s_]);
+  if (nk > 0) sstore(0, ra_[0], rb_[0]);
   __syncthreads();
-  int t = 0;
-  for (; t + 1 < nfull; ++t) {
-    gload(kb + (t + 1) * BK, std::true_type());
-    // keep the prefetch issued ahead of the MFMA block (the scheduler otherwise sinks the
-    // loads next to their first use, i.e. behind the MFMAs, and exposes their latency)
-    __builtin_amdgcn_sched_barrier(0);
-    compute(t & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    sstore((t & 1) ^ 1);
-    __syncthreads();
+  int t0 = 0;
+  for (; t0 + 2 * ST <= nfull; t0 += ST) {
+#pragma unroll
+    for (int s_ = 0; s_ < ST; ++s_) {
+      const int t = t0 + s_;
+      gload(kb + (t + ST) * BK, ra_[s_], rb_[s_], std::true_type());
+      // keep the prefetch issued ahead of the MFMA block (the scheduler otherwise sinks
+      // the loads next to their first use, behind the MFMAs, and exposes their latency)
+      __builtin_amdgcn_sched_barrier(0);
+      compute(t & 1);
+      if (!IL) __builtin_amdgcn_sched_barrier(0);
+      sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+      if (IL) {  // tile t+1 arrived an iteration ago: split + stage it under the MFMAs
+        constexpr int NMF = TM * TN * NP * (BK / 16);
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
   }
-  if (t + 1 < nk) {
-    gload(kb + (t + 1) * BK, std::false_type());
-    compute(t & 1);
-    sstore((t & 1) ^ 1);
-    __syncthreads();
-    ++t;
+  for (; t0 < nk; t0 += ST) {
+#pragma unroll
+    for (int s_ = 0; s_ < ST; ++s_) {
+      const int t = t0 + s_;
+      if (t < nk) {
+        if (t + ST < nk) gload_rt(kb + (t + ST) * BK, ra_[s_], rb_[s_]);
+        compute(t & 1);
+        if (t + 1 < nk) sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+        __syncthreads();
+      }
+    }
   }
-  if (t < nk) compute(t & 1);
 
   const int lk = lane >> 5, lr = lane & 31;
 #pragma unroll
@@ -696,20 +721,21 @@ inline int gemm_mode() {
   return g_gemm_mode;
 }
 
-// launch the main loop for one tile shape in the selected arithmetic mode
+// launch the main loop for one tile shape in the selected arithmetic mode.  Measured
+// variants of the split-bf16 loop (tools/gemm_modes.py, bench.py): 128-row tiles: prefetch
+// distance 2 with the split of tile t+1 interleaved under the MFMAs of tile t (52.6 vs
+// 53.2 ms/step for distance 1, no interleave); 64x64 tiles (latency-bound, about one
+// workgroup per CU): distance 4 (BK 16) beats BK 32 x distance 2 and the fp32 loop.
 template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP>
 void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps, int tm) {
-  const int mode = (BM == 64 && BN == 64) ? 0 : gemm_mode();
-  if constexpr (BM == 64 && BN == 64) {
+  if (gemm_mode() == 0) {
     k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-  } else {
-    if (mode == 6)
-      k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-    else if (mode == 3)
-      k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 3><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-    else
-      k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+    return;
   }
+  if constexpr (BM == 64 && BN == 64)
+    k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  else
+    k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 2, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
 }
 
 __global__ void k_splitk_reduce(const float* __restrict__ slab, int S, long MN, int N,
@@ -796,7 +822,7 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
 
 extern "C" int dd_gemm_set_mode(int mode) {
   const int prev = gemm_mode();
-  DD_REQUIRE(mode == 0 || mode == 3 || mode == 6, "dd_gemm_set_mode: mode must be 0, 3 or 6");
+  DD_REQUIRE(mode == 0 || mode == 6, "dd_gemm_set_mode: mode must be 0 or 6");
   g_gemm_mode = mode;
   return prev;
 }

@@ -530,7 +530,9 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
       constexpr int LPR = decltype(lpr)::value, V = decltype(v)::value;
       constexpr int RPW = 64 / LPR;
       long groups = (rows + RPW - 1) / RPW;
-      int blocks = want ? row_blocks(groups, 256) : row_blocks(groups, 1 << 20);
+      // (one 256-block wave of the grid leaves 4 waves per CU: too few loads in flight for
+      // the big convolutional LayerNorms, 1.7 TB/s; 8 blocks per CU reach the HBM rate)
+      int blocks = want ? row_blocks(groups, groups > 200000 ? 2048 : 256) : row_blocks(groups, 1 << 20);
       size_t shmem = want ? (size_t)WPB * RPW * 3 * C * sizeof(float) : 0;
       if (want) DD_REQUIRE(ws && (size_t)blocks * 3 * C * sizeof(float) <= ws_bytes, "dd_ln_act_bwd: workspace too small");
       k_ln_act_bwd_v<LPR, V><<<blocks, 256, shmem, st>>>(

@@ -7,6 +7,7 @@ from daydreamer_amd import hipops
 
 ops = hipops.HipOps('cuda:0', ws_bytes=1024 << 20)
 g = torch.Generator(device='cuda').manual_seed(0)
+MODES = tuple(int(x) for x in os.environ.get('GEMM_MODES', '0,6').split(','))
 
 
 def timeit(fn, n=10):
@@ -32,7 +33,7 @@ def gemm_case(M, N, K, ta, tb, check=True):
     a = A.double().T if ta else A.double(); b = B.double().T if tb else B.double()
     ref = a @ b
   out = []
-  for mode in (0, 6, 3):
+  for mode in MODES:
     ops.lib.dd_gemm_set_mode(mode)
     C.zero_(); ops.gemm(A, B, C, ta=ta, tb=tb)
     err = relerr(C, ref) if check else float('nan')
@@ -59,12 +60,12 @@ def conv_case(n, hb, cb, cs, k):
       ('wgrad', lambda: ops.conv_wgrad(big, small, dw, k), None)):
     out = []
     ref_w = None
-    for mode in (0, 6, 3):
+    for mode in MODES:
       ops.lib.dd_gemm_set_mode(mode)
       fn()
       if chk: err = chk()
       else:
-        if ref_w is None: ref_w = dw.double().clone(); err = 0.0  # mode 0 as the reference
+        if ref_w is None: ref_w = dw.double().clone(); err = 0.0  # first mode as the reference
         else: err = relerr(dw, ref_w)
       ms = timeit(fn, 5)
       out.append(f'm{mode}: {fl/ms/1e9:6.1f} TF err {err:.1e}')
