@@ -153,6 +153,26 @@ def main():
   barrier()
   dt_incl = (time.perf_counter() - t0) / n_incl
 
+  # ---- replay-inclusive: minibatches gathered in HBM from a DeviceReplay
+  # (embodied.Replay API) -> Agent.train; no host copy of the batch
+  dt_replay = None
+  if world == 1:
+    from daydreamer_amd import replay as replay_mod
+    rep = replay_mod.DeviceReplay(chunk=T, capacity=50_000)
+    eps = synthetic.make_batch(obs, act, 16, 4 * T, seed=1)
+    for e in range(16):
+      rep.add_traj({**{k: v[e] for k, v in eps.items()},
+                    'is_last': np.arange(4 * T) == 4 * T - 1})
+    ds = agent.dataset(rep.dataset)
+    for _ in range(2):
+      _, state, mets = agent.train(next(ds), state)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_incl):
+      _, state, mets = agent.train(next(ds), state)
+    barrier()
+    dt_replay = (time.perf_counter() - t0) / n_incl
+
   # ---- live roofline of the dominant kernel: events around every contraction
   # launch of one eager step on the launch stream.
   roof = None
@@ -183,9 +203,12 @@ def main():
     ach = tot_f / tot_t / 1e12
     roof = dict(
         bound='mfma',
-        kernel='k_mfma_gemm<*> (fp32 MFMA GEMM + implicit-GEMM conv, incl. split-K reduce)',
+        kernel='k_mfma_gemm_s3<*> (fp32 GEMM + implicit-GEMM conv on the bf16 matrix pipe: exact 3-way bf16 split, 6 products, fp32 accumulate; incl. split-K reduce)',
         achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
         frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        peak_note='157.3 = dense fp32-input MFMA peak (the dtype of the path); the split-bf16 '
+                  'loop is bounded by the bf16 MFMA rate / 6 = 397 TFLOP/s (2382 measured '
+                  'peak, MI355X_MICROARCH.md), frac of that = %.4f' % (ach / (2382.0 / 6)),
         traffic=None if pmc is None else pmc['bytes_per_launch'],
         traffic_source=None if pmc is None else pmc['source'],
         algorithmic_bytes_per_launch=round(alg_bytes / len(trace)),
@@ -222,6 +245,10 @@ def main():
             parallelism=f'dp{world}', hip_graphs=plan.n_graphs),
         pcie_inclusive=dict(value=round(B * world * T * H / dt_incl, 1),
                             ms_per_step=round(1e3 * dt_incl, 3)),
+        replay_inclusive=None if dt_replay is None else dict(
+            value=round(B * T * H / dt_replay, 1), ms_per_step=round(1e3 * dt_replay, 3),
+            note='DeviceReplay.sample_batch (dd_replay_gather from the HBM episode ring) + '
+                 'Agent.train per step, numpy metrics out'),
         step_algorithmic_tflop=None if step_flops is None else round(step_flops / 1e12, 4),
         step_mfma_frac=None if step_flops is None else round(
             step_flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

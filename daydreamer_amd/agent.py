@@ -25,6 +25,7 @@ import torch
 
 from . import config as config_mod
 from . import learner as learner_mod
+from . import replay as replay_mod
 from . import spec as spec_mod
 
 
@@ -181,11 +182,17 @@ class Agent:
   # ---------------------------------------------------------------------- API
 
   def dataset(self, generator_fn):
+    """Iterable of [B,T,...] minibatches (reference agent.py:108-121).  A
+    `DeviceReplay.dataset` generator is recognised and replaced by minibatches
+    gathered in HBM (no host staging); any other generator is zipped on the host."""
+    owner = getattr(generator_fn, '__self__', None)
+    if isinstance(owner, replay_mod.DeviceReplay):
+      return owner.batches(self.cfg['batch_size'])
     return Batcher(generator_fn, self.cfg['batch_size'])
 
   def train(self, data, state=None):
-    data = {k: np.asarray(v) for k, v in data.items()
-            if not k.startswith('log_')}
+    data = {k: (v if isinstance(v, torch.Tensor) else np.asarray(v))
+            for k, v in data.items() if not k.startswith('log_')}
     B, T = data['is_first'].shape[:2]
     L = self.learner
     if L is None or getattr(self, '_bootstrap', False) or (L.Bg, L.T) != (B, T):

@@ -364,6 +364,47 @@ extern "C" int dd_copy2d(const float* src, long lds, float* dst, long ldd, long 
   return 0;
 }
 
+// Replay minibatch assembly from an HBM-resident episode ring (byte rows): sample b is
+// the T consecutive ring rows starting at starts[b] (a chunk never wraps: episodes are
+// stored contiguously).  One workgroup column per sample, 16-byte lanes when the row
+// size allows (images, vectors), bytes otherwise (reward, flags).
+__global__ void __launch_bounds__(256)
+k_replay_gather(const unsigned char* __restrict__ ring, long row_bytes,
+                const long long* __restrict__ starts, int T, unsigned char* __restrict__ out,
+                int first_flag) {
+  const int b = blockIdx.y;
+  const long n = (long)T * row_bytes;
+  unsigned char* o = out + (long)b * n;
+  if (first_flag) {  // is_first of a sampled chunk: 1 at t = 0, else 0 (fixed_length.py:79-80)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+      o[i] = (i < row_bytes) ? 1 : 0;
+    return;
+  }
+  const unsigned char* s = ring + starts[b] * row_bytes;
+  if ((row_bytes & 15) == 0 && (((uintptr_t)ring | (uintptr_t)out) & 15) == 0) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    uint4* o4 = reinterpret_cast<uint4*>(o);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n / 16; i += (long)gridDim.x * 256)
+      o4[i] = s4[i];
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+      o[i] = s[i];
+  }
+}
+
+extern "C" int dd_replay_gather(const void* ring, long row_bytes, const long long* starts,
+                                int B, int T, void* out, int first_flag, void* stream) {
+  if (B <= 0 || T <= 0 || row_bytes <= 0) return 0;
+  const long n = (long)T * row_bytes;
+  long per = (n / 16 + 255) / 256;
+  if (per < 1) per = 1;
+  if (per > 64) per = 64;
+  k_replay_gather<<<dim3((unsigned)per, (unsigned)B), 256, 0, (hipStream_t)stream>>>(
+      (const unsigned char*)ring, row_bytes, starts, T, (unsigned char*)out, first_flag);
+  DD_CHECK_LAUNCH("dd_replay_gather");
+  return 0;
+}
+
 extern "C" int dd_reset_mask(const float* prev, long ldp, const float* first, long fstride,
                              const float* init, float* out, long ldo, long rows, int cols,
                              void* stream) {

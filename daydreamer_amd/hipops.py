@@ -65,6 +65,7 @@ _SIGS = {
     'dd_grad_norm': [c_p, c_l, c_p, c_p, c_z, c_p],
     'dd_adam_step': [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
     'dd_fill': [c_p, c_l, c_f, c_p],
+    'dd_replay_gather': [c_p, c_l, c_p, c_i, c_i, c_p, c_i, c_p],
     'dd_copy2d': [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
     'dd_reset_mask': [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_l, c_i, c_p],
     'dd_reset_mask_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p],
@@ -472,6 +473,17 @@ class HipOps:
     d, ldd = _mat(dst)
     self._check(self.lib.dd_copy2d(s, lds, d, ldd, rows, cols, self.stream),
                 'dd_copy2d')
+
+  def replay_gather(self, ring, starts, out, first_flag=False):
+    """out[b, t] = ring[starts[b] + t] over whole rows (any dtype); ring
+    [rows, ...], starts int64 [B] on the device, out [B, T, ...]."""
+    assert (first_flag or ring.is_contiguous()) and out.is_contiguous() and starts.dtype == torch.int64
+    B, T = out.shape[:2]
+    row_bytes = out[0, 0].numel() * out.element_size()
+    assert first_flag or (ring.dtype == out.dtype and ring[0].numel() * ring.element_size() == row_bytes)
+    self._check(self.lib.dd_replay_gather(
+        _ptr(ring), row_bytes, starts.data_ptr(), B, T, out.data_ptr(),
+        int(first_flag), self.stream), 'dd_replay_gather')
 
   def reset_mask(self, prev, first, init, out):
     rows, cols = out.shape

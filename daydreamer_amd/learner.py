@@ -791,29 +791,29 @@ class Learner:
   # ------------------------------------------------------------------ phases
 
   def upload(self, data):
-    """Host -> HBM staging of one replay minibatch (wire format)."""
+    """Stage one replay minibatch (wire format) into the learner's HBM buffers.
+    Values are host numpy arrays (copied over PCIe) or device tensors, e.g. from
+    replay.DeviceReplay.sample_batch (device-to-device)."""
     s, b = self.spec, self.b
     dev = self.device
-    def put(dst, arr, dtype=None):
-      t = torch.from_numpy(np.ascontiguousarray(arr))
-      if dtype is not None:
-        t = t.to(dtype)
-      dst.copy_(t.reshape(dst.shape).to(dev, non_blocking=True))
+    def tens(x):
+      if isinstance(x, torch.Tensor):
+        return x
+      return torch.from_numpy(np.ascontiguousarray(x)).to(dev, non_blocking=True)
+    def put(dst, t):
+      dst.copy_(t.reshape(dst.shape))  # copy_ converts dtype (bool -> uint8, f64 -> f32)
     if s.enc_cnn_keys:
-      imgs = [np.asarray(data[k]) for k in s.enc_cnn_keys]
-      put(b['image'], imgs[0] if len(imgs) == 1 else np.concatenate(imgs, -1))
+      imgs = [tens(data[k]) for k in s.enc_cnn_keys]
+      put(b['image'], imgs[0] if len(imgs) == 1 else torch.cat(imgs, -1))
     if s.enc_mlp_keys:
-      cols = []
-      for k in s.enc_mlp_keys:
-        v = np.asarray(data[k], np.float32).reshape(self.N, -1)
-        cols.append(v)
-      put(b['vec_in'], np.concatenate(cols, -1))
+      cols = [tens(data[k]).reshape(self.N, -1).to(b['vec_in'].dtype) for k in s.enc_mlp_keys]
+      put(b['vec_in'], cols[0] if len(cols) == 1 else torch.cat(cols, -1))
     for k in s.dec_mlp_keys:
-      put(b['vec_tgt'][k], np.asarray(data[k], np.float32))
-    put(b['action'], np.asarray(data['action'], np.float32))
-    put(b['reward'], np.asarray(data['reward'], np.float32))
-    put(b['is_first'], np.asarray(data['is_first']).astype(np.uint8))
-    put(b['is_terminal'], np.asarray(data['is_terminal']).astype(np.uint8))
+      put(b['vec_tgt'][k], tens(data[k]))
+    put(b['action'], tens(data['action']))
+    put(b['reward'], tens(data['reward']))
+    put(b['is_first'], tens(data['is_first']))
+    put(b['is_terminal'], tens(data['is_terminal']))
 
   def phase_prep(self):
     ops, b = self.ops, self.b

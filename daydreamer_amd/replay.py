@@ -1,0 +1,255 @@
+"""HBM-resident replay with the reference's `embodied.Replay` interface.
+
+`DeviceReplay` keeps the `FixedLength` semantics of the reference
+(embodied/replay/fixed_length.py:10-81 over a `RAMStore`, replay/store.py:10-57):
+whole episodes go in, uniformly sampled episode + uniformly sampled start give
+chunks of `chunk` steps whose `is_first[0]` is forced to True, episodes shorter
+than `chunk` / `minlen` are skipped, `log_` keys are dropped, dtypes are
+canonicalised as `embodied.convert` does (core/convert.py:4-23), and the oldest
+episodes are evicted while more than `capacity` steps are stored.
+
+What differs is where the bytes live.  Every key is one ring `[ring_steps, ...]`
+in HBM (uint8 images stay uint8: 12 KiB per 64x64x3 step, so 10^6 steps are
+12.3 GB of the 288 GB); an episode is one contiguous row range.  A training
+minibatch is assembled on the device by `dd_replay_gather` (one 16-byte-lane
+copy kernel per key) from B sampled row offsets, and `Agent.train` consumes the
+device tensors directly: the learner never waits for PCIe.  The sampler is the
+reference's: the same `np.random.RandomState(0)` call sequence on the host, so
+with the same episodes inserted in the same order it returns the same chunks
+(tests/test_replay.py checks this against the reference class itself and against
+committed golden picks).
+
+`dataset()` is the drop-in generator of host numpy chunks for unmodified callers
+(`run/learning.py:25`, `run/train.py:65`); `Agent.dataset(replay.dataset)`
+recognises a DeviceReplay and switches to device batches.
+
+Episodes travel between processes in the reference's on-disk format
+(`DiskStore._format/_save`, replay/store.py:123-153): `save(directory)` /
+`load(directory)` write and read `<time>-<uuid>-len<L>-rew<R>.npz`.
+"""
+
+import collections
+import io
+import pathlib
+import time as timelib
+import uuid
+
+import numpy as np
+import torch
+
+_CONVERSION = (
+    (np.floating, np.float32),
+    (np.signedinteger, np.int64),
+    (np.uint8, np.uint8),
+    (bool, bool),
+)
+
+
+def convert(value):
+  """core/convert.py:12-23."""
+  if not isinstance(value, np.ndarray):
+    value = np.array(value)
+  if value.dtype in (np.float32, np.int64, np.uint8, np.bool_):
+    return value
+  for src, dst in _CONVERSION:
+    if np.issubdtype(value.dtype, src):
+      return value.astype(dst)
+  raise TypeError(f'Unsupported dtype: {value.dtype}')
+
+
+class DeviceReplay:
+
+  def __init__(self, chunk=64, capacity=None, length=0, prio_starts=0.0,
+               prio_ends=1.0, minlen=0, seed=0, device='cuda:0', ops=None,
+               ring_steps=None, directory=None):
+    self.chunk = int(chunk)
+    self.capacity = capacity and int(capacity)
+    self.length = length
+    self.minlen = minlen
+    self.prio_starts = prio_starts
+    self.prio_ends = prio_ends
+    self.random = np.random.RandomState(seed=seed)
+    self.device = torch.device(device)
+    self._ops = ops
+    if ring_steps is None:
+      # eviction keeps <= capacity steps live (+ the episode being inserted); the slack
+      # absorbs the unused tail left when an episode does not fit before the wrap
+      ring_steps = (self.capacity + max(self.capacity // 4, 8 * self.chunk)
+                    if self.capacity else 1_000_000)
+    self.ring_steps = int(ring_steps)
+    self.directory = directory and pathlib.Path(directory)
+    self.rings = None            # key -> [ring_steps, ...] device tensor
+    self.table = collections.OrderedDict()  # episode id -> (offset, length), oldest first
+    self.steps = 0
+    self.head = 0
+    self.ongoing = collections.defaultdict(lambda: collections.defaultdict(list))
+    self._saved = set()
+    self._out = {}               # batch size -> output buffers
+
+  # ------------------------------------------------------------ embodied.Replay
+
+  def __len__(self):
+    return self.steps
+
+  @property
+  def stats(self):
+    return {'replay_steps': self.steps, 'replay_trajs': len(self.table)}
+
+  def add(self, tran, worker=0):
+    if tran['is_first']:
+      self.ongoing[worker].clear()
+    ep = self.ongoing[worker]
+    [ep[k].append(v) for k, v in tran.items()]
+    if tran['is_last'] or (self.length and len(ep['is_first']) >= self.length):
+      self.add_traj(self.ongoing.pop(worker))
+
+  def add_traj(self, traj, key=None):
+    length = len(next(iter(traj.values())))
+    if length < self.chunk or length < self.minlen:
+      print(f'Skipping short trajectory of length {length}.')
+      return None
+    traj = {k: convert(v) for k, v in traj.items() if not k.startswith('log_')}
+    if length > self.ring_steps:
+      raise ValueError(f'episode of {length} steps exceeds the ring ({self.ring_steps})')
+    if self.rings is None:
+      self.rings = {
+          k: torch.empty((self.ring_steps,) + v.shape[1:],
+                         dtype=torch.from_numpy(v[:1]).dtype, device=self.device)
+          for k, v in traj.items()}
+    if set(traj) != set(self.rings):
+      raise KeyError(f'episode keys {sorted(traj)} != replay keys {sorted(self.rings)}')
+    if self.head + length > self.ring_steps:
+      self.head = 0
+    lo, hi = self.head, self.head + length
+    # the ring is written in order, so whatever overlaps the new range is the oldest data
+    for old in [k for k, (o, n) in self.table.items() if o < hi and lo < o + n]:
+      self._drop(old)
+    for k, v in traj.items():
+      src = torch.from_numpy(np.ascontiguousarray(v))
+      self.rings[k][lo:hi].copy_(src.reshape(self.rings[k][lo:hi].shape))
+    key = key or uuid.uuid4().hex
+    self.table[key] = (lo, length)
+    self.steps += length
+    self.head = hi
+    while self.capacity and len(self.table) > 1 and self.steps > self.capacity:
+      self._drop(next(iter(self.table)))  # RAMStore._enforce_limit, store.py:51-56
+    return key
+
+  def dataset(self):
+    """Host-side chunks (numpy) for callers that batch themselves."""
+    while True:
+      pick = self._pick()
+      if pick is None:
+        print('Waiting for episodes.')
+        timelib.sleep(1)
+        continue
+      start = pick[1]
+      chunk = {k: r[start:start + self.chunk].cpu().numpy() for k, r in self.rings.items()}
+      chunk['is_first'] = np.zeros(self.chunk, bool)
+      chunk['is_first'][0] = True
+      yield chunk
+
+  def prioritize(self, keys, priorities):
+    pass
+
+  def save(self, directory=None):
+    """Write every not-yet-written episode as `<time>-<id>-len<L>-rew<R>.npz`
+    (store.py:123-153) and return the directory (None without one)."""
+    directory = pathlib.Path(directory) if directory else self.directory
+    if directory is None:
+      return None
+    directory.mkdir(parents=True, exist_ok=True)
+    for key, (off, n) in self.table.items():
+      if key in self._saved:
+        continue
+      traj = {k: r[off:off + n].cpu().numpy() for k, r in self.rings.items()}
+      stamp = timelib.strftime('%Y%m%dT%H%M%S', timelib.gmtime(timelib.time()))
+      reward = str(int(traj['reward'].sum())).replace('-', 'm') if 'reward' in traj else '0'
+      with io.BytesIO() as stream:
+        np.savez_compressed(stream, **traj)
+        (directory / f'{stamp}-{key}-len{n}-rew{reward}.npz').write_bytes(stream.getvalue())
+      self._saved.add(key)
+    return str(directory)
+
+  def load(self, data=None):
+    """Read the newest episodes of a directory up to `capacity` steps, oldest of
+    them first (DiskStore.sync, store.py:106-119)."""
+    directory = pathlib.Path(data) if data else self.directory
+    if directory is None or not directory.exists():
+      return
+    selected, steps = [], 0
+    for filename in reversed(sorted(directory.glob('*.npz'))):
+      _, key, length, _ = filename.stem.split('-')
+      length = int(length[3:])
+      if self.capacity and steps + length > self.capacity:
+        break
+      selected.append((filename, key))
+      steps += length
+    for filename, key in reversed(selected):
+      if key in self.table:
+        continue
+      with np.load(filename) as f:
+        traj = {k: f[k] for k in f.keys()}
+      if self.add_traj(traj, key=key) is not None:
+        self._saved.add(key)
+
+  # ------------------------------------------------------------------- native
+
+  @property
+  def ops(self):
+    if self._ops is None:
+      from . import hipops
+      self._ops = hipops.HipOps(self.device, ws_bytes=1 << 20)
+    return self._ops
+
+  def _drop(self, key):
+    _, n = self.table.pop(key)
+    self.steps -= n
+    self._saved.discard(key)
+
+  def _pick(self):
+    """FixedLength._sample, fixed_length.py:64-77: (episode id, first ring row)."""
+    keys = tuple(self.table.keys())
+    if not keys:
+      return None
+    key = keys[self.random.randint(0, len(keys))]
+    offset, total = self.table[key]
+    lower = 0
+    upper = total - self.chunk + 1
+    if self.prio_starts:
+      lower -= int(self.chunk * self.prio_starts)
+    if self.prio_ends:
+      upper += int(self.chunk * self.prio_ends)
+    index = self.random.randint(lower, upper)
+    index = int(np.clip(index, 0, total - self.chunk))
+    return key, offset + index
+
+  def sample_batch(self, batch):
+    """One [batch, chunk, ...] minibatch as device tensors (buffers are reused by the
+    next call on the same stream)."""
+    picks = []
+    while len(picks) < batch:
+      pick = self._pick()
+      if pick is None:
+        raise RuntimeError('DeviceReplay.sample_batch: no episodes stored')
+      picks.append(pick[1])
+    starts = torch.tensor(picks, dtype=torch.int64).to(self.device, non_blocking=True)
+    out = self._out.get(batch)
+    if out is None:
+      out = {k: torch.empty((batch, self.chunk) + tuple(r.shape[1:]), dtype=r.dtype,
+                            device=self.device) for k, r in self.rings.items()}
+      out['is_first'] = torch.empty((batch, self.chunk), dtype=torch.bool, device=self.device)
+      self._out[batch] = out
+    for k, r in self.rings.items():
+      if k != 'is_first':
+        self.ops.replay_gather(r, starts, out[k])
+    self.ops.replay_gather(None, starts, out['is_first'], first_flag=True)
+    return out
+
+  def batches(self, batch):
+    while True:
+      if not self.table:
+        print('Waiting for episodes.')
+        timelib.sleep(1)
+        continue
+      yield self.sample_batch(batch)

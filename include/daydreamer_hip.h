@@ -217,6 +217,13 @@ int dd_reset_mask_bwd(const float* dout, long ldo, const float* first, long fstr
 int dd_batch_prep(const unsigned char* is_first, const unsigned char* is_terminal,
                   const float* action, float* first_f, float* cont_f,
                   float* act_masked, long ldm, long n, int A, void* stream);
+/* Minibatch assembly from an HBM-resident replay ring: out[b, t, :] = ring[starts[b] + t, :]
+ * for row_bytes-byte rows (any dtype), b < B, t < T.  first_flag != 0 writes the
+ * chunk's is_first column instead (1 at t = 0, else 0).  Replaces the host-side
+ * slicing + np.stack + upload of FixedLength._sample / Prefetch.__next__ / TFAgent._convert_inps
+ * (replay/fixed_length.py:64-81, core/prefetch.py:55, tfagent.py:105-116). */
+int dd_replay_gather(const void* ring, long row_bytes, const long long* starts, int B, int T,
+                     void* out, int first_flag, void* stream);
 int dd_tanh_fwd(const float* x, float* y, int n, void* stream);
 int dd_tanh_bwd(const float* x, const float* dy, float* dx, int n, float beta, void* stream);
 

@@ -511,6 +511,15 @@ class RefOps:
   def copy2d(self, src, dst):
     dst.copy_(src)
 
+  def replay_gather(self, ring, starts, out, first_flag=False):
+    B, T = out.shape[:2]
+    if first_flag:
+      out.zero_()
+      out[:, 0] = 1
+      return
+    idx = starts.reshape(B, 1) + torch.arange(T, device=starts.device).reshape(1, T)
+    out.copy_(ring[idx.reshape(-1)].reshape(out.shape))
+
   def reset_mask(self, prev, first, init, out):
     f = first.reshape(-1, 1)
     pv = prev if prev is not None else torch.zeros_like(out)

@@ -413,3 +413,24 @@ def test_misc(hip, ref):
   x, dy, dx = rnd(256, seed=5), rnd(256, seed=6), rnd(256, seed=7)
   res = both(hip, ref, lambda ops, x, dy, dx: ops.tanh_bwd(x, dy, dx, 1.0), [x, dy, dx], [2])
   close(*res[0], rtol=1e-5, what='tanh_bwd')
+
+
+@pytest.mark.parametrize('shape,dtype', [((64, 64, 3), torch.uint8), ((16,), torch.float32),
+                                         ((), torch.float32), ((7,), torch.int64), ((), torch.bool)])
+def test_replay_gather(hip, ref, shape, dtype):
+  """dd_replay_gather: byte-exact rows for every wire dtype and row size (16-byte
+  lanes for images / vectors, bytes for 4- and 1-byte rows)."""
+  g = torch.Generator().manual_seed(3)
+  ring = torch.randint(0, 2 if dtype == torch.bool else 200, (300,) + shape, generator=g).to(dtype)
+  starts = torch.tensor([0, 288, 17, 100, 33], dtype=torch.int64)
+  out_c = torch.zeros((5, 12) + shape, dtype=dtype)
+  ref.replay_gather(ring, starts, out_c)
+  out_g = torch.zeros((5, 12) + shape, dtype=dtype, device='cuda')
+  hip.replay_gather(ring.cuda(), starts.cuda(), out_g)
+  torch.cuda.synchronize()
+  assert torch.equal(out_g.cpu(), out_c)
+  f_c = torch.ones(5, 12, dtype=torch.bool)
+  f_g = torch.ones(5, 12, dtype=torch.bool, device='cuda')
+  ref.replay_gather(None, starts, f_c, first_flag=True)
+  hip.replay_gather(None, starts.cuda(), f_g, first_flag=True)
+  assert torch.equal(f_g.cpu(), f_c) and bool(f_c[:, 0].all()) and not bool(f_c[:, 1:].any())

@@ -194,3 +194,32 @@ def test_training_reduces_loss_through_agent(hip):
   a, st = ag.policy(o, None, 'train')
   a2, st = ag.policy({**o, 'is_first': np.array([False])}, st, 'eval')
   assert a['action'].shape == (1, 3) and np.isfinite(a2['action']).all()
+
+
+def test_training_from_device_replay(hip):
+  """embodied.Replay on the GPU: episodes in an HBM ring, Agent.dataset(replay.dataset)
+  yields device minibatches (dd_replay_gather), Agent.train consumes them without a
+  host copy.  The first step equals the step on the same minibatch passed as numpy."""
+  import numpy as np
+  from daydreamer_amd import agent as agent_mod, replay as replay_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=6, replay_chunk=8, imag_horizon=4)
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  rep = replay_mod.DeviceReplay(chunk=8, capacity=2000)
+  for e in range(6):
+    ep = synthetic.make_batch(obs, act, 1, 40, seed=e, terminals=0.0, smooth_images=True)
+    for t in range(40):
+      rep.add({**{k: v[0, t] for k, v in ep.items()}, 'is_first': t == 0, 'is_last': t == 39})
+  assert rep.stats == {'replay_steps': 240, 'replay_trajs': 6}
+  ag, ag2 = agent_mod.Agent(obs, act, None, cfg), agent_mod.Agent(obs, act, None, cfg)
+  ds = ag.dataset(rep.dataset)
+  batch = next(ds)
+  assert batch['image'].is_cuda and batch['image'].dtype == torch.uint8
+  host = {k: v.cpu().numpy() for k, v in batch.items()}
+  _, state, m1 = ag.train(batch)
+  _, _, m2 = ag2.train(host)
+  for k in m1:
+    assert np.array_equal(m1[k], m2[k], equal_nan=True), k
+  for i in range(6):  # graph replay on fresh device minibatches
+    _, state, mets = ag.train(next(ds), state)
+    assert all(np.isfinite(v) for v in mets.values()), i
+  assert ag._plan is not None
