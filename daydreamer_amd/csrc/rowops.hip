@@ -326,21 +326,30 @@ k_ln_param_grad(const float* __restrict__ dout, long ldd, const float* __restric
   }
 }
 
-// out[w] = beta*out[w] + sum_p partials[p*stride + w]
-// block = 64 columns x 4 partial lanes (coalesced 256-B rows, 4-way split of P).
+// Several outputs in one launch: out_j[w] = beta*out_j[w] + sum_p partials[p*stride + j*W + w]
+// (the fused LayerNorm-backward partials are [P][nout][W]).  Block = 16 columns x 16 partial
+// lanes, grid (ceil(W/16), nout): the three separate 64x4 passes it replaces took ~15 us
+// each, more than the LayerNorm kernel they follow on mid-size problems.
 __global__ void __launch_bounds__(256)
-k_col_reduce(const float* __restrict__ partials, int P, long stride, int W,
-             float* __restrict__ out, float beta) {
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int w = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (w < W)
-    for (int p = pl; p < P; p += 4) s += partials[(long)p * stride + w];
-  __shared__ float sh[4][64];
-  sh[pl][cl] = s;
+k_col_reduce_n(const float* __restrict__ partials, int P, long stride, int W,
+               float* o0, float* o1, float* o2, float beta) {
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int w = blockIdx.x * 16 + cl, j = blockIdx.y;
+  float* out = j == 0 ? o0 : (j == 1 ? o1 : o2);
+  float s0 = 0.f, s1 = 0.f;
+  if (w < W) {
+    const float* q = partials + (long)j * W + w;
+    int p = pl;
+    for (; p + 16 < P; p += 32) { s0 += q[(long)p * stride]; s1 += q[(long)(p + 16) * stride]; }
+    if (p < P) s0 += q[(long)p * stride];
+  }
+  __shared__ float sh[16][17];
+  sh[pl][cl] = s0 + s1;
   __syncthreads();
   if (pl == 0 && w < W) {
-    float t = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][cl];
     out[w] = (beta != 0.f ? beta * out[w] : 0.f) + t;
   }
 }
@@ -522,7 +531,6 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
   hipStream_t st = (hipStream_t)stream;
   const bool want = dgamma != nullptr;
   const float b = accumulate ? 1.f : 0.f;
-  const int nb = (C + 63) / 64;
   const bool vec = C % 4 == 0 && C <= 1024 && ldd % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 &&
                    lddz % 4 == 0 && al16(dout) && al16(z) && al16(out) && al16(dz) && al16(gamma);
   if (vec) {
@@ -532,16 +540,18 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
       long groups = (rows + RPW - 1) / RPW;
       // (one 256-block wave of the grid leaves 4 waves per CU: too few loads in flight for
       // the big convolutional LayerNorms, 1.7 TB/s; 8 blocks per CU reach the HBM rate)
-      int blocks = want ? row_blocks(groups, groups > 200000 ? 2048 : 256) : row_blocks(groups, 1 << 20);
+      // (enough blocks to keep a memory-bound kernel's loads in flight - 256 blocks ran the
+      // big convolutional LayerNorms at 1.7 TB/s - but few enough partial rows for the
+      // reduce pass; measured: 512 / 8192 beat proportional grids)
+      int blocks = want ? row_blocks(groups, groups > 200000 ? 8192 : 512) : row_blocks(groups, 1 << 20);
       size_t shmem = want ? (size_t)WPB * RPW * 3 * C * sizeof(float) : 0;
       if (want) DD_REQUIRE(ws && (size_t)blocks * 3 * C * sizeof(float) <= ws_bytes, "dd_ln_act_bwd: workspace too small");
       k_ln_act_bwd_v<LPR, V><<<blocks, 256, shmem, st>>>(
           dout, ldd, z, ldz, out, ldo, stats, lds, gamma, dz, lddz, want ? ws : nullptr, rows, C, act);
       DD_CHECK_LAUNCH("dd_ln_act_bwd");
       if (want) {
-        k_col_reduce<<<nb, 256, 0, st>>>(ws, blocks, 3L * C, C, dgamma, b);
-        k_col_reduce<<<nb, 256, 0, st>>>(ws + C, blocks, 3L * C, C, dbeta, b);
-        if (dbias_pre) k_col_reduce<<<nb, 256, 0, st>>>(ws + 2 * C, blocks, 3L * C, C, dbias_pre, b);
+        k_col_reduce_n<<<dim3((C + 15) / 16, dbias_pre ? 3 : 2), 256, 0, st>>>(
+            ws, blocks, 3L * C, C, dgamma, dbeta, dbias_pre, b);
         DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce)");
       }
       return 0;
@@ -564,10 +574,8 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
     DD_CHECK_LAUNCH("dd_ln_act_bwd(param grad)");
   }
   // partials are [parts][2][C]: gamma rows at stride 2C from ws, beta rows from ws + C.
-  k_col_reduce<<<nb, 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, b);
-  DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce gamma)");
-  k_col_reduce<<<nb, 256, 0, st>>>(ws + C, parts, 2L * C, C, dbeta, b);
-  DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce beta)");
+  k_col_reduce_n<<<dim3((C + 15) / 16, 2), 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, dbeta, nullptr, b);
+  DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce)");
   if (dbias_pre) return dd_col_sum(dz, lddz, dbias_pre, b, rows, C, ws, ws_bytes, stream);
   return 0;
 }
@@ -586,12 +594,9 @@ extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, lon
   dim3 grid((C + 63) / 64, parts);
   k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, lds, ws, rows, C, act);
   DD_CHECK_LAUNCH("dd_ln_param_grad");
-  const int nb = (C + 63) / 64;
   const float b = accumulate ? 1.f : 0.f;
-  k_col_reduce<<<nb, 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, b);
-  DD_CHECK_LAUNCH("dd_ln_param_grad(reduce gamma)");
-  k_col_reduce<<<nb, 256, 0, st>>>(ws + C, parts, 2L * C, C, dbeta, b);
-  DD_CHECK_LAUNCH("dd_ln_param_grad(reduce beta)");
+  k_col_reduce_n<<<dim3((C + 15) / 16, 2), 256, 0, st>>>(ws, parts, 2L * C, C, dgamma, dbeta, nullptr, b);
+  DD_CHECK_LAUNCH("dd_ln_param_grad(reduce)");
   return 0;
 }
 
@@ -628,7 +633,7 @@ extern "C" int dd_col_sum(const float* x, long ldx, float* out, float beta, long
   dim3 grid((C + 63) / 64, parts);
   k_col_sum<<<grid, 256, 0, st>>>(x, ldx, ws, rows, C);
   DD_CHECK_LAUNCH("dd_col_sum");
-  k_col_reduce<<<(C + 63) / 64, 256, 0, st>>>(ws, parts, (long)C, C, out, beta);
+  k_col_reduce_n<<<dim3((C + 15) / 16, 1), 256, 0, st>>>(ws, parts, (long)C, C, out, nullptr, nullptr, beta);
   DD_CHECK_LAUNCH("dd_col_sum(reduce)");
   return 0;
 }
