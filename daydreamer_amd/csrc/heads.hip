@@ -125,29 +125,44 @@ k_normal_head_bwd(const float* __restrict__ om, long ldm, const float* __restric
   if (lane == 0 && ent_row) ent_row[r] = (r < rows_ent) ? w[r] * er : 0.f;
 }
 
-// Per action dimension: sum and sum of squares (fp64) of the normalised
-// entropy over the first `rows` rows.  Single block.
-__global__ void __launch_bounds__(1024)
-k_actent_stats(const float* __restrict__ os, long ldsd, int rows, int A, float lo, float hi,
-               float ent_lo, float ent_div, double* __restrict__ out) {
-  __shared__ double sh[2][16];
-  for (int a = 0; a < A; ++a) {
-    double s = 0.0, q = 0.0;
-    for (long r = threadIdx.x; r < rows; r += 1024) {
+// Per action dimension: sum and sum of squares (fp64) of the normalised entropy over
+// the first `rows` rows.  Two deterministic stages: thread (a, l) of a block walks rows
+// l, l+L, ... of the block's chunk (a row's A values are one coalesced segment), lanes are
+// combined through LDS in fixed order into partial[block][2][A]; one small block then adds
+// the partials in block order.
+__global__ void __launch_bounds__(256)
+k_actent_partial(const float* __restrict__ os, long ldsd, int rows, int A, int rows_per_block,
+                 float lo, float hi, float ent_lo, float ent_div, double* __restrict__ partial) {
+  extern __shared__ double shd[];  // [L][2][A]
+  const int L = 256 / A;
+  const int a = threadIdx.x % A, l = threadIdx.x / A;
+  double s = 0.0, q = 0.0;
+  if (l < L) {
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long r = r0 + l; r < r1; r += L) {
       float std = (hi - lo) * sigmoidf_(os[r * ldsd + a]) + lo;
       float e = (logf(std) - ent_lo) / ent_div;
       s += e; q += (double)e * e;
     }
-    s = wave_sum_d(s); q = wave_sum_d(q);
-    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double ts = 0.0, tq = 0.0;
-      for (int i = 0; i < 16; ++i) { ts += sh[0][i]; tq += sh[1][i]; }
-      out[a] = ts; out[A + a] = tq;
-    }
-    __syncthreads();
+    shd[(l * 2 + 0) * A + a] = s;
+    shd[(l * 2 + 1) * A + a] = q;
   }
+  __syncthreads();
+  if (threadIdx.x < 2 * A) {
+    double t = 0.0;
+    for (int i = 0; i < L; ++i) t += shd[i * 2 * A + threadIdx.x];
+    partial[(long)blockIdx.x * 2 * A + threadIdx.x] = t;
+  }
+}
+
+__global__ void k_actent_final(const double* __restrict__ partial, int P, int A, double* __restrict__ out) {
+  const int j = threadIdx.x;
+  if (j >= 2 * A) return;
+  double t = 0.0;
+  for (int p = 0; p < P; ++p) t += partial[(long)p * 2 * A + j];
+  out[j] = t;
 }
 
 // Thread per imagined trajectory (column n), sequential over the horizon.
@@ -364,9 +379,20 @@ extern "C" int dd_normal_head_bwd(const float* om, long ldm, const float* os, lo
 }
 
 extern "C" int dd_actent_stats(const float* os, long ldsd, int rows, int A, float lo, float hi,
-                               float ent_lo, float ent_div, double* out, void* stream) {
-  k_actent_stats<<<1, 1024, 0, (hipStream_t)stream>>>(os, ldsd, rows, A, lo, hi, ent_lo, ent_div, out);
+                               float ent_lo, float ent_div, double* out, double* ws,
+                               size_t ws_bytes, void* stream) {
+  DD_REQUIRE(A >= 1 && A <= 128, "dd_actent_stats: 1 <= A <= 128");
+  const int L = 256 / A;
+  int P = (rows + L * 16 - 1) / (L * 16);
+  if (P > 256) P = 256;
+  if (P < 1) P = 1;
+  DD_REQUIRE(ws && (size_t)P * 2 * A * sizeof(double) <= ws_bytes, "dd_actent_stats: workspace too small");
+  const int rpb = (rows + P - 1) / P;
+  k_actent_partial<<<P, 256, (size_t)L * 2 * A * sizeof(double), (hipStream_t)stream>>>(
+      os, ldsd, rows, A, rpb, lo, hi, ent_lo, ent_div, ws);
   DD_CHECK_LAUNCH("dd_actent_stats");
+  k_actent_final<<<1, 2 * A <= 64 ? 64 : 256, 0, (hipStream_t)stream>>>(ws, P, A, out);
+  DD_CHECK_LAUNCH("dd_actent_stats(final)");
   return 0;
 }
 

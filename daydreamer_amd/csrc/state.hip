@@ -177,10 +177,14 @@ k_sumsq_partial(const float* __restrict__ g, long n, double* __restrict__ partia
 }
 
 // opt_state: [0]=step (as double), [1]=grad norm, [2]=finite flag
-__global__ void k_norm_finalize(const double* __restrict__ partial, int P, double* __restrict__ st) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (one wave: lane l adds partials l, l+64, ...; fixed butterfly order - a single thread
+// walking ~1000 partials took 68 us, three times per step)
+__global__ void __launch_bounds__(64)
+k_norm_finalize(const double* __restrict__ partial, int P, double* __restrict__ st) {
   double s = 0.0;
-  for (int i = 0; i < P; ++i) s += partial[i];
+  for (int i = threadIdx.x; i < P; i += 64) s += partial[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x != 0) return;
   double norm = sqrt(s);
   st[1] = norm;
   bool fin = isfinite(norm);
@@ -246,6 +250,41 @@ __global__ void k_reset_mask_bwd(const float* __restrict__ dout, long ldo, const
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i / cols; int c = (int)(i - r * cols);
     dprev[r * ldp + c] += dout[r * ldo + c] * (1.f - first[r * fstride]);
+  }
+}
+
+// Two column segments (deter | stoch of the carried state) in one launch.
+__global__ void k_reset_mask2(const float* __restrict__ pa, long ldpa, const float* __restrict__ ia,
+                              float* __restrict__ oa, long ldoa, int ca,
+                              const float* __restrict__ pb, long ldpb, const float* __restrict__ ib,
+                              float* __restrict__ ob, long ldob, int cb,
+                              const float* __restrict__ first, long fstride, long rows) {
+  const int cols = ca + cb;
+  long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cols; int c = (int)(i - r * cols);
+    float f = first[r * fstride];
+    if (c < ca) {
+      float pv = pa ? pa[r * ldpa + c] : 0.f, iv = ia ? ia[c] : 0.f;
+      oa[r * ldoa + c] = pv * (1.f - f) + iv * f;
+    } else {
+      c -= ca;
+      float pv = pb ? pb[r * ldpb + c] : 0.f, iv = ib ? ib[c] : 0.f;
+      ob[r * ldob + c] = pv * (1.f - f) + iv * f;
+    }
+  }
+}
+
+__global__ void k_reset_mask_bwd2(const float* __restrict__ da, long ldda, float* __restrict__ pa, long ldpa, int ca,
+                                  const float* __restrict__ db, long lddb, float* __restrict__ pb, long ldpb, int cb,
+                                  const float* __restrict__ first, long fstride, long rows) {
+  const int cols = ca + cb;
+  long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cols; int c = (int)(i - r * cols);
+    float g = 1.f - first[r * fstride];
+    if (c < ca) pa[r * ldpa + c] += da[r * ldda + c] * g;
+    else { c -= ca; pb[r * ldpb + c] += db[r * lddb + c] * g; }
   }
 }
 
@@ -335,7 +374,7 @@ extern "C" int dd_grad_norm(const float* g, long n, double* opt_state, double* w
   DD_REQUIRE(ws && (size_t)P * sizeof(double) <= ws_bytes, "dd_grad_norm: workspace too small");
   k_sumsq_partial<<<P, 256, 0, (hipStream_t)stream>>>(g, n, ws);
   DD_CHECK_LAUNCH("dd_grad_norm");
-  k_norm_finalize<<<1, 1, 0, (hipStream_t)stream>>>(ws, P, opt_state);
+  k_norm_finalize<<<1, 64, 0, (hipStream_t)stream>>>(ws, P, opt_state);
   DD_CHECK_LAUNCH("dd_grad_norm(finalize)");
   return 0;
 }
@@ -419,6 +458,26 @@ extern "C" int dd_reset_mask_bwd(const float* dout, long ldo, const float* first
   if (rows * cols <= 0) return 0;
   k_reset_mask_bwd<<<gsz(rows * cols), 256, 0, (hipStream_t)stream>>>(dout, ldo, first, fstride, dprev, ldp, rows, cols);
   DD_CHECK_LAUNCH("dd_reset_mask_bwd");
+  return 0;
+}
+
+extern "C" int dd_reset_mask2(const float* prev_a, long ldpa, const float* init_a, float* out_a, long ldoa, int cols_a,
+                              const float* prev_b, long ldpb, const float* init_b, float* out_b, long ldob, int cols_b,
+                              const float* first, long fstride, long rows, void* stream) {
+  if (rows * (cols_a + cols_b) <= 0) return 0;
+  k_reset_mask2<<<gsz(rows * (cols_a + cols_b)), 256, 0, (hipStream_t)stream>>>(
+      prev_a, ldpa, init_a, out_a, ldoa, cols_a, prev_b, ldpb, init_b, out_b, ldob, cols_b, first, fstride, rows);
+  DD_CHECK_LAUNCH("dd_reset_mask2");
+  return 0;
+}
+
+extern "C" int dd_reset_mask_bwd2(const float* dout_a, long ldda, float* dprev_a, long ldpa, int cols_a,
+                                  const float* dout_b, long lddb, float* dprev_b, long ldpb, int cols_b,
+                                  const float* first, long fstride, long rows, void* stream) {
+  if (rows * (cols_a + cols_b) <= 0) return 0;
+  k_reset_mask_bwd2<<<gsz(rows * (cols_a + cols_b)), 256, 0, (hipStream_t)stream>>>(
+      dout_a, ldda, dprev_a, ldpa, cols_a, dout_b, lddb, dprev_b, ldpb, cols_b, first, fstride, rows);
+  DD_CHECK_LAUNCH("dd_reset_mask_bwd2");
   return 0;
 }
 

@@ -48,7 +48,7 @@ _SIGS = {
     'dd_scalar_loss': [c_p, c_p, c_p, c_p, c_l, c_f, c_i, c_p],
     'dd_normal_head_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_f, c_p],
     'dd_normal_head_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p],
-    'dd_actent_stats': [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p],
+    'dd_actent_stats': [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p, c_z, c_p],
     'dd_imag_returns_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_p],
     'dd_imag_returns_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_p],
     'dd_critic_loss': [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
@@ -65,6 +65,8 @@ _SIGS = {
     'dd_grad_norm': [c_p, c_l, c_p, c_p, c_z, c_p],
     'dd_adam_step': [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
     'dd_fill': [c_p, c_l, c_f, c_p],
+    'dd_reset_mask2': [c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_l, c_p],
+    'dd_reset_mask_bwd2': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p],
     'dd_replay_gather': [c_p, c_l, c_p, c_i, c_i, c_p, c_i, c_p],
     'dd_copy2d': [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
     'dd_reset_mask': [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_l, c_i, c_p],
@@ -360,7 +362,7 @@ class HipOps:
     b, ldb = _mat(os)
     self._check(self.lib.dd_actent_stats(
         b, ldb, rows, os.shape[1], lo, hi, ent_lo, ent_div, out.data_ptr(),
-        self.stream), 'dd_actent_stats')
+        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_actent_stats')
 
   def imag_returns_fwd(self, rew_raw, val_raw, cont_raw, first_cont, reward,
                        value, cont, weight, ret, H, N, gamma, lam):
@@ -493,6 +495,24 @@ class HipOps:
     self._check(self.lib.dd_reset_mask(
         p, ldp, f, fs, _ptr(init), o, ldo, rows, cols, self.stream),
         'dd_reset_mask')
+
+  def reset_mask2(self, prev_a, init_a, out_a, prev_b, init_b, out_b, first):
+    rows = out_a.shape[0]
+    pa, ldpa = _mat(prev_a) if prev_a is not None else (0, 0)
+    pb, ldpb = _mat(prev_b) if prev_b is not None else (0, 0)
+    f, fs = _vec(first)
+    self._check(self.lib.dd_reset_mask2(
+        pa, ldpa, _ptr(init_a), *_mat(out_a), out_a.shape[1],
+        pb, ldpb, _ptr(init_b), *_mat(out_b), out_b.shape[1], f, fs, rows,
+        self.stream), 'dd_reset_mask2')
+
+  def reset_mask_bwd2(self, dout_a, dprev_a, dout_b, dprev_b, first):
+    rows = dout_a.shape[0]
+    f, fs = _vec(first)
+    self._check(self.lib.dd_reset_mask_bwd2(
+        *_mat(dout_a), *_mat(dprev_a), dout_a.shape[1],
+        *_mat(dout_b), *_mat(dprev_b), dout_b.shape[1], f, fs, rows,
+        self.stream), 'dd_reset_mask_bwd2')
 
   def reset_mask_bwd(self, dout, first, dprev):
     rows, cols = dout.shape

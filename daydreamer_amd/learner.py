@@ -705,8 +705,8 @@ class Learner:
         pd, ps = post[:, t - 1, :D], post[:, t - 1, D:]
       hprev = sel(b['hprev'])
       xin = sel(b['xin'])
-      ops.reset_mask(pd, first[:, t], b['init_deter'], hprev)
-      ops.reset_mask(ps, first[:, t], b['init_stoch'], xin[:, :S])
+      ops.reset_mask2(pd, b['init_deter'], hprev, ps, b['init_stoch'], xin[:, :S],
+                      first[:, t])
       self.core_fwd(xin, hprev, post[:, t, :D], self.a_img_in, b['z3'],
                     b['gstats'], sel, gin=b['gin'])
       # posterior: obs_out on concat[deter, embed]; embed part already in z
@@ -756,8 +756,8 @@ class Learner:
                     sel(b['dhprev']), sel(b['dxin_s']), 0.0, P['img_in_s'],
                     dgin=b['dgin'])
       if t > 0:
-        ops.reset_mask_bwd(sel(b['dhprev']), first[:, t], dfeat[:, t - 1, :D])
-        ops.reset_mask_bwd(sel(b['dxin_s']), first[:, t], dfeat[:, t - 1, D:])
+        ops.reset_mask_bwd2(sel(b['dhprev']), dfeat[:, t - 1, :D],
+                            sel(b['dxin_s']), dfeat[:, t - 1, D:], first[:, t])
     # ---- bulk parameter gradients of the scan layers over all T steps
     m = self.groups['model']
     lnp = lambda L, A: ops.ln_param_grad(A.dout, A.z, A.out, A.stats, L.dgamma,

@@ -155,7 +155,8 @@ int dd_normal_head_bwd(const float* om, long ldm, const float* os, long ldsd,
                        int rows, int rows_ent, int A, float lo, float hi,
                        float ent_coef, float ent_lo, float ent_div, void* stream);
 int dd_actent_stats(const float* os, long ldsd, int rows, int A, float lo, float hi,
-                    float ent_lo, float ent_div, double* out, void* stream);
+                    float ent_lo, float ent_div, double* out, double* ws,
+                    size_t ws_bytes, void* stream);
 /* symexp / sigmoid of the head outputs, discount weights agent.py:256-259 and
  * the 'gve' lambda-return agent.py:434-440, one thread per trajectory. */
 int dd_imag_returns_fwd(const float* rew_raw, const float* val_raw, const float* cont_raw,
@@ -214,6 +215,14 @@ int dd_reset_mask(const float* prev, long ldp, const float* first, long fstride,
                   const float* init, float* out, long ldo, long rows, int cols, void* stream);
 int dd_reset_mask_bwd(const float* dout, long ldo, const float* first, long fstride,
                       float* dprev, long ldp, long rows, int cols, void* stream);
+/* The same for two column segments at once (the [deter | stoch] halves of the carried
+ * state go to different buffers): one launch per scan step instead of two. */
+int dd_reset_mask2(const float* prev_a, long ldpa, const float* init_a, float* out_a, long ldoa, int cols_a,
+                   const float* prev_b, long ldpb, const float* init_b, float* out_b, long ldob, int cols_b,
+                   const float* first, long fstride, long rows, void* stream);
+int dd_reset_mask_bwd2(const float* dout_a, long ldda, float* dprev_a, long ldpa, int cols_a,
+                       const float* dout_b, long lddb, float* dprev_b, long ldpb, int cols_b,
+                       const float* first, long fstride, long rows, void* stream);
 int dd_batch_prep(const unsigned char* is_first, const unsigned char* is_terminal,
                   const float* action, float* first_f, float* cont_f,
                   float* act_masked, long ldm, long n, int A, void* stream);

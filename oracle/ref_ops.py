@@ -526,6 +526,14 @@ class RefOps:
     iv = init.reshape(1, -1) if init is not None else 0.0
     out.copy_(pv * (1 - f) + iv * f)
 
+  def reset_mask2(self, prev_a, init_a, out_a, prev_b, init_b, out_b, first):
+    self.reset_mask(prev_a, first, init_a, out_a)
+    self.reset_mask(prev_b, first, init_b, out_b)
+
+  def reset_mask_bwd2(self, dout_a, dprev_a, dout_b, dprev_b, first):
+    self.reset_mask_bwd(dout_a, first, dprev_a)
+    self.reset_mask_bwd(dout_b, first, dprev_b)
+
   def reset_mask_bwd(self, dout, first, dprev):
     dprev.add_(dout * (1 - first.reshape(-1, 1)))
 

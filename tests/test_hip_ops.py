@@ -434,3 +434,26 @@ def test_replay_gather(hip, ref, shape, dtype):
   ref.replay_gather(None, starts, f_c, first_flag=True)
   hip.replay_gather(None, starts.cuda(), f_g, first_flag=True)
   assert torch.equal(f_g.cpu(), f_c) and bool(f_c[:, 0].all()) and not bool(f_c[:, 1:].any())
+
+
+def test_reset_mask_pairs_and_actent_large(hip, ref):
+  """Two-segment reset kernels (views with leading dimensions, null prev) and the
+  two-stage entropy statistics at the step's size and an odd action width."""
+  post = rnd(50, 40, seed=1)
+  first = (torch.rand(50, 4) > 0.6).float()
+  ia, ib = rnd(24, seed=2), rnd(16, seed=3)
+  oa, ob = torch.zeros(50, 30), torch.zeros(50, 64)
+  da, db = rnd(50, 24, seed=4), rnd(50, 16, seed=5)
+  def fn(ops, post, first, ia, ib, oa, ob, da, db):
+    ops.reset_mask2(post[:, :24], ia, oa[:, 3:27], post[:, 24:], ib, ob[:, 40:56], first[:, 1])
+    ops.reset_mask_bwd2(da, post[:, :24], db, post[:, 24:], first[:, 1])
+    ops.reset_mask2(None, ia, oa[:, 3:27], None, None, ob[:, :16], first[:, 2])
+  res = both(hip, ref, fn, [post, first, ia, ib, oa, ob, da, db], [0, 4, 5])
+  for g, c in res:
+    close(g, c, rtol=0, atol=0, what='reset_mask2')
+  for rows, A in ((40000, 16), (37, 6), (5000, 3)):
+    os_ = rnd(rows + 5, 2 * A, seed=6)
+    out = torch.zeros(2 * A, dtype=torch.float64)
+    res = both(hip, ref, lambda ops, os_, out: ops.actent_stats(os_[:, A:], rows, 0.1, 1.0, -2.3, 2.3, out),
+               [os_, out], [1])
+    close(*res[0], rtol=1e-6, what=f'actent_stats {rows}x{A}')
