@@ -86,6 +86,8 @@ def main():
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--config', default='a1_vision')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--pipeline', type=int, default=1,
+                  help='hip.pipeline (two-stream pipeline of consecutive steps; single GPU)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', 1))
@@ -104,7 +106,7 @@ def main():
       dist.init_process_group(backend)
   assert world == args.gpus, (world, args.gpus)
 
-  cfg = make_config(args.config)
+  cfg = make_config(args.config).update({'hip.pipeline': bool(args.pipeline)})
   plain = config_mod.to_plain(cfg)
   B, T, H = plain['batch_size'], plain['replay_chunk'], plain['imag_horizon']
   obs, act = synthetic.make_spaces(64, 16, 16)
@@ -125,7 +127,11 @@ def main():
   L = agent.learner
   plan = agent._plan
 
+  pipelined = isinstance(plan, agent_mod.Pipeline)
+
   def resident_step():
+    if pipelined:  # enqueue step k, read the metrics of step k-1
+      return plan.step()
     plan.replay()
     return L.read_metrics()
 
@@ -133,7 +139,8 @@ def main():
   barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    mets = resident_step()
+    mets = resident_step() or mets
+  mets = agent.flush() or mets  # (pipeline: the last step's behaviour phase is inside the timed region)
   barrier()
   dt = time.perf_counter() - t0
   if world > 1:
@@ -242,7 +249,9 @@ def main():
                       'per GPU, rssm deter 256 / stoch 32x32, one full '
                       'Agent.train step (world model + critic + actor updates)'),
             global_batch=B * world, seq_len=T, horizon=H,
-            parallelism=f'dp{world}', hip_graphs=plan.n_graphs),
+            parallelism=f'dp{world}', hip_graphs=plan.n_graphs,
+            pipeline=('two-stream: behaviour phase of step k overlaps world-model phase of step k+1'
+                      if pipelined else 'off')),
         pcie_inclusive=dict(value=round(B * world * T * H / dt_incl, 1),
                             ms_per_step=round(1e3 * dt_incl, 3)),
         replay_inclusive=None if dt_replay is None else dict(

@@ -75,6 +75,100 @@ class Batcher:
     return batch
 
 
+class Pipeline:
+  """Two-stream software pipeline of the train step (hip.pipeline: true).
+
+  A step is  A1 (world-model forward + backward)  ->  A2 (world-model optimizer,
+  hand-over copies)  ->  B (imagination, critic and actor updates).  B(k) only reads
+  world-model weights and its own buffers, A1(k+1) only reads weights: they are
+  independent, and between them they mix the GPU-filling convolution / head
+  contractions with the latency-bound recurrent scans.  So B(k) is replayed on a
+  second stream while A1(k+1) runs on the first; A2(k+1), which writes the world-model
+  weights, waits for B(k).  The arithmetic and its order inside every phase are those
+  of the sequential step (parameters after n steps are bit-identical,
+  tests/test_learner_gpu.py); only the metrics come back one call late.
+  """
+
+  def __init__(self, learner, device):
+    self.L = learner
+    self.device = device
+    # dedicated streams for both phases: work queued on the default stream does not run
+    # next to other streams
+    # (equal priorities: a high-priority stream for either phase was measured at 62 / 99
+    # instead of 43.5 ms per step)
+    self.s1 = torch.cuda.Stream(device)   # world-model phase
+    self.s2 = torch.cuda.Stream(device)   # behaviour phase
+    self.s3 = torch.cuda.Stream(device)   # metric read-out
+    self.pa1, self.pa2, self.pb = learner.capture_pipeline()
+    self.ev_in = torch.cuda.Event()
+    self.ev_a = torch.cuda.Event()
+    self.ev_b = [torch.cuda.Event(), torch.cuda.Event()]
+    live = learner.metric_tensors()
+    self.pub_a = [{k: torch.empty_like(v) for k, v in live.items()} for _ in range(2)]
+    self.pub_b = [{k: torch.empty_like(v) for k, v in live.items()} for _ in range(2)]
+    self.k = 0
+    self.pending = None  # parity of the step whose metrics have not been returned yet
+
+  @property
+  def n_graphs(self):
+    return self.pa1.n_graphs + self.pa2.n_graphs + self.pb.n_graphs
+
+  def _publish(self, pub, stream):
+    with torch.cuda.stream(stream):
+      for k, v in self.L.metric_tensors().items():
+        pub[k].copy_(v)
+
+  def step(self):
+    """Enqueue one step; returns the metrics of the previous pipelined step (None for
+    the first).  The caller's current stream holds the uploaded inputs."""
+    cur = torch.cuda.current_stream(self.device)
+    s1, s2 = self.s1, self.s2
+    par = self.k & 1
+    s1.wait_stream(cur)                    # inputs / carry reset issued by the caller
+    self.pa1.replay_on(s1)
+    self.ev_in.record(s1)
+    if self.pending is not None:
+      s1.wait_event(self.ev_b[par ^ 1])    # B(k-1) still reads the world-model weights
+    self.pa2.replay_on(s1)
+    self._publish(self.pub_a[par], s1)
+    self.ev_a.record(s1)
+    s2.wait_event(self.ev_a)
+    self.pb.replay_on(s2)
+    self._publish(self.pub_b[par], s2)
+    self.ev_b[par].record(s2)
+    cur.wait_event(self.ev_in)             # the next upload must not overtake A1's reads
+    prev, self.pending = self.pending, par
+    self.k += 1
+    return None if prev is None else self._read(prev)
+
+  def _read(self, par):
+    with torch.cuda.stream(self.s3):
+      self.s3.wait_event(self.ev_b[par])
+      a = {k: v.cpu().numpy() for k, v in self.pub_a[par].items()}
+      b = {k: v.cpu().numpy() for k, v in self.pub_b[par].items()}
+    host = dict(a)
+    for k in self.L.METRIC_B:
+      if k in b:
+        host[k] = b[k]
+    rows = sorted(self.L.stat_b_slots)
+    for k in ('sums', 'maxs'):
+      host[k] = a[k].copy()
+      host[k][rows] = b[k][rows]
+    return self.L.read_metrics(host)
+
+  def flush(self):
+    """Wait for everything in flight; returns the last step's metrics (or None)."""
+    mets = None
+    if self.pending is not None:
+      mets = self._read(self.pending)
+      self.pending = None
+    cur = torch.cuda.current_stream(self.device)
+    cur.wait_stream(self.s1)
+    cur.wait_stream(self.s2)
+    self.s2.synchronize()
+    return mets
+
+
 class TrainState:
   """Opaque recurrent state handed back to the caller (the carried posterior
   lives in the learner's HBM buffers)."""
@@ -126,14 +220,24 @@ class Agent:
       self.ops = hipops.HipOps(self.device)
       # second launch context (own scratch workspace) for the side stream
       self.ops2 = hipops.HipOps(self.device, ws_bytes=1024 << 20)
+      self.ops_b = None
     else:
       self.ops = _ops
       self.ops2 = None
+      self.ops_b = None
       self.device = torch.device(_device or 'cpu')
     self._dtype = _dtype
     hip = self.cfg.get('hip', {})
     self._use_graph = bool(hip.get('graph', True)) and self.device.type == 'cuda'
     self._noise_seed = int(hip.get('noise_seed', 0))
+    # two-stream pipeline of consecutive steps (class Pipeline); single process only
+    self._pipeline = (bool(hip.get('pipeline', False)) and self._use_graph and
+                      self.world == 1)
+    if self._pipeline:
+      from . import hipops
+      self.ops_b = hipops.HipOps(self.device, ws_bytes=1024 << 20)
+    self._pipe = None
+    self._last_metrics = None
     self._seed = int(self.cfg.get('seed', 0))
     # Parameter / optimizer arenas are owned by the agent and shared by every
     # learner instance (train, policy, report), so rebuilding for a new batch
@@ -160,7 +264,7 @@ class Agent:
         self.spec, self.ops, self.device, batch // self.world, length,
         rank=self.rank, world=self.world, comm=self.comm,
         noise_seed=self._noise_seed, dtype=self._dtype, groups=self.groups,
-        ops2=self.ops2)
+        ops2=self.ops2, ops_b=self.ops_b)
     if self._pending_load is not None:
       self._apply_load(self._pending_load)
       self._pending_load = None
@@ -196,6 +300,7 @@ class Agent:
     B, T = data['is_first'].shape[:2]
     L = self.learner
     if L is None or getattr(self, '_bootstrap', False) or (L.Bg, L.T) != (B, T):
+      self.flush()
       saved = None
       if L is not None and not getattr(self, '_bootstrap', False):
         saved = self.save()  # controller state lives in the learner
@@ -205,19 +310,30 @@ class Agent:
       if saved is not None:
         self._apply_load(saved)
       L = self.learner
-      self._plan, self._train_calls = None, 0
+      self._plan, self._pipe, self._train_calls = None, None, 0
     L.upload(self._shard(data))
     carry = isinstance(state, TrainState) and state.owner is L
     if not carry:
       L.reset_carry()
+    if self._pipeline and self._train_calls >= 1 and 'key' not in data:
+      if self._pipe is None:
+        self._pipe = Pipeline(L, self.device)
+        self._plan = self._pipe
+      metrics = self._pipe.step()   # metrics of the previous step
+      self._train_calls += 1
+      if metrics is None:
+        metrics = self._last_metrics
+      self._last_metrics = metrics
+      return {}, TrainState(L), metrics
+    self.flush()
     if self._use_graph and self._train_calls >= 1:
-      if self._plan is None:
+      if self._plan is None or isinstance(self._plan, Pipeline):
         self._plan = L.capture()
       self._plan.replay()
     else:
       L.train_step_device(True)
     self._train_calls += 1
-    metrics = L.read_metrics()
+    metrics = self._last_metrics = L.read_metrics()
     outs = {}
     if 'key' in data:  # prioritized replay, agent.py:89-93
       name = self.cfg['priority']
@@ -231,10 +347,21 @@ class Agent:
 
   train_step = train  # BASELINE.json names the learner step `train_step`
 
+  def flush(self):
+    """Drain the two-stream pipeline (no-op otherwise); returns the metrics of the
+    last step if they had not been handed out yet."""
+    if self._pipe is None:
+      return None
+    mets = self._pipe.flush()
+    if mets is not None:
+      self._last_metrics = mets
+    return mets
+
   def policy(self, obs, state=None, mode='train'):
     obs = {k: np.asarray(v) for k, v in obs.items() if not k.startswith('log_')}
     n = len(obs['is_first'])
     self._ensure_params()
+    self.flush()
     P = self._policies.get(n)
     if P is None:
       P = learner_mod.Learner(
@@ -273,6 +400,7 @@ class Agent:
     data = {k: np.asarray(v) for k, v in data.items()
             if not k.startswith('log_')}
     B, T = data['is_first'].shape[:2]
+    self.flush()
     key = ('report', B, T)
     R = self._policies.get(key)
     self._ensure_params()
@@ -285,6 +413,7 @@ class Agent:
     R.upload(data)
     R.reset_carry()
     R.phase_prep()
+    R.phase_prep_b()  # prior-sample noise of the open-loop rollout
     R.phase_wm_fwd(True, training=False)
     sums = R.stat_sums.cpu().numpy()
     out = {}
@@ -311,6 +440,7 @@ class Agent:
 
   def save(self):
     self._ensure_params()
+    self.flush()
     L = self.learner
     out = {f'params/{k}': v for k, v in L.export_params().items()}
     for gname in ('model', 'actor', 'critic'):
@@ -326,10 +456,11 @@ class Agent:
     for k, v in L.norm_state.items():
       out[f'state/norm/{k}'] = v.cpu().numpy().copy()
     out['state/slow_updates'] = np.asarray(L.slow_updates, np.int64)
-    out['state/noise_step'] = L.step_ctr.cpu().numpy().copy()
+    out['state/noise_step'] = L.step_ctr.cpu().numpy().copy()  # == step_ctr_b when drained
     return out
 
   def load(self, data):
+    self.flush()
     if self.learner is None:
       self._pending_load = dict(data)
       self._ensure_params()
@@ -360,3 +491,4 @@ class Agent:
         L.norm_state[k].copy_(torch.as_tensor(data[f'state/norm/{k}']))
       L.slow_updates = int(data['state/slow_updates'])
       L.step_ctr.copy_(torch.as_tensor(data['state/noise_step']))
+      L.step_ctr_b.copy_(torch.as_tensor(data['state/noise_step']))

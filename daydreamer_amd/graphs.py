@@ -74,6 +74,16 @@ class GraphPlan:
           item()
     cur.wait_stream(self.stream)
 
+  def replay_on(self, stream):
+    """Enqueue the plan on `stream` and return without joining any other stream (the
+    caller orders streams with events: agent.Agent's two-stream pipeline)."""
+    with torch.cuda.stream(stream):
+      for kind, item in self.items:
+        if kind == 'graph':
+          item.replay()
+        else:
+          item()
+
   @property
   def n_graphs(self):
     return sum(1 for k, _ in self.items if k == 'graph')

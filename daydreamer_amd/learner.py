@@ -109,8 +109,13 @@ class Learner:
 
   def __init__(self, spec, ops, device, batch, length, params=None, seed=0,
                rank=0, world=1, comm=None, noise_seed=0, dtype=F32,
-               groups=None, ops2=None):
+               groups=None, ops2=None, ops_b=None):
     self.spec, self.ops, self.device = spec, ops, torch.device(device)
+    # ops_b: launch context (own scratch workspace) of the behaviour phase, so that it
+    # can run on its own stream next to the next step's world-model phase (pipeline)
+    self.ops_a, self.ops_b = ops, (ops_b if ops_b is not None else ops)
+    self._in_b = False
+    self.stat_b_slots = set()  # metric slots written by the behaviour phase
     # ops2: a second kernel-launch context with its own scratch workspace, used on
     # a side HIP stream to overlap weight-gradient contractions with the
     # latency-bound reverse scan (None: everything runs in program order)
@@ -161,6 +166,9 @@ class Learner:
         g.load(init)
     # ---- device scalars
     self.step_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+    # the behaviour phase keeps its own copy of the step number (it may run while the
+    # next world-model phase has already advanced step_ctr)
+    self.step_ctr_b = torch.zeros(1, dtype=torch.int64, device=self.device)
     self.wmkl_scale = torch.ones(1, dtype=dtype, device=self.device)
     self.actent_scale = torch.ones(self.A, dtype=dtype, device=self.device)
     self.norm_state = {k: torch.zeros(3, dtype=torch.float64, device=self.device)
@@ -260,6 +268,7 @@ class Learner:
     b['is_terminal'] = z(N, dtype=torch.uint8)
     b['first'] = z(N)
     b['cont'] = z(N)
+    b['cont_b'] = z(N)  # snapshot for the behaviour phase
     # ---- noise
     b['u_prior'] = z(B, T, G)      # batch-major: consumed in bulk after the scan
     b['u_post'] = z(T, B, G)
@@ -374,6 +383,8 @@ class Learner:
     if name not in self.stat_names:
       self.stat_names.append(name)
     k = self.stat_names.index(name)
+    if self._in_b:
+      self.stat_b_slots.add(k)
     self.ops.reduce_stats(x, self.stat_sums[k], self.stat_maxs[k])
     return k
 
@@ -816,20 +827,30 @@ class Learner:
     put(b['is_terminal'], tens(data['is_terminal']))
 
   def phase_prep(self):
+    """Per-step preparation of the world-model phase: step number, wire-format flags,
+    the observe scan's sampling noise."""
     ops, b = self.ops, self.b
-    B, T, N, H, G, A = self.B, self.T, self.N, self.H, self.G, self.A
+    B, T, G = self.B, self.T, self.G
     ops.counter_add(self.step_ctr, 1)
     ops.batch_prep(b['is_first'], b['is_terminal'], b['action'], b['first'],
                    b['cont'], b['xin'][:, self.S:])
     r0 = self.rank * B
     ops.philox(b['u_prior'], B, T, G, T, r0 * T, self.noise_seed, self.step_ctr, SITE_OBS_PRIOR, 0)
     ops.philox(b['u_post'], T, B, G, self.Bg, r0, self.noise_seed, self.step_ctr, SITE_OBS_POST, 0)
+
+  def phase_prep_b(self):
+    """The behaviour phase's own step number and sampling noise (same Philox keys as
+    if drawn in phase_prep: (seed, step, site, global row))."""
+    ops, b = self.ops, self.b
+    B, T, N, H, G, A = self.B, self.T, self.N, self.H, self.G, self.A
+    ops.counter_add(self.step_ctr_b, 1)
+    r0 = self.rank * B
     if H > 0:
-      ops.philox(b['u_img'], H, N, G, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_IMG, 0)
+      ops.philox(b['u_img'], H, N, G, self.Ng, r0 * T, self.noise_seed, self.step_ctr_b, SITE_IMG, 0)
     if self.discrete:
-      ops.philox(b['u_act'], H + 1, N, 1, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_ACT, 0)
+      ops.philox(b['u_act'], H + 1, N, 1, self.Ng, r0 * T, self.noise_seed, self.step_ctr_b, SITE_ACT, 0)
     else:
-      ops.philox(b['eps'], H + 1, N, A, self.Ng, r0 * T, self.noise_seed, self.step_ctr, SITE_ACT, 1)
+      ops.philox(b['eps'], H + 1, N, A, self.Ng, r0 * T, self.noise_seed, self.step_ctr_b, SITE_ACT, 1)
 
   def phase_wm_fwd(self, use_carry=True, training=True):
     ops, b, cfg = self.ops, self.b, self.cfg
@@ -900,10 +921,19 @@ class Learner:
     self.observe_bwd()
     self.encoder_bwd()
     self.join()
+
+  def phase_wm_opt(self):
+    """World-model optimizer step and the hand-over to the behaviour phase.  Everything
+    the behaviour phase needs from this step's buffers (imagination start states, the
+    start continuation flags) is copied here, so it never reads world-model-phase
+    buffers and the next step's world-model phase may overwrite them while it runs."""
+    ops, b = self.ops, self.b
     self.opt_step('model', 'model_opt')
     # carry the last posterior to the next call (reference agent.py:211)
     post = b['post'].view(self.B, self.T, self.F)
     ops.copy2d(post[:, self.T - 1], b['carry'])
+    ops.copy2d(b['post'], b['traj'][0][:, :self.F])
+    ops.copy2d(b['cont'].view(1, -1), b['cont_b'].view(1, -1))
 
   def phase_imagine(self):
     ops, b, cfg = self.ops, self.b, self.cfg
@@ -911,8 +941,7 @@ class Learner:
     traj = b['traj']
     ca = cfg['actor']
     lo, hi = ca['minstd'], ca['maxstd']
-    ops.copy2d(b['post'], traj[0][:, :F])
-    la, oa = self.acts_im['actor']
+    la, oa = self.acts_im['actor']  # traj[0][:, :F] = start states, set by phase_wm_opt
     for t in range(H + 1):
       st = lambda buf, t_=t: buf.view(H + 1, N, -1)[t_]
       if self.discrete:
@@ -939,7 +968,7 @@ class Learner:
       (val,) = self.head_fwd('critic_target', self.acts_im['critic_target'], feat)
     else:
       raise NotImplementedError('slow_target: False')
-    ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont'],
+    ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont_b'],
                          b['i_reward'], b['i_value'], b['i_cont'], b['i_weight'],
                          b['i_ret'], H, N, cfg['discount'], cfg['return_lambda'])
     # ---- critic update (reference agent.py:398-417)
@@ -982,7 +1011,7 @@ class Learner:
     (val,) = self.head_fwd('critic_target', self.acts_im['critic_target'], feat)
     rew = self.acts_im['reward'][1][0].z
     cont = self.acts_im['cont'][1][0].z
-    ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont'],
+    ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont_b'],
                          b['i_reward'], b['i_value2'], None, None, b['i_ret2'],
                          H, N, cfg['discount'], cfg['return_lambda'])
     ops.sub(b['i_ret2'], b['i_value2'], b['i_diff'][:HN])
@@ -1169,17 +1198,34 @@ class Learner:
 
   # --------------------------------------------------------------- train step
 
+  def phase_a1(self, use_carry=True):
+    """World-model phase up to the gradients."""
+    self.phase_prep()
+    self.phase_wm_fwd(use_carry)
+    self.phase_wm_bwd()
+
+  def phase_b(self):
+    """Behaviour phase: imagination, critic update, slow-critic copy, actor update.
+    Reads world-model weights, writes actor / critic state only."""
+    self.ops = self.ops_b
+    self._in_b = True
+    try:
+      self.phase_prep_b()
+      self.phase_imagine()
+      self.plan.cut(self.update_slow)
+      self.phase_actor()
+    finally:
+      self.ops = self.ops_a
+      self._in_b = False
+
   def train_step_device(self, use_carry=True):
     """All device work of one Agent.train call (inputs already uploaded)."""
     if not use_carry:
       self.reset_carry()
       use_carry = True
-    self.phase_prep()
-    self.phase_wm_fwd(use_carry)
-    self.phase_wm_bwd()
-    self.phase_imagine()
-    self.plan.cut(self.update_slow)
-    self.phase_actor()
+    self.phase_a1(use_carry)
+    self.phase_wm_opt()
+    self.phase_b()
 
   def capture(self):
     """Capture the whole step into HIP graphs (after at least one eager step,
@@ -1189,19 +1235,49 @@ class Learner:
     plan.capture(lambda: self.train_step_device(True))
     return plan
 
-  def read_metrics(self):
+  def capture_pipeline(self):
+    """The step as three separately replayable plans (world-model gradients | world-model
+    optimizer + hand-over | behaviour phase) for the two-stream software pipeline of
+    agent.Agent: step k's behaviour phase runs next to step k+1's world-model phase."""
+    plans = []
+    for fn in (lambda: self.phase_a1(True), self.phase_wm_opt, self.phase_b):
+      plan = graphs.GraphPlan(self.device)
+      self.plan = plan
+      plan.capture(fn)
+      plans.append(plan)
+    return plans
+
+  def metric_tensors(self):
+    """The device tensors a metrics read-out needs (name -> tensor)."""
+    t = dict(sums=self.stat_sums, maxs=self.stat_maxs, wmkl=self.wmkl_scale, sc=self.sc,
+             actent_scale=self.actent_scale)
+    for g in ('model', 'critic', 'actor'):
+      t[f'opt_{g}'] = self.groups[g].opt_state
+    if not self.discrete:
+      t['actent_sums'] = self.actent_sums
+    return t
+
+  # which of them the behaviour phase writes (the rest belong to the world-model phase;
+  # sums / maxs are split by row: stat_b_slots)
+  METRIC_B = ('sc', 'actent_scale', 'opt_critic', 'opt_actor', 'actent_sums')
+
+  def read_metrics(self, host=None):
     """One device->host transfer of the statistics slabs -> metrics dict with
     the reference's names (agent.py:184-203, 339-342, 407-415, tfutils.py
-    :208,250,266,445-446)."""
+    :208,250,266,445-446).  `host`: already fetched numpy copies of metric_tensors()
+    (the pipelined agent snapshots them per phase)."""
     cfg = self.cfg
-    sums = self.stat_sums.clone()
-    maxs = self.stat_maxs.clone()
-    if self.comm is not None and self.world > 1:
-      self.comm.allreduce_sum(sums)
-      self.comm.allreduce_max(maxs)
-      for k in self.stat_prereduced:  # identical on every rank already
-        sums[k] /= self.world
-    sums, maxs = sums.cpu().numpy(), maxs.cpu().numpy()
+    if host is None:
+      sums = self.stat_sums.clone()
+      maxs = self.stat_maxs.clone()
+      if self.comm is not None and self.world > 1:
+        self.comm.allreduce_sum(sums)
+        self.comm.allreduce_max(maxs)
+        for k in self.stat_prereduced:  # identical on every rank already
+          sums[k] /= self.world
+      host = {k: v.cpu().numpy() for k, v in self.metric_tensors().items()}
+      host['sums'], host['maxs'] = sums.cpu().numpy(), maxs.cpu().numpy()
+    sums, maxs = host['sums'], host['maxs']
     N, H, w = self.N, self.H, self.world
     counts = dict(imag_value=(H + 1) * N * w)
     for k in ('critic_loss', 'imag_reward', 'imag_return', 'ret2', 'diff',
@@ -1218,7 +1294,7 @@ class Learner:
     mets = {}
     f = np.float32
     ls = cfg['loss_scales']
-    wmkl = float(self.wmkl_scale.cpu()[0])
+    wmkl = float(host['wmkl'][0])
     model_loss = 0.0
     for name in st:
       if name.endswith('_loss') and name not in ('critic_loss',):
@@ -1240,7 +1316,7 @@ class Learner:
     mets['model_loss_mean'] = model_loss
     mets['model_loss'] = model_loss
     for gname, pre in (('model', ''), ('critic', 'extr_'), ('actor', '')):
-      o = self.groups[gname].opt_state.cpu().numpy()
+      o = host[f'opt_{gname}']
       mets[f'{pre}{gname}_grad_norm'] = o[1]
       mets[f'{pre}{gname}_grad_steps'] = o[0]
       if o[2] == 0.0:
@@ -1250,7 +1326,7 @@ class Learner:
     mets['extr_imag_reward_std'] = st['imag_reward']['std']
     mets['extr_imag_return_mean'] = st['imag_return']['mean']
     mets['extr_imag_return_std'] = st['imag_return']['std']
-    sc = self.sc.cpu().numpy()
+    sc = host['sc']
     d = st['diff']
     mets['extr_score_mean'] = d['mean'] * sc[0]
     mets['extr_score_std'] = d['std'] * sc[0]
@@ -1263,13 +1339,13 @@ class Learner:
     if self.discrete:
       mets['actent_mean'] = st['actent']['mean']
       mets['actent_std'] = st['actent']['std']
-      a = self.actent_scale[0:1].cpu().numpy()
+      a = host['actent_scale'][0:1]
     else:
-      asum = self.actent_sums.cpu().numpy()
+      asum = host['actent_sums']
       emean = asum[:A].sum() / (cnt * A)
       mets['actent_mean'] = emean
       mets['actent_std'] = math.sqrt(max(asum[A:].sum() / (cnt * A) - emean ** 2, 0.0))
-      a = self.actent_scale.cpu().numpy()
+      a = host['actent_scale']
     mets['actent_scale_mean'] = a.mean()
     mets['actent_scale_std'] = a.std()
     for k in ('model_loss', 'extr_critic_loss', 'actor_loss'):

@@ -223,3 +223,35 @@ def test_training_from_device_replay(hip):
     _, state, mets = ag.train(next(ds), state)
     assert all(np.isfinite(v) for v in mets.values()), i
   assert ag._plan is not None
+
+
+def test_pipelined_steps_equal_sequential(hip):
+  """hip.pipeline: step k's behaviour phase (imagination, critic, actor) runs on a second
+  stream next to step k+1's world-model phase.  Same arithmetic in the same order inside
+  each phase => parameters, optimizer moments and controller state after n steps are
+  bit-identical to the sequential schedule; metrics arrive one call late."""
+  import numpy as np
+  from daydreamer_amd import agent as agent_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=6, replay_chunk=8, imag_horizon=4)
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  batches = [synthetic.make_batch(obs, act, 6, 8, seed=s, smooth_images=True) for s in range(4)]
+  runs = {}
+  for mode in (False, True):
+    ag = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': mode}))
+    state, mets = None, []
+    for i in range(9):
+      _, state, m = ag.train(batches[i % 4], state)
+      mets.append(m)
+    last = ag.flush()
+    if mode:
+      assert isinstance(ag._plan, agent_mod.Pipeline) and last is not None
+      mets = mets[:1] + mets[2:] + [last]   # call i >= 2 returned step i-1; call 1 repeated step 0
+    runs[mode] = (ag.save(), mets)
+  (sa, ma), (sb, mb) = runs[False], runs[True]
+  assert sa.keys() == sb.keys()
+  for k in sa:
+    assert np.array_equal(np.asarray(sa[k]), np.asarray(sb[k]), equal_nan=True), k
+  assert len(ma) == len(mb)
+  for i, (x, y) in enumerate(zip(ma, mb)):
+    for k in x:
+      assert np.array_equal(x[k], y[k], equal_nan=True), (i, k)
