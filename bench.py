@@ -157,6 +157,7 @@ def main():
   n_incl = max(3, args.steps // 4)
   for _ in range(n_incl):
     _, state, mets = agent.train(data, state)
+  mets = agent.flush() or mets
   barrier()
   dt_incl = (time.perf_counter() - t0) / n_incl
 
@@ -177,6 +178,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(n_incl):
       _, state, mets = agent.train(next(ds), state)
+    mets = agent.flush() or mets
     barrier()
     dt_replay = (time.perf_counter() - t0) / n_incl
 
@@ -185,12 +187,19 @@ def main():
   roof = None
   step_flops = None
   if rank == 0:
-    L.ops.trace = []
+    # every launch context of the step: main, side stream (deferred weight gradients),
+    # behaviour phase
+    all_ops = [o for o in {id(o): o for o in (L.ops_a, L.ops2, L.ops_b) if o is not None}.values()]
+    shared = []
+    for o in all_ops:
+      o.trace = shared
     L.plan_backup, L.plan = L.plan, __import__('daydreamer_amd.graphs', fromlist=['EagerPlan']).EagerPlan()
     torch.cuda.synchronize()
     L.train_step_device(True)
     torch.cuda.synchronize()
-    trace, L.ops.trace = L.ops.trace, None
+    trace = shared
+    for o in all_ops:
+      o.trace = None
     L.plan = L.plan_backup
     tot_f = sum(f for _, f, _, _ in trace)
     tot_t = sum(e0.elapsed_time(e1) for _, _, e0, e1 in trace) * 1e-3

@@ -32,16 +32,17 @@ from . import spec as spec_mod
 class DistComm:
   """Sum / max all-reduce over the data-parallel group (RCCL on GPUs)."""
 
-  def __init__(self):
+  def __init__(self, group=None):
     import torch.distributed as dist
     self.dist = dist
+    self.group = group  # None: the default group
     self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
   def allreduce_sum(self, t):
-    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
   def allreduce_max(self, t):
-    self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
 
 
 class Batcher:
@@ -89,9 +90,10 @@ class Pipeline:
   tests/test_learner_gpu.py); only the metrics come back one call late.
   """
 
-  def __init__(self, learner, device):
+  def __init__(self, learner, device, comm=None):
     self.L = learner
     self.device = device
+    self.comm = comm  # data-parallel: communicator of the metric read-out
     # dedicated streams for both phases: work queued on the default stream does not run
     # next to other streams
     # (equal priorities: a high-priority stream for either phase was measured at 62 / 99
@@ -142,19 +144,25 @@ class Pipeline:
     return None if prev is None else self._read(prev)
 
   def _read(self, par):
+    L = self.L
     with torch.cuda.stream(self.s3):
       self.s3.wait_event(self.ev_b[par])
-      a = {k: v.cpu().numpy() for k, v in self.pub_a[par].items()}
-      b = {k: v.cpu().numpy() for k, v in self.pub_b[par].items()}
-    host = dict(a)
-    for k in self.L.METRIC_B:
-      if k in b:
-        host[k] = b[k]
-    rows = sorted(self.L.stat_b_slots)
-    for k in ('sums', 'maxs'):
-      host[k] = a[k].copy()
-      host[k][rows] = b[k][rows]
-    return self.L.read_metrics(host)
+      a, b = self.pub_a[par], self.pub_b[par]
+      rows = sorted(L.stat_b_slots)
+      merged = dict(a)
+      for k in L.METRIC_B:
+        if k in b:
+          merged[k] = b[k]
+      for k in ('sums', 'maxs'):
+        merged[k] = a[k].clone()
+        merged[k][rows] = b[k][rows]
+      if self.comm is not None and L.world > 1:
+        self.comm.allreduce_sum(merged['sums'])
+        self.comm.allreduce_max(merged['maxs'])
+        for k in L.stat_prereduced:  # identical on every rank already
+          merged['sums'][k] /= L.world
+      host = {k: v.cpu().numpy() for k, v in merged.items()}
+    return L.read_metrics(host)
 
   def flush(self):
     """Wait for everything in flight; returns the last step's metrics (or None)."""
@@ -231,11 +239,18 @@ class Agent:
     self._use_graph = bool(hip.get('graph', True)) and self.device.type == 'cuda'
     self._noise_seed = int(hip.get('noise_seed', 0))
     # two-stream pipeline of consecutive steps (class Pipeline); single process only
-    self._pipeline = (bool(hip.get('pipeline', False)) and self._use_graph and
-                      self.world == 1)
+    self._pipeline = bool(hip.get('pipeline', True)) and self._use_graph
+    self.comm_b = self.comm_m = None
     if self._pipeline:
       from . import hipops
       self.ops_b = hipops.HipOps(self.device, ws_bytes=1024 << 20)
+      if self.comm is not None:
+        # the two phases' collectives are in flight at the same time on different
+        # streams: one communicator each (+ one for the metric read-out); every rank
+        # creates them in the same order
+        import torch.distributed as dist
+        self.comm_b = DistComm(dist.new_group())
+        self.comm_m = DistComm(dist.new_group())
     self._pipe = None
     self._last_metrics = None
     self._seed = int(self.cfg.get('seed', 0))
@@ -264,7 +279,7 @@ class Agent:
         self.spec, self.ops, self.device, batch // self.world, length,
         rank=self.rank, world=self.world, comm=self.comm,
         noise_seed=self._noise_seed, dtype=self._dtype, groups=self.groups,
-        ops2=self.ops2, ops_b=self.ops_b)
+        ops2=self.ops2, ops_b=self.ops_b, comm_b=self.comm_b)
     if self._pending_load is not None:
       self._apply_load(self._pending_load)
       self._pending_load = None
@@ -317,7 +332,7 @@ class Agent:
       L.reset_carry()
     if self._pipeline and self._train_calls >= 1 and 'key' not in data:
       if self._pipe is None:
-        self._pipe = Pipeline(L, self.device)
+        self._pipe = Pipeline(L, self.device, self.comm_m)
         self._plan = self._pipe
       metrics = self._pipe.step()   # metrics of the previous step
       self._train_calls += 1

@@ -8,6 +8,8 @@ schedule is a host counter); `cut(fn)` marks such a point.  PyTorch is used only
 for its stream / graph handles.
 """
 
+import warnings
+
 import torch
 
 
@@ -36,7 +38,10 @@ class GraphPlan:
     self.cur.capture_begin(capture_error_mode='thread_local')
 
   def _end(self):
-    self.cur.capture_end()
+    with warnings.catch_warnings():
+      # a segment between two adjacent cut points holds no kernels: fine
+      warnings.filterwarnings('ignore', message='The CUDA Graph is empty')
+      self.cur.capture_end()
     self.items.append(('graph', self.cur))
     self.cur = None
 

@@ -109,13 +109,14 @@ class Learner:
 
   def __init__(self, spec, ops, device, batch, length, params=None, seed=0,
                rank=0, world=1, comm=None, noise_seed=0, dtype=F32,
-               groups=None, ops2=None, ops_b=None):
+               groups=None, ops2=None, ops_b=None, comm_b=None):
     self.spec, self.ops, self.device = spec, ops, torch.device(device)
     # ops_b: launch context (own scratch workspace) of the behaviour phase, so that it
     # can run on its own stream next to the next step's world-model phase (pipeline)
     self.ops_a, self.ops_b = ops, (ops_b if ops_b is not None else ops)
     self._in_b = False
     self.stat_b_slots = set()  # metric slots written by the behaviour phase
+    self.comm_a, self.comm_b = comm, (comm_b if comm_b is not None else comm)
     # ops2: a second kernel-launch context with its own scratch workspace, used on
     # a side HIP stream to overlap weight-gradient contractions with the
     # latency-bound reverse scan (None: everything runs in program order)
@@ -403,7 +404,8 @@ class Learner:
   def allreduce(self, t):
     """Sum over data-parallel ranks (RCCL); a graph cut point."""
     if self.comm is not None and self.world > 1:
-      self.plan.cut(lambda: self.comm.allreduce_sum(t))
+      comm = self.comm  # the phase's communicator at issue time (the cut runs at replay)
+      self.plan.cut(lambda: comm.allreduce_sum(t))
 
   def lin_fwd(self, P, A, x, sel=None):
     sel = sel or (lambda t: t)
@@ -1208,6 +1210,7 @@ class Learner:
     """Behaviour phase: imagination, critic update, slow-critic copy, actor update.
     Reads world-model weights, writes actor / critic state only."""
     self.ops = self.ops_b
+    self.comm = self.comm_b
     self._in_b = True
     try:
       self.phase_prep_b()
@@ -1216,6 +1219,7 @@ class Learner:
       self.phase_actor()
     finally:
       self.ops = self.ops_a
+      self.comm = self.comm_a
       self._in_b = False
 
   def train_step_device(self, use_carry=True):

@@ -185,6 +185,8 @@ def test_training_reduces_loss_through_agent(hip):
     assert all(np.isfinite(v) for v in mets.values()), i
     first = first if first is not None else float(mets['model_loss'])
     last = float(mets['model_loss'])
+  mets = ag.flush() or mets  # pipelined: train() hands out the previous step's metrics
+  last = float(mets['model_loss'])
   assert ag._plan is not None and ag._plan.n_graphs >= 2   # replayed from HIP graphs
   assert last < 0.9 * first, (first, last)
   assert float(mets['model_grad_steps']) == 40 and float(mets['actor_grad_steps']) == 40
