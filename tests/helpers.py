@@ -17,9 +17,14 @@ def make_config(blocks=('a1_vision', 'debug'), **overrides):
 
 
 def make_problem(cfg, image=64, vector=5, action=3, batch=None, length=None,
-                 seed=0, terminals=0.1, smooth=True, discrete=False):
+                 seed=0, terminals=0.1, smooth=True, discrete=False, cameras=1):
   plain = config.to_plain(cfg)
   obs, act = synthetic.make_spaces(image, vector, action)
+  for i in range(1, cameras):  # further cameras: `image2`, ... (matched by cnn_keys 'image')
+    obs[f'image{i + 1}'] = synthetic.Space(np.uint8, (image, image, 3))
+  if cameras > 1:  # keep the reference's key order (images first)
+    obs = {**{k: v for k, v in obs.items() if k.startswith('image')},
+           **{k: v for k, v in obs.items() if not k.startswith('image')}}
   shapes = {k: v.shape for k, v in obs.items()}
   sp = spec.build_spec(plain, shapes, action, discrete)
   params = spec.init_params(sp, seed)

@@ -161,3 +161,12 @@ def test_report_open_loop_grid():
   assert model.min() > 0 and model.max() < 1
   assert np.allclose(error, (model - grid_truth + 1) / 2, atol=1e-6)
   assert np.isfinite(rep['image_loss_mean'])
+
+
+def test_learner_matches_oracle_multicam_128():
+  """BASELINE configs[3] geometry: two 128x128 cameras concatenated on channels, five
+  transposed-conv decoder layers (kernels 5,5,6,6,2 -> 128x128), per-camera image losses."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=2, replay_chunk=3,
+                            imag_horizon=2)
+  cfg = cfg.update({'decoder.cnn_kernels': [5, 5, 6, 6, 2]})
+  run_pair(cfg, steps=1, image=128, cameras=2, vector=5, action=3, terminals=0.1)

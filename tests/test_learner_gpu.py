@@ -97,6 +97,14 @@ def test_e2e_scaled_latent(hip):
   run(hip, cfg, 1, image=64, vector=16, action=16, terminals=0.0)
 
 
+def test_e2e_multicam_128(hip):
+  """BASELINE configs[3] geometry (ur5 multi-camera): two 128x128 cameras on channels,
+  decoder kernels 5,5,6,6,2 -> 128x128 (k = 2 transposed conv, 6-channel uint8 input)."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=3, replay_chunk=4, imag_horizon=3)
+  cfg = cfg.update({'decoder.cnn_kernels': [5, 5, 6, 6, 2]})
+  run(hip, cfg, 1, image=128, cameras=2, vector=5, action=3, terminals=0.1)
+
+
 def test_full_size_properties(hip):
   """BASELINE configs[1] at full size (batch 50 x seq 50 x horizon 15): the oracle
   is too slow here, so check size-independent properties instead: finite losses,
