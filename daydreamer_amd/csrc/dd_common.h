@@ -29,6 +29,36 @@ void dd_set_error_msg(const char* msg);
     }                                                 \
   } while (0)
 
+// Deferred split-K sum (dd_gemm_f32 with `deferred`): S partial results [S][rows][N] sit
+// in the GEMM's workspace; the consumer kernel adds them in the reduce pass's order
+// (slabs ascending, then bias, then beta * old value), writes the total back to its input
+// buffer (later kernels read it) and continues.  S = 0: plain input.
+struct PreSum {
+  const float* p; int S; long MN; int N; float beta; const float* bias;
+};
+__device__ __forceinline__ float presum1(const PreSum& ps, long row, int c, float old) {
+  const float* q = ps.p + row * ps.N + c;
+  float s = 0.f;
+  for (int z = 0; z < ps.S; ++z) s += q[z * ps.MN];
+  if (ps.bias) s += ps.bias[c];
+  if (ps.beta != 0.f) s += ps.beta * old;
+  return s;
+}
+__device__ __forceinline__ float4 presum4(const PreSum& ps, long row, int c, float4 old) {
+  const float* q = ps.p + row * ps.N + c;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < ps.S; ++z) {
+    float4 t = *reinterpret_cast<const float4*>(q + z * ps.MN);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  if (ps.bias) {
+    float4 b = *reinterpret_cast<const float4*>(ps.bias + c);
+    s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+  }
+  if (ps.beta != 0.f) { s.x += ps.beta * old.x; s.y += ps.beta * old.y; s.z += ps.beta * old.z; s.w += ps.beta * old.w; }
+  return s;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

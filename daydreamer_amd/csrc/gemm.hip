@@ -774,7 +774,7 @@ int pick_split(long tiles, int K, long MN, size_t ws_bytes) {
 template <bool AKC, bool BKC, class AL, class BL>
 int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* bias,
             float alpha, float beta, float* ws, size_t ws_bytes, hipStream_t st,
-            const char* name) {
+            const char* name, int* deferred = nullptr) {
   if (M <= 0 || N <= 0) return 0;
   // tiles: 128x128 for large problems, 128x64 for narrow outputs, 64x64 for few rows;
   // mid-size problems drop to smaller tiles until the grid covers the 256 CUs.
@@ -809,6 +809,11 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
   else
     launch_tile<64, 64, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
   DD_CHECK_LAUNCH(name);
+  if (deferred) *deferred = 0;
+  if (S > 1 && deferred) {
+    *deferred = S;  // the consumer kernel adds the slabs (PreSum)
+    return 0;
+  }
   if (S > 1) {
     int blocks = (int)((MN + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -827,11 +832,26 @@ extern "C" int dd_gemm_set_mode(int mode) {
   return prev;
 }
 
+extern "C" int dd_splitk_finish(const float* slabs, int n_slabs, float* C, long ldc, int M, int N,
+                                float beta, const float* bias, void* stream) {
+  if (n_slabs <= 0 || M <= 0 || N <= 0) return 0;
+  const long MN = (long)M * N;
+  int blocks = (int)((MN + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  k_splitk_reduce<<<blocks, 256, 0, (hipStream_t)stream>>>(slabs, n_slabs, MN, N, C, ldc, bias, 1.f, beta);
+  DD_CHECK_LAUNCH("dd_splitk_finish");
+  return 0;
+}
+
 extern "C" int dd_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                            long lda, long ldb, long ldc, int transA, int transB,
                            float alpha, float beta, const float* bias,
-                           float* ws, size_t ws_bytes, void* stream) {
+                           float* ws, size_t ws_bytes, int* deferred, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (deferred) {
+    *deferred = 0;
+    if (alpha != 1.f) deferred = nullptr;  // slabs are raw accumulators
+  }
   int va = aligned16(A) && (lda % 4 == 0);
   int vb = aligned16(B) && (ldb % 4 == 0);
   // fast (branch-free) loaders: the float4 axis must be a multiple of 4 (K for a
@@ -841,7 +861,7 @@ extern "C" int dd_gemm_f32(const float* A, const float* B, float* C, int M, int 
   const char* nm = "dd_gemm_f32";
 #define DD_RUN(AKC, BKC, AT, BT, FF)                                                        \
   return run_mat<AKC, BKC>(AT<FF>{A, lda, M, va}, BT<FF>{B, ldb, N, vb}, M, N, K, C, ldc,   \
-                           bias, alpha, beta, ws, ws_bytes, st, nm)
+                           bias, alpha, beta, ws, ws_bytes, st, nm, deferred)
   if (fa && fb) {
     if (!transA && !transB) DD_RUN(true, false, MatKC, MatRC, true);
     if (!transA && transB) DD_RUN(true, true, MatKC, MatKC, true);

@@ -31,9 +31,9 @@ __device__ __forceinline__ float sub_max(float v) {
 // mode: 0 sample with u, 1 argmax (OneHotCategorical.mode()).
 template <int LW>
 __global__ void __launch_bounds__(256)
-k_stats_fwd(const float* __restrict__ x, long ldx, const float* __restrict__ u, long ldu,
+k_stats_fwd(float* __restrict__ x, long ldx, const float* __restrict__ u, long ldu,
             float* __restrict__ logit, long ldl, float* __restrict__ stoch, long lds,
-            int rows, int G, int C, float unimix, int mode) {
+            int rows, int G, int C, float unimix, int mode, PreSum ps) {
   constexpr int GPW = 64 / LW;  // groups per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane % LW, sub = lane / LW;
@@ -45,7 +45,16 @@ k_stats_fwd(const float* __restrict__ x, long ldx, const float* __restrict__ u, 
     const long row = live ? item / G : 0;
     const int g = live ? (int)(item - row * G) : 0;
     const bool ok = live && c < C;
-    float xv = ok ? x[row * ldx + (long)g * C + c] : -INFINITY;
+    float xv = -INFINITY;
+    if (ok) {
+      float* xp = x + row * ldx + (long)g * C + c;
+      if (ps.S) {
+        xv = presum1(ps, row, g * C + c, ps.beta != 0.f ? *xp : 0.f);
+        *xp = xv;  // the backward pass reads the raw statistics
+      } else {
+        xv = *xp;
+      }
+    }
     float m = sub_max<LW>(xv);
     float e = ok ? expf(xv - m) : 0.f;
     float s = sub_sum<LW>(e);
@@ -210,16 +219,19 @@ inline int item_blocks(long rows, int G, int LW) {
 
 }  // namespace
 
-extern "C" int dd_stats_sample_fwd(const float* x, long ldx, const float* u, long ldu,
+extern "C" int dd_stats_sample_fwd(float* x, long ldx, const float* u, long ldu,
                                    float* logit, long ldl, float* stoch, long lds,
-                                   int rows, int G, int C, float unimix, int mode, void* stream) {
+                                   int rows, int G, int C, float unimix, int mode,
+                                   const float* slabs, int n_slabs, float beta_pre,
+                                   const float* bias_pre, void* stream) {
   if (rows <= 0) return 0;
   DD_REQUIRE(C >= 2 && C <= 64, "dd_stats_sample_fwd: classes must be in [2,64]");
   DD_REQUIRE(mode == 1 || u != nullptr, "dd_stats_sample_fwd: noise required");
+  PreSum ps{slabs, n_slabs, (long)rows * G * C, G * C, beta_pre, bias_pre};
   return dispatch_lw(C, [&](auto lw) {
     constexpr int LW = decltype(lw)::value;
     k_stats_fwd<LW><<<item_blocks(rows, G, LW), 256, 0, (hipStream_t)stream>>>(
-        x, ldx, u, ldu, logit, ldl, stoch, lds, rows, G, C, unimix, mode);
+        x, ldx, u, ldu, logit, ldl, stoch, lds, rows, G, C, unimix, mode, ps);
     DD_CHECK_LAUNCH("dd_stats_sample_fwd");
     return 0;
   });

@@ -162,9 +162,9 @@ __device__ __forceinline__ float grp_sum(float v) {
 
 template <int LPR, int V>
 __global__ void __launch_bounds__(256)
-k_ln_act_fwd_v(const float* __restrict__ z, long ldz, const float* __restrict__ gamma,
+k_ln_act_fwd_v(float* __restrict__ z, long ldz, const float* __restrict__ gamma,
                const float* __restrict__ beta, float* __restrict__ out, long ldo,
-               float* __restrict__ stats, long lds, int rows, int C, int act) {
+               float* __restrict__ stats, long lds, int rows, int C, int act, PreSum ps) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -177,8 +177,16 @@ k_ln_act_fwd_v(const float* __restrict__ z, long ldz, const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       int c = (l + LPR * i) * 4;
-      x[i] = (live && c < C) ? *reinterpret_cast<const float4*>(z + row * ldz + c)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && c < C) {
+        float4* zp = reinterpret_cast<float4*>(z + row * ldz + c);
+        if (ps.S) {
+          x[i] = presum4(ps, row, c, ps.beta != 0.f ? *zp : x[i]);
+          *zp = x[i];
+        } else {
+          x[i] = *zp;
+        }
+      }
       s += x[i].x + x[i].y + x[i].z + x[i].w;
     }
     const float mean = grp_sum<LPR>(s) / (float)C;
@@ -216,10 +224,10 @@ k_ln_act_fwd_v(const float* __restrict__ z, long ldz, const float* __restrict__ 
 // partials layout: [gridDim.x][3][C] = (dgamma, dbeta, column sum of dz)
 template <int LPR, int V>
 __global__ void __launch_bounds__(256)
-k_ln_act_bwd_v(const float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
+k_ln_act_bwd_v(float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
                const float* __restrict__ out, long ldo, const float* __restrict__ stats, long lds,
                const float* __restrict__ gamma, float* __restrict__ dz, long lddz,
-               float* __restrict__ partials, int rows, int C, int act) {
+               float* __restrict__ partials, int rows, int C, int act, PreSum ps) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -240,7 +248,14 @@ k_ln_act_bwd_v(const float* __restrict__ dout, long ldd, const float* __restrict
       int c = (l + LPR * i) * 4;
       g[i] = make_float4(0.f, 0.f, 0.f, 0.f); xh[i] = g[i];
       if (live && c < C) {
-        float4 dy = *reinterpret_cast<const float4*>(dout + row * ldd + c);
+        float4* dyp = reinterpret_cast<float4*>(dout + row * ldd + c);
+        float4 dy;
+        if (ps.S) {
+          dy = presum4(ps, row, c, ps.beta != 0.f ? *dyp : make_float4(0.f, 0.f, 0.f, 0.f));
+          *dyp = dy;  // the bulk parameter-gradient pass reads it later
+        } else {
+          dy = *dyp;
+        }
         if (act) {
           float4 o = *reinterpret_cast<const float4*>(out + row * ldo + c);
           dy.x *= (o.x > 0.f ? 1.f : o.x + 1.f); dy.y *= (o.y > 0.f ? 1.f : o.y + 1.f);
@@ -375,15 +390,40 @@ k_col_sum(const float* __restrict__ x, long ldx, float* __restrict__ partials, l
 // then reset = sig(r); cand = tanh(reset * c); update = sig(u - 1);
 // h' = update * cand + (1 - update) * h.
 __global__ void __launch_bounds__(256)
-k_gru_fwd(const float* __restrict__ z3, long ldz, const float* __restrict__ gamma,
+k_gru_fwd(float* __restrict__ z3, long ldz, const float* __restrict__ gamma,
           const float* __restrict__ beta, const float* __restrict__ h, long ldh,
-          float* __restrict__ hn, long ldn, float* __restrict__ stats, long lds, int rows, int D) {
+          float* __restrict__ hn, long ldn, float* __restrict__ stats, long lds, int rows, int D,
+          PreSum ps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = 3 * D;
   for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
-    const float* zr = z3 + row * ldz;
+    float* zr = z3 + row * ldz;
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += zr[c];
+    if (ps.S) {
+      // (D % 64 == 0, checked by the host: every later read of zr[c] is by the lane that
+      // wrote it here)
+      // four columns per round, all their slab loads in flight together (a store between
+      // the loads of successive columns would serialise one memory latency per column)
+      for (int c0 = lane; c0 < C; c0 += 256) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* q = ps.p + row * ps.N + c0;
+        for (int z = 0; z < ps.S; ++z)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c0 + 64 * j < C) v[j] += q[z * ps.MN + 64 * j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = c0 + 64 * j;
+          if (c < C) {
+            if (ps.beta != 0.f) v[j] += ps.beta * zr[c];
+            zr[c] = v[j];
+            s += v[j];
+          }
+        }
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) s += zr[c];
+    }
     const float mean = wave_sum(s) / (float)C;
     float v = 0.f;
     for (int c = lane; c < C; c += 64) { float d = zr[c] - mean; v += d * d; }
@@ -489,18 +529,26 @@ inline int row_blocks(long rows, int cap) {
 
 }  // namespace
 
-extern "C" int dd_ln_act_fwd(const float* z, long ldz, const float* gamma, const float* beta,
+extern "C" int dd_ln_act_fwd(float* z, long ldz, const float* gamma, const float* beta,
                              float* out, long ldo, float* stats, long lds, int rows, int C, int act,
+                             const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
                              void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (C % 4 == 0 && C <= 1024 && ldz % 4 == 0 && ldo % 4 == 0 && al16(z) && al16(out) &&
-      al16(gamma) && al16(beta)) {
+  const bool vec = C % 4 == 0 && C <= 1024 && ldz % 4 == 0 && ldo % 4 == 0 && al16(z) && al16(out) &&
+                   al16(gamma) && al16(beta) && al16(slabs) && al16(bias_pre);
+  if (n_slabs > 0 && !vec) {  // the scalar kernels take plain input: finish the sum first
+    int rc = dd_splitk_finish(slabs, n_slabs, z, ldz, rows, C, beta_pre, bias_pre, stream);
+    if (rc) return rc;
+    n_slabs = 0;
+  }
+  PreSum ps{slabs, n_slabs, (long)rows * C, C, beta_pre, bias_pre};
+  if (vec) {
     return dispatch_vec(C, [&](auto lpr, auto v) {
       constexpr int LPR = decltype(lpr)::value, V = decltype(v)::value;
       long groups = (rows + (64 / LPR) - 1) / (64 / LPR);
       int blocks = row_blocks(groups, 1 << 20);
-      k_ln_act_fwd_v<LPR, V><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act);
+      k_ln_act_fwd_v<LPR, V><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act, ps);
       DD_CHECK_LAUNCH("dd_ln_act_fwd");
       return 0;
     });
@@ -522,17 +570,26 @@ extern "C" int dd_ln_bwd_parts(int rows, int C) {
   return row_blocks(rows, 256);
 }
 
-extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
+extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
                              const float* out, long ldo, const float* stats, long lds, const float* gamma,
                              float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
                              int accumulate, int rows, int C, int act, float* ws, size_t ws_bytes,
-                             void* stream) {
+                             const float* slabs, int n_slabs, float beta_pre, void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool want = dgamma != nullptr;
   const float b = accumulate ? 1.f : 0.f;
   const bool vec = C % 4 == 0 && C <= 1024 && ldd % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 &&
-                   lddz % 4 == 0 && al16(dout) && al16(z) && al16(out) && al16(dz) && al16(gamma);
+                   lddz % 4 == 0 && al16(dout) && al16(z) && al16(out) && al16(dz) && al16(gamma) &&
+                   al16(slabs);
+  // the deferred sum shares the workspace with the parameter-gradient partials: only
+  // the parameter-free vector path consumes it in place
+  if (n_slabs > 0 && (!vec || want)) {
+    int rc = dd_splitk_finish(slabs, n_slabs, dout, ldd, rows, C, beta_pre, nullptr, stream);
+    if (rc) return rc;
+    n_slabs = 0;
+  }
+  PreSum ps{slabs, n_slabs, (long)rows * C, C, beta_pre, nullptr};
   if (vec) {
     return dispatch_vec(C, [&](auto lpr, auto v) {
       constexpr int LPR = decltype(lpr)::value, V = decltype(v)::value;
@@ -547,7 +604,7 @@ extern "C" int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long l
       size_t shmem = want ? (size_t)WPB * RPW * 3 * C * sizeof(float) : 0;
       if (want) DD_REQUIRE(ws && (size_t)blocks * 3 * C * sizeof(float) <= ws_bytes, "dd_ln_act_bwd: workspace too small");
       k_ln_act_bwd_v<LPR, V><<<blocks, 256, shmem, st>>>(
-          dout, ldd, z, ldz, out, ldo, stats, lds, gamma, dz, lddz, want ? ws : nullptr, rows, C, act);
+          dout, ldd, z, ldz, out, ldo, stats, lds, gamma, dz, lddz, want ? ws : nullptr, rows, C, act, ps);
       DD_CHECK_LAUNCH("dd_ln_act_bwd");
       if (want) {
         k_col_reduce_n<<<dim3((C + 15) / 16, dbias_pre ? 3 : 2), 256, 0, st>>>(
@@ -600,12 +657,19 @@ extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, lon
   return 0;
 }
 
-extern "C" int dd_gru_cell_fwd(const float* z3, long ldz, const float* gamma, const float* beta,
+extern "C" int dd_gru_cell_fwd(float* z3, long ldz, const float* gamma, const float* beta,
                                const float* h, long ldh, float* hn, long ldn, float* stats, long lds,
-                               int rows, int D, void* stream) {
+                               int rows, int D, const float* slabs, int n_slabs, float beta_pre,
+                               void* stream) {
   if (rows <= 0) return 0;
+  if (n_slabs > 0 && D % 64 != 0) {
+    int rc = dd_splitk_finish(slabs, n_slabs, z3, ldz, rows, 3 * D, beta_pre, nullptr, stream);
+    if (rc) return rc;
+    n_slabs = 0;
+  }
+  PreSum ps{slabs, n_slabs, (long)rows * 3 * D, 3 * D, beta_pre, nullptr};
   k_gru_fwd<<<row_blocks(rows, 1 << 20), 256, 0, (hipStream_t)stream>>>(
-      z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, D);
+      z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, D, ps);
   DD_CHECK_LAUNCH("dd_gru_cell_fwd");
   return 0;
 }

@@ -28,18 +28,19 @@ c_ull = ctypes.c_ulonglong
 
 _SIGS = {
     'dd_gemm_set_mode': [c_i],
-    'dd_gemm_f32': [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p, c_p, c_z, c_p],
+    'dd_gemm_f32': [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p, c_p, c_z, c_p, c_p],
+    'dd_splitk_finish': [c_p, c_i, c_p, c_l, c_i, c_i, c_f, c_p, c_p],
     'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
     'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
-    'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
-    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
+    'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_i, c_f, c_p, c_p],
+    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p, c_i, c_f, c_p],
     'dd_ln_bwd_parts': [c_i, c_i],
     'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_col_sum': [c_p, c_l, c_p, c_f, c_l, c_i, c_p, c_z, c_p],
-    'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_i, c_f, c_p],
     'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
-    'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
+    'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_f, c_p, c_p],
     'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
     'dd_cat_kl_fwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     'dd_cat_kl_bwd': [c_p, c_l, c_p, c_l, c_p, c_f, c_f, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
@@ -117,6 +118,13 @@ def _vec(t):
   return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else 1)
 
 
+class Slabs:
+  """Deferred split-K partial sums sitting in a HipOps workspace (dd_gemm_f32 `deferred`)."""
+
+  def __init__(self, n, M, N, beta, bias):
+    self.n, self.M, self.N, self.beta, self.bias = n, M, N, beta, bias
+
+
 class HipOps:
 
   name = 'hip'
@@ -154,7 +162,11 @@ class HipOps:
 
   # ---- contractions ---------------------------------------------------------
 
-  def gemm(self, A, B, C, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
+  def gemm(self, A, B, C, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, defer=False):
+    """defer=True: if the GEMM splits K, skip its reduce pass and return a `Slabs`
+    handle for the consumer (ln_act_fwd / gru_fwd / stats_fwd / ln_act_bwd `pre=`), which
+    must be the next operation on this launch context; otherwise (and always with
+    defer=False) C is complete and None is returned."""
     M, N = C.shape
     K = A.shape[0] if ta else A.shape[1]
     assert (A.shape[1] if ta else A.shape[0]) == M, (A.shape, C.shape, ta)
@@ -162,9 +174,22 @@ class HipOps:
     a, lda = _mat(A)
     b, ldb = _mat(B)
     c, ldc = _mat(C)
+    # in deferred mode bias / beta are applied by the consumer together with the sum
+    flag = ctypes.c_int(0) if (defer and alpha == 1.0) else None
     self._check(self._traced(f'gemm {M}x{N}x{K} ta{int(ta)} tb{int(tb)} B{4 * (M * K + K * N + M * N)}', 2.0 * M * N * K, lambda: self.lib.dd_gemm_f32(
         a, b, c, M, N, K, lda, ldb, ldc, int(ta), int(tb), alpha, beta,
-        _ptr(bias), self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_gemm_f32')
+        _ptr(bias), self.ws.data_ptr(), self.ws_bytes,
+        ctypes.byref(flag) if flag is not None else None, self.stream)), 'dd_gemm_f32')
+    if flag is not None and flag.value > 0:
+      return Slabs(flag.value, M, N, beta, bias)
+    return None
+
+  def _pre(self, pre, rows, cols):
+    """(slabs, n_slabs, beta_pre, bias_pre) arguments of a consumer."""
+    if pre is None:
+      return 0, 0, 0.0, 0
+    assert (pre.M, pre.N) == (rows, cols), ((pre.M, pre.N), (rows, cols))
+    return self.ws.data_ptr(), pre.n, pre.beta, _ptr(pre.bias)
 
   def conv_down(self, big, w, bias, small, k, in_scale=1.0):
     n, hb, wb, cb = big.shape
@@ -201,16 +226,16 @@ class HipOps:
 
   # ---- LayerNorm / GRU -------------------------------------------------------
 
-  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True):
+  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True, pre=None):
     rows, C = z.shape
     zp, ldz = _mat(z)
     op, ldo = _mat(out)
     self._check(self.lib.dd_ln_act_fwd(
         zp, ldz, gamma.data_ptr(), beta.data_ptr(), op, ldo, *_mat(stats),
-        rows, C, int(act), self.stream), 'dd_ln_act_fwd')
+        rows, C, int(act), *self._pre(pre, rows, C), self.stream), 'dd_ln_act_fwd')
 
   def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
-                 dbeta=None, accumulate=False, act=True, dbias_pre=None):
+                 dbeta=None, accumulate=False, act=True, dbias_pre=None, pre=None):
     rows, C = z.shape
     dp, ldd = _mat(dout)
     zp, ldz = _mat(z)
@@ -220,7 +245,8 @@ class HipOps:
         dp, ldd, zp, ldz, op, ldo, *_mat(stats), gamma.data_ptr(), dzp,
         lddz, _ptr(dgamma), _ptr(dbeta), _ptr(dbias_pre), int(accumulate),
         rows, C, int(act),
-        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_ln_act_bwd')
+        self.ws.data_ptr(), self.ws_bytes, *self._pre(pre, rows, C)[:3], self.stream),
+        'dd_ln_act_bwd')
 
   def ln_param_grad(self, dout, z, out, stats, dgamma, dbeta,
                     accumulate=False, act=True):
@@ -240,14 +266,15 @@ class HipOps:
         xp, ldx, out.data_ptr(), beta, rows, C, self.ws.data_ptr(),
         self.ws_bytes, self.stream), 'dd_col_sum')
 
-  def gru_fwd(self, z3, gamma, beta, h, hn, stats):
+  def gru_fwd(self, z3, gamma, beta, h, hn, stats, pre=None):
     rows, D = h.shape
     zp, ldz = _mat(z3)
     hp, ldh = _mat(h)
     np_, ldn = _mat(hn)
     self._check(self.lib.dd_gru_cell_fwd(
         zp, ldz, gamma.data_ptr(), beta.data_ptr(), hp, ldh, np_, ldn,
-        *_mat(stats), rows, D, self.stream), 'dd_gru_cell_fwd')
+        *_mat(stats), rows, D, *self._pre(pre, rows, 3 * D)[:3], self.stream),
+        'dd_gru_cell_fwd')
 
   def gru_bwd(self, dhn, z3, stats, gamma, beta, h, dz3, dh, dy3, zero=None):
     rows, D = h.shape
@@ -267,7 +294,7 @@ class HipOps:
 
   # ---- categorical latent -----------------------------------------------------
 
-  def stats_fwd(self, x, u, logit, stoch, G, C, unimix, mode=0):
+  def stats_fwd(self, x, u, logit, stoch, G, C, unimix, mode=0, pre=None):
     rows = x.shape[0]
     xp, ldx = _mat(x)
     up, ldu = _mat(u) if u is not None else (0, 0)
@@ -275,7 +302,7 @@ class HipOps:
     sp, lds = _mat(stoch)
     self._check(self.lib.dd_stats_sample_fwd(
         xp, ldx, up, ldu, lp, ldl, sp, lds, rows, G, C, unimix, mode,
-        self.stream), 'dd_stats_sample_fwd')
+        *self._pre(pre, rows, G * C), self.stream), 'dd_stats_sample_fwd')
 
   def stats_bwd(self, x, dlogit, dstoch, dx, G, C, unimix):
     rows = x.shape[0]

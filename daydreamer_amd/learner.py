@@ -407,13 +407,17 @@ class Learner:
       comm = self.comm  # the phase's communicator at issue time (the cut runs at replay)
       self.plan.cut(lambda: comm.allreduce_sum(t))
 
-  def lin_fwd(self, P, A, x, sel=None):
+  def lin_fwd(self, P, A, x, sel=None, defer=False):
+    """Linear (+ LayerNorm + ELU).  The GEMM of a normed layer leaves a split-K sum to
+    the LayerNorm kernel (one launch less); for a plain layer `defer=True` returns
+    (z, pending sum) for a consumer that takes `pre=`."""
     sel = sel or (lambda t: t)
     zv = sel(A.z)
-    self.ops.gemm(x, P.W, zv, bias=None if P.norm else P.bias)
     if not P.norm:
-      return zv
-    self.ops.ln_act_fwd(zv, P.gamma, P.beta, sel(A.out), sel(A.stats), True)
+      pre = self.ops.gemm(x, P.W, zv, bias=P.bias, defer=defer)
+      return (zv, pre) if defer else zv
+    pre = self.ops.gemm(x, P.W, zv, defer=True)
+    self.ops.ln_act_fwd(zv, P.gamma, P.beta, sel(A.out), sel(A.stats), True, pre=pre)
     return sel(A.out)
 
   def lin_bwd(self, P, A, x, sel=None, dx=None, dx_beta=0.0, params=True,
@@ -648,12 +652,12 @@ class Learner:
     x1 = self.lin_fwd(self.P['img_in'], A_in, xin, sel)
     z3v = sel(z3)
     if gin is not None:  # hprev and x1 are adjacent column blocks of gin
-      ops.gemm(sel(gin), self.P['gru'].W, z3v)
+      pre = ops.gemm(sel(gin), self.P['gru'].W, z3v, defer=True)
     else:
       ops.gemm(hprev, self.P['gru_h'].W, z3v)
-      ops.gemm(x1, self.P['gru_x'].W, z3v, beta=1.0)
+      pre = ops.gemm(x1, self.P['gru_x'].W, z3v, beta=1.0, defer=True)
     g = self.P['gru_h']
-    ops.gru_fwd(z3v, g.gamma, g.beta, hprev, hn, sel(gstats))
+    ops.gru_fwd(z3v, g.gamma, g.beta, hprev, hn, sel(gstats), pre=pre)
 
   def prior_fwd(self, deter, A_out, A_stats, sel=None):
     """img_out layers + img_stats on the new deter (reference nets.py:131-134);
@@ -724,12 +728,12 @@ class Learner:
                     b['gstats'], sel, gin=b['gin'])
       # posterior: obs_out on concat[deter, embed]; embed part already in z
       Ao = self.a_obs_out
-      ops.gemm(post[:, t, :D], self.P['obs_out_h'].W, sel(Ao.z), beta=1.0)
+      pre = ops.gemm(post[:, t, :D], self.P['obs_out_h'].W, sel(Ao.z), beta=1.0, defer=True)
       Po = self.P['obs_out_h']
-      ops.ln_act_fwd(sel(Ao.z), Po.gamma, Po.beta, sel(Ao.out), sel(Ao.stats), True)
-      xq = self.lin_fwd(self.P['obs_stats'], self.a_obs_stats, sel(Ao.out), sel)
+      ops.ln_act_fwd(sel(Ao.z), Po.gamma, Po.beta, sel(Ao.out), sel(Ao.stats), True, pre=pre)
+      xq, pre = self.lin_fwd(self.P['obs_stats'], self.a_obs_stats, sel(Ao.out), sel, defer=True)
       ops.stats_fwd(xq, b['u_post'][t], sel(b['post_logit']), post[:, t, D:],
-                    self.G, self.C, self.unimix, 0)
+                    self.G, self.C, self.unimix, 0, pre=pre)
     # The prior statistics depend only on deter_t and feed nothing inside the
     # scan (the prior sample is unused by obs_step): evaluate them for all T
     # steps at once, off the sequential critical path.
@@ -760,9 +764,10 @@ class Learner:
       # posterior sample + statistics
       ops.stats_bwd(sel(self.a_obs_stats.z), sel(b['dpost_logit']), dstoch,
                     sel(self.a_obs_stats.dout), self.G, self.C, self.unimix)
-      ops.gemm(sel(self.a_obs_stats.dout), P['obs_stats'].W, sel(Ao.dout), tb=True)
+      pre = ops.gemm(sel(self.a_obs_stats.dout), P['obs_stats'].W, sel(Ao.dout), tb=True,
+                     defer=True)
       ops.ln_act_bwd(sel(Ao.dout), sel(Ao.z), sel(Ao.out), sel(Ao.stats),
-                     Po.gamma, sel(Ao.dz), None, None, False, True)
+                     Po.gamma, sel(Ao.dz), None, None, False, True, pre=pre)
       ops.gemm(sel(Ao.dz), Po.W, ddeter, tb=True, beta=1.0)
       self.core_bwd(ddeter, sel(b['hprev']), self.a_img_in, b['z3'],
                     b['gstats'], sel, sel(b['dz3']), sel(b['dy3']),

@@ -36,7 +36,17 @@ const char* dd_last_error(void);
 int dd_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                 long lda, long ldb, long ldc, int transA, int transB,
                 float alpha, float beta, const float* bias,
-                float* ws, size_t ws_bytes, void* stream);
+                float* ws, size_t ws_bytes, int* deferred, void* stream);
+/* Deferred split-K sum.  With `deferred` != NULL (host pointer) and alpha == 1, a GEMM that
+ * splits K leaves its n = *deferred partial results [n][M][N] at the start of ws instead of
+ * running the reduce pass, and does not touch C; *deferred = 0 means C is complete.  The
+ * consumer kernels below that take (slabs, n_slabs, beta_pre[, bias_pre]) add the slabs in
+ * the reduce pass's order (slabs ascending, + bias, + beta * old input), write the total
+ * back to their input buffer and continue: one launch less per layer of the latency-bound
+ * scans.  Nothing else may use that workspace in between.  dd_splitk_finish is the
+ * stand-alone pass (used when a consumer cannot take slabs). */
+int dd_splitk_finish(const float* slabs, int n_slabs, float* C, long ldc, int M, int N,
+                     float beta, const float* bias, void* stream);
 
 /* Arithmetic of the 128-row tiles of every contraction below: 6 (default) = fp32
  * operands split exactly into three bf16 terms, six cross products on the bf16 matrix
@@ -72,16 +82,19 @@ int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float
 
 /* out = act(LN(z)*gamma+beta), eps 1e-3, population variance; act 0 none,
  * 1 elu.  stats[rows,2] = (mean, rstd), row stride lds.  Norm nets.py:585-602 + get_act. */
-int dd_ln_act_fwd(const float* z, long ldz, const float* gamma, const float* beta,
-                  float* out, long ldo, float* stats, long lds, int rows, int C, int act, void* stream);
+int dd_ln_act_fwd(float* z, long ldz, const float* gamma, const float* beta,
+                  float* out, long ldo, float* stats, long lds, int rows, int C, int act,
+                  const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
+                  void* stream);
 /* dz from dout; if dgamma != NULL also dgamma/dbeta and, if dbias_pre != NULL,
  * the column sum of dz (gradient of a bias added before the norm, as in Conv2D
  * nets.py:548-553); accumulate: += . */
-int dd_ln_act_bwd(const float* dout, long ldd, const float* z, long ldz,
+int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
                   const float* out, long ldo, const float* stats, long lds, const float* gamma,
                   float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
                   int accumulate,
-                  int rows, int C, int act, float* ws, size_t ws_bytes, void* stream);
+                  int rows, int C, int act, float* ws, size_t ws_bytes,
+                  const float* slabs, int n_slabs, float beta_pre, void* stream);
 int dd_ln_bwd_parts(int rows, int C);
 /* dgamma/dbeta only, from stored activations of all scan steps. */
 int dd_ln_param_grad(const float* dout, long ldd, const float* z, long ldz,
@@ -95,9 +108,10 @@ int dd_col_sum(const float* x, long ldx, float* out, float beta, long rows, int 
 
 /* RSSM._gru nets.py:149-160 after the [D+U,3D] matmul: LayerNorm over all 3D,
  * reset/cand/update gates, new deter.  z3 [rows,3D]; h, hn [rows,D]. */
-int dd_gru_cell_fwd(const float* z3, long ldz, const float* gamma, const float* beta,
+int dd_gru_cell_fwd(float* z3, long ldz, const float* gamma, const float* beta,
                     const float* h, long ldh, float* hn, long ldn, float* stats, long lds,
-                    int rows, int D, void* stream);
+                    int rows, int D, const float* slabs, int n_slabs, float beta_pre,
+                    void* stream);
 /* dz3 (through LN), dh = (1-update)*dhn, dy3 = gradient at the LN output.
  * zx (NULL ok): a [rows,U] region to zero-fill, so that one beta=1 GEMM can
  * then accumulate dz3 @ W^T into the adjacent [dh | dx] buffer. */
@@ -112,9 +126,11 @@ int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
 /* logit = log((1-unimix)*softmax(x)+unimix/C); stoch = one_hot(draw).
  * mode 0: inverse-CDF draw with u[rows,G]; mode 1: argmax.
  * RSSM._stats_layer nets.py:165-170 + OneHotDist.sample tfutils.py:368-378. */
-int dd_stats_sample_fwd(const float* x, long ldx, const float* u, long ldu,
+int dd_stats_sample_fwd(float* x, long ldx, const float* u, long ldu,
                         float* logit, long ldl, float* stoch, long lds,
-                        int rows, int G, int C, float unimix, int mode, void* stream);
+                        int rows, int G, int C, float unimix, int mode,
+                        const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
+                        void* stream);
 /* dx from dlogit (NULL ok) and the straight-through dstoch (NULL ok),
  * tfutils.py:380-381. */
 int dd_stats_sample_bwd(const float* x, long ldx, const float* dlogit, long ldl,

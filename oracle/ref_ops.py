@@ -82,7 +82,9 @@ class RefOps:
 
   # ---- contractions ---------------------------------------------------------
 
-  def gemm(self, A, B, C, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None):
+  def gemm(self, A, B, C, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, defer=False):
+    # (defer: the HIP path may leave split-K partial sums for the consumer; here C is
+    # always complete and None is returned, so consumers get pre=None)
     a = A.t() if ta else A
     b = B.t() if tb else B
     r = alpha * (a @ b)
@@ -125,7 +127,8 @@ class RefOps:
 
   # ---- LayerNorm / GRU ----------------------------------------------------------
 
-  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True):
+  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True, pre=None):
+    assert pre is None
     mean = z.mean(-1, keepdim=True)
     var = ((z - mean) ** 2).mean(-1, keepdim=True)
     rstd = torch.rsqrt(var + LN_EPS)
@@ -140,7 +143,8 @@ class RefOps:
     return dout
 
   def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
-                 dbeta=None, accumulate=False, act=True, dbias_pre=None):
+                 dbeta=None, accumulate=False, act=True, dbias_pre=None, pre=None):
+    assert pre is None
     mean, rstd = stats[:, :1], stats[:, 1:2]
     dy = self._ln_dy(dout, out, act)
     xh = (z - mean) * rstd
@@ -170,7 +174,8 @@ class RefOps:
     r = x.sum(0)
     out.copy_(beta * out + r if beta != 0.0 else r)
 
-  def gru_fwd(self, z3, gamma, beta, h, hn, stats):
+  def gru_fwd(self, z3, gamma, beta, h, hn, stats, pre=None):
+    assert pre is None
     D = h.shape[1]
     mean = z3.mean(-1, keepdim=True)
     var = ((z3 - mean) ** 2).mean(-1, keepdim=True)
@@ -227,7 +232,8 @@ class RefOps:
       o *= 2
     return x[..., :C]
 
-  def stats_fwd(self, x, u, logit, stoch, G, C, unimix, mode=0):
+  def stats_fwd(self, x, u, logit, stoch, G, C, unimix, mode=0, pre=None):
+    assert pre is None
     rows = x.shape[0]
     xv = x.reshape(rows, G, C)
     m = xv.max(-1, keepdim=True).values

@@ -457,3 +457,53 @@ def test_reset_mask_pairs_and_actent_large(hip, ref):
     res = both(hip, ref, lambda ops, os_, out: ops.actent_stats(os_[:, A:], rows, 0.1, 1.0, -2.3, 2.3, out),
                [os_, out], [1])
     close(*res[0], rtol=1e-6, what=f'actent_stats {rows}x{A}')
+
+
+def test_deferred_splitk_sum(hip):
+  """gemm(defer=True) leaves the split-K partial sums to the consumer kernel; every
+  consumer must produce exactly (bitwise) what the reduce pass + plain consumer gives,
+  including the written-back input buffer."""
+  torch.manual_seed(0)
+  dev = 'cuda'
+  rows, K, D = 50, 512, 256
+  x = torch.randn(rows, K, device=dev)
+  def pair(N, consume, beta=0.0, bias=None):
+    W = torch.randn(K, N, device=dev) * 0.05
+    z0 = torch.randn(rows, N, device=dev)
+    za, zb = z0.clone(), z0.clone()
+    hip.gemm(x, W, za, beta=beta, bias=bias)
+    ra = consume(za, None)
+    pre = hip.gemm(x, W, zb, beta=beta, bias=bias, defer=True)
+    assert pre is not None and pre.n > 1, 'shape no longer splits K: pick another'
+    rb = consume(zb, pre)
+    torch.cuda.synchronize()
+    assert torch.equal(za, zb), 'written-back input'
+    for a, b in zip(ra, rb):
+      assert torch.equal(a, b)
+  g, bt = torch.rand(D, device=dev) + 0.5, torch.randn(D, device=dev)
+  def ln(z, pre):
+    out, st = torch.empty_like(z), torch.empty(rows, 2, device=dev)
+    hip.ln_act_fwd(z, g, bt, out, st, True, pre=pre)
+    return out, st
+  pair(D, ln)
+  pair(D, ln, beta=1.0)
+  g3, b3, h = torch.rand(3 * D, device=dev) + 0.5, torch.randn(3 * D, device=dev), torch.randn(rows, D, device=dev)
+  def gru(z, pre):
+    hn, st = torch.empty(rows, D, device=dev), torch.empty(rows, 2, device=dev)
+    hip.gru_fwd(z, g3, b3, h, hn, st, pre=pre)
+    return hn, st
+  pair(3 * D, gru)
+  G, C = 32, 32
+  u = torch.rand(rows, G, device=dev)
+  def stats(z, pre):
+    lg, sm = torch.empty(rows, G * C, device=dev), torch.empty(rows, G * C, device=dev)
+    hip.stats_fwd(z, u, lg, sm, G, C, 0.01, 0, pre=pre)
+    return lg, sm
+  pair(G * C, stats, bias=torch.randn(G * C, device=dev))
+  zz, oo = torch.randn(rows, D, device=dev), torch.randn(rows, D, device=dev)
+  st = torch.stack([zz.mean(1), 1.0 / (zz.var(1, unbiased=False) + 1e-3).sqrt()], 1).contiguous()
+  def lnb(dout, pre):
+    dz = torch.empty(rows, D, device=dev)
+    hip.ln_act_bwd(dout, zz, oo, st, g, dz, None, None, False, True, pre=pre)
+    return (dz,)
+  pair(D, lnb)
