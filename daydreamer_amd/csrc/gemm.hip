@@ -251,6 +251,28 @@ struct ConvUpB {
   }
 };
 
+// conv "up", all four output parities in one contraction (even k: every parity has the
+// same (k/2)^2 taps and, for class pixel (j,i), the same source pixels (j-m, i-mx); only the
+// filter taps differ).  The parity becomes part of the column index, n = (py,px,cb):
+// B[k=(m,mx,cs)][n] = W[py+2m][px+2mx][cb][cs].  One launch with N = 4*Cb instead of four
+// with N = Cb: full 128-wide tiles for 64-channel layers and a quarter of the gather traffic.
+struct ConvUpB4 {
+  const float* w; int Cb, Cs, kw, nkx, R;
+  FastDiv d_cs, d_nkx, d_cb;
+  template <bool FULL = false>
+  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
+    const int rr = min(r, R - 1), kk = FULL ? k : min(k, kend - 4);
+    int tap, c, m, mx, q, cb;
+    d_cs.divmod(kk, tap, c);
+    d_nkx.divmod(tap, m, mx);
+    d_cb.divmod(rr, q, cb);
+    const int ky = (q >> 1) + 2 * m, kx = (q & 1) + 2 * mx;
+    float4 t = *reinterpret_cast<const float4*>(w + (((long)ky * kw + kx) * Cb + cb) * Cs + c);
+    const bool ok = FULL || k < kend;
+    v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+  }
+};
+
 // filter gradient: rows r = (ky, kx*Cb + cb) (contiguous in runs of kw*Cb),
 // k = small-side pixel (n,sy,sx).
 template <typename T, bool F>
@@ -329,6 +351,21 @@ struct EpiConvUp {
     d_i.divmod(rem, j, i);
     long a = (((long)img * hb + 2 * j + py) * wb + 2 * i + px) * Cb + n;
     big[a] = bias ? v + bias[n] : v;
+  }
+};
+
+struct EpiConvUp4 {  // column n = (py, px, cb)
+  float* big; const float* bias; int npix, nj, ni, hb, wb, Cb;
+  FastDiv d_ji, d_i, d_cb;
+  __device__ __forceinline__ void operator()(int m, int n, float v) const {
+    if (m >= npix || n >= 4 * Cb) return;
+    int img, rem, j, i, q, cb;
+    d_ji.divmod(m, img, rem);
+    d_i.divmod(rem, j, i);
+    d_cb.divmod(n, q, cb);
+    const int y = 2 * j + (q >> 1), x = 2 * i + (q & 1);
+    if (y >= hb || x >= wb) return;
+    big[(((long)img * hb + y) * wb + x) * Cb + cb] = bias ? v + bias[cb] : v;
   }
 };
 
@@ -935,8 +972,13 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
   // column buffer is small enough (<= 1 GiB) that its HBM round trip costs less than
   // the parity form's out-of-range taps (13-55% of its MFMA work at these sizes).
   const size_t cols_bytes = per_img * (size_t)n_img;
+  // (c) with an even k the one-launch parity form below is the faster implicit path, so
+  // the column buffer only pays up to 512 MiB (measured: 6x6x256 -> 14x14x128 k4, 737 MB of
+  // columns: 986 us here vs 864 us implicit; 2x2x512 -> 6x6x256 k4, 118 MB: 351 vs 640 us).
+  const bool uni_ok = aligned16(small) && aligned16(w) && (Cs % 4 == 0) && k % 2 == 0 && 4 * Cb >= 64;
+  const size_t cols_max = uni_ok ? ((size_t)512 << 20) : ((size_t)1 << 30);
   if (wsp && ws_bytes >= 2 * per_img &&
-      (Cb <= 8 || (cols_bytes <= ((size_t)1 << 30) && cols_bytes <= ws_bytes / 2))) {
+      (Cb <= 8 || (cols_bytes <= cols_max && cols_bytes <= ws_bytes / 2))) {
     // cols = small[npix,Cs] @ W^T[Cs, k*k*Cb] (dense GEMM), then a gather.
     const int chunk = (int)((ws_bytes / 2) / per_img);  // second half: split-K scratch
     float* cols = wsp;
@@ -962,6 +1004,21 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
     return 0;
   }
   const int vec = aligned16(small) && aligned16(w) && (Cs % 4 == 0);
+  if (uni_ok) {  // all parities in one contraction
+    const int nj = (hb + 1) / 2, ni = (wb + 1) / 2, nk = k / 2;
+    const int M = n_img * nj * ni, N = 4 * Cb, K = nk * nk * Cs;
+    EpiConvUp4 ep{big, bias, M, nj, ni, hb, wb, Cb, FastDiv(nj * ni), FastDiv(ni), FastDiv(Cb)};
+    ConvUpA<true> al{small, M, nj, ni, hs, ws_, Cs, nk, vec, FastDiv(nj * ni), FastDiv(ni), FastDiv(Cs), FastDiv(nk)};
+    ConvUpB4 bl{w, Cb, Cs, k, nk, N, FastDiv(Cs), FastDiv(nk), FastDiv(Cb)};
+    const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
+    const int tm = dd_ceil_div(M, 128);
+    if (N > 64)
+      launch_tile<128, 128, true, true>(dim3(tm * dd_ceil_div(N, 128), 1, 1), st, al, bl, ep, K, kps, tm);
+    else
+      launch_tile<128, 64, true, true>(dim3(tm, 1, 1), st, al, bl, ep, K, kps, tm);
+    DD_CHECK_LAUNCH("dd_conv2d_s2_up");
+    return 0;
+  }
   auto launch = [&](auto fast) -> int {
     constexpr bool FF = decltype(fast)::value;
     using AT = ConvUpA<FF>;
