@@ -113,6 +113,19 @@ struct FastDiv {
   }
 };
 
+// four consecutive elements of a gather operand: one 16-byte load for float, one
+// (possibly 2-byte aligned) dword load + byte unpack for uint8 images
+typedef unsigned int __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ void load4_elems(const float* p, float, float v[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4_elems(const unsigned char* p, float s, float v[4]) {
+  const unsigned w = *reinterpret_cast<const u32_unaligned*>(p);
+  v[0] = (float)(w & 255u) * s; v[1] = (float)((w >> 8) & 255u) * s;
+  v[2] = (float)((w >> 16) & 255u) * s; v[3] = (float)(w >> 24) * s;
+}
+
 __device__ __forceinline__ float cvt(float x, float) { return x; }
 __device__ __forceinline__ float cvt(unsigned char x, float s) { return (float)x * s; }
 
@@ -129,11 +142,8 @@ struct ConvDownA {
       d_hw.divmod(rr, n, rem);
       d_w.divmod(rem, sy, sx);
       d_kwc.divmod(kk, ky, o);
-      const float* q = reinterpret_cast<const float*>(big) +
-          (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o;
-      float4 t = *reinterpret_cast<const float4*>(q);
-      const bool ok = FULL || k < kend;
-      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+      load4_elems(big + (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o, scale, v);
+      if (!(FULL || k < kend)) v[0] = v[1] = v[2] = v[3] = 0.f;
       return;
     }
     if (r >= npix) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
@@ -287,11 +297,8 @@ struct ConvWgradA {
       d_hw.divmod(kk, n, rem);
       d_w.divmod(rem, sy, sx);
       d_kwc.divmod(rr, ky, o);
-      const float* q = reinterpret_cast<const float*>(big) +
-          (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o;
-      float4 t = *reinterpret_cast<const float4*>(q);
-      const bool ok = FULL || k < kend;
-      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+      load4_elems(big + (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o, scale, v);
+      if (!(FULL || k < kend)) v[0] = v[1] = v[2] = v[3] = 0.f;
       return;
     }
     if (k >= kend) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
@@ -922,6 +929,10 @@ extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w,
   const int kwc = k * Cb;
   const int vb = aligned16(w) && (Cs % 4 == 0);
   if (big_is_u8) {
+    if (kwc % 4 == 0 && vb) {  // a float4 chunk of the patch row = 4 contiguous bytes
+      ConvDownA<unsigned char, true> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 1, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+      return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+    }
     ConvDownA<unsigned char, false> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 0, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
     return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
   }
@@ -1061,6 +1072,10 @@ extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* s
   const int kwc = k * Cb;
   const int vb = aligned16(small) && (Cs % 4 == 0);
   if (big_is_u8) {
+    if (kwc % 4 == 0 && vb) {
+      ConvWgradA<unsigned char, true> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 1, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+      return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+    }
     ConvWgradA<unsigned char, false> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 0, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
     return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
   }
