@@ -460,11 +460,10 @@ class Agent:
     out = {f'params/{k}': v for k, v in L.export_params().items()}
     for gname in ('model', 'actor', 'critic'):
       g = L.groups[gname]
-      off = 0
       for p in g.specs:
+        off = g.offset[p.name]
         out[f'opt/{gname}/m/{p.name}'] = g.m[off:off + p.size].cpu().numpy().copy().reshape(p.shape)
         out[f'opt/{gname}/v/{p.name}'] = g.v[off:off + p.size].cpu().numpy().copy().reshape(p.shape)
-        off += p.size
       out[f'opt/{gname}/step'] = np.asarray(g.opt_state.cpu().numpy()[0], np.int64)
     out['state/wmkl_scale'] = L.wmkl_scale.cpu().numpy().copy()
     out['state/actent_scale'] = L.actent_scale.cpu().numpy().copy()
@@ -490,13 +489,12 @@ class Agent:
       g.load(params)
     for gname in ('model', 'actor', 'critic'):
       g = L.groups[gname]
-      off = 0
       for p in g.specs:
+        off = g.offset[p.name]
         for slot, buf in (('m', g.m), ('v', g.v)):
           arr = data.get(f'opt/{gname}/{slot}/{p.name}')
           if arr is not None:
             buf[off:off + p.size].copy_(torch.as_tensor(np.asarray(arr)).reshape(-1))
-        off += p.size
       if f'opt/{gname}/step' in data:
         g.opt_state[0] = float(data[f'opt/{gname}/step'])
     if 'state/wmkl_scale' in data:

@@ -50,8 +50,18 @@ class ParamGroup:
     F32 = dtype
     order = [p for p in plist if p.decay] + [p for p in plist if not p.decay]
     self.specs = order
-    self.n = sum(p.size for p in order)
-    self.n_decay = sum(p.size for p in order if p.decay)
+    # every tensor starts on a 16-byte boundary (4 elements): a 3-element bias in the
+    # middle of the arena would otherwise knock every later scale / bias vector off the
+    # float4 paths of the LayerNorm kernels.  The padding stays zero (zero gradient).
+    self.offset, off = {}, 0
+    for p in order:
+      self.offset[p.name] = off
+      off += (p.size + 3) // 4 * 4
+      if p.decay:
+        self.n_decay = off
+    if not any(p.decay for p in order):
+      self.n_decay = 0
+    self.n = off
     self.flat = torch.zeros(self.n, dtype=F32, device=device)
     self.p, self.g = {}, {}
     if trainable:
@@ -59,12 +69,11 @@ class ParamGroup:
       self.m = torch.zeros(self.n, dtype=F32, device=device)
       self.v = torch.zeros(self.n, dtype=F32, device=device)
       self.opt_state = torch.zeros(3, dtype=torch.float64, device=device)
-    off = 0
     for p in order:
+      off = self.offset[p.name]
       self.p[p.name] = self.flat[off:off + p.size].view(p.shape)
       if trainable:
         self.g[p.name] = self.gflat[off:off + p.size].view(p.shape)
-      off += p.size
 
   def load(self, arrays):
     for p in self.specs:

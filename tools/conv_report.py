@@ -14,7 +14,7 @@ for _ in range(2):
   _, state, _ = ag.train(data, state)
 L = ag.learner
 shared = []
-for o in (L.ops_a, L.ops2):
+for o in (L.ops_a, L.ops2, L.ops_b):
   o.trace = shared
 L.plan = graphs.EagerPlan()
 torch.cuda.synchronize()
@@ -27,3 +27,13 @@ for lab, f, ms in rows:
 print('--- slowest GEMMs')
 for lab, f, ms in sorted((r for r in rows if r[0].startswith('gemm')), key=lambda r: -r[2])[:12]:
   print(f'{lab:60s} {ms*1e3:8.1f} us {f/ms/1e9:7.1f} TF')
+
+print('--- GEMMs by shape (count, total us, avg us, TF)')
+import collections
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for lab, f, ms in rows:
+  if lab.startswith('gemm'):
+    k = ' '.join(lab.split(' ')[:4])
+    agg[k][0] += 1; agg[k][1] += ms; agg[k][2] += f
+for k, (n, ms, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+  print(f'{k:40s} x{n:4d} {ms*1e3:9.1f} us  avg {ms*1e3/n:7.1f} us {f/ms/1e9:7.1f} TF')
