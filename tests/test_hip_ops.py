@@ -507,3 +507,23 @@ def test_deferred_splitk_sum(hip):
     hip.ln_act_bwd(dout, zz, oo, st, g, dz, None, None, False, True, pre=pre)
     return (dz,)
   pair(D, lnb)
+
+
+def test_native_fp32_mode(hip, ref):
+  """dd_gemm_set_mode(0): the native v_mfma_f32_32x32x2_f32 loop stays parity-green next to
+  the default split-bf16 loop; an invalid mode is rejected."""
+  assert hip.lib.dd_gemm_set_mode(7) == -1
+  prev = hip.lib.dd_gemm_set_mode(0)
+  try:
+    assert prev == 6
+    for M, N, K, ta, tb in ((300, 260, 1999, 0, 0), (2500, 512, 1280, 0, 1), (50, 768, 512, 1, 0)):
+      A = rnd(*((K, M) if ta else (M, K)), seed=1)
+      B = rnd(*((N, K) if tb else (K, N)), seed=2)
+      C = torch.zeros(M, N)
+      res = both(hip, ref, lambda ops, A, B, C: ops.gemm(A, B, C, bool(ta), bool(tb)), [A, B, C], [2])
+      close(*res[0], what=f'native gemm {M}x{N}x{K}')
+    big, w, small = rnd(6, 30, 30, 16, seed=3), rnd(6, 6, 16, 32, seed=4) * 0.1, torch.zeros(6, 13, 13, 32)
+    res = both(hip, ref, lambda ops, big, w, small: ops.conv_down(big, w, None, small, 6), [big, w, small], [2])
+    close(*res[0], what='native conv_down')
+  finally:
+    assert hip.lib.dd_gemm_set_mode(6) == 0
