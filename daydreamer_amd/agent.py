@@ -326,8 +326,12 @@ class Agent:
         self._apply_load(saved)
       L = self.learner
       self._plan, self._pipe, self._train_calls = None, None, 0
-    L.upload(self._shard(data))
     carry = isinstance(state, TrainState) and state.owner is L
+    if self._pipe is not None and not carry:
+      # reset_carry reads world-model weights and writes the carried state on this
+      # stream: order it after the world-model phase still in flight
+      torch.cuda.current_stream(self.device).wait_stream(self._pipe.s1)
+    L.upload(self._shard(data))
     if not carry:
       L.reset_carry()
     if self._pipeline and self._train_calls >= 1 and 'key' not in data:

@@ -250,7 +250,8 @@ def test_pipelined_steps_equal_sequential(hip):
     ag = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': mode}))
     state, mets = None, []
     for i in range(9):
-      _, state, m = ag.train(batches[i % 4], state)
+      # (call 5 starts from the initial state again: reset_carry next to work in flight)
+      _, state, m = ag.train(batches[i % 4], None if i == 5 else state)
       mets.append(m)
     last = ag.flush()
     if mode:
