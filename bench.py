@@ -91,13 +91,28 @@ def main():
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', 1))
+  if world == 1 and not os.environ.get('DD_BENCH_CHILD') and os.environ.get('DD_FORCE_DIST') != '1':
+    # Single GPU: run the measurement in a child process.  The one-time stream-pair
+    # selection of the pipeline re-captures HIP graphs; should the runtime die in it, the
+    # measurement is repeated with the default pair instead of losing the bench line.
+    import subprocess
+    for tune in ('1', '0') if os.environ.get('DD_PIPE_TUNE', '1') == '1' else ('0',):
+      env = dict(os.environ, DD_BENCH_CHILD='1', DD_PIPE_TUNE=tune)
+      r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                         stdout=subprocess.PIPE, text=True)
+      lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+      if r.returncode == 0 and lines:
+        print(lines[-1])
+        return
+      sys.stderr.write(f'bench child (DD_PIPE_TUNE={tune}) failed with code {r.returncode}\n')
+    sys.exit(1)
   rank = int(os.environ.get('RANK', 0))
   local = int(os.environ.get('LOCAL_RANK', 0))
   ndev = torch.cuda.device_count()
   local = local % max(ndev, 1)  # (testing aid: several ranks may share one GPU under gloo)
   os.environ['LOCAL_RANK'] = str(local)
   torch.cuda.set_device(local)
-  if world > 1:
+  if world > 1 or os.environ.get('DD_FORCE_DIST') == '1':
     import torch.distributed as dist
     backend = os.environ.get('DD_DIST_BACKEND', 'nccl')  # nccl == RCCL on ROCm
     if backend == 'nccl':
@@ -134,6 +149,9 @@ def main():
       return plan.step()
     plan.replay()
     return L.read_metrics()
+
+  if pipelined:  # finish the one-time stream-pair selection (real train steps, untimed)
+    plan.tune(resident_step)
 
   # ---- timed region: inputs already resident in HBM
   barrier()
@@ -275,7 +293,7 @@ def main():
                     critic_loss=float(mets['extr_critic_loss'])),
         roofline=roof, cpu_baseline=base)
     print(json.dumps(out))
-  if world > 1:
+  if world > 1 or os.environ.get('DD_FORCE_DIST') == '1':
     import torch.distributed as dist
     dist.destroy_process_group()
 

@@ -29,6 +29,9 @@ from . import replay as replay_mod
 from . import spec as spec_mod
 
 
+_FAKE_COMM = os.environ.get('DD_FAKE_COMM') == '1'  # experiment: collectives as no-ops
+
+
 class DistComm:
   """Sum / max all-reduce over the data-parallel group (RCCL on GPUs)."""
 
@@ -39,9 +42,13 @@ class DistComm:
     self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
   def allreduce_sum(self, t):
+    if _FAKE_COMM:
+      return
     self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
   def allreduce_max(self, t):
+    if _FAKE_COMM:
+      return
     self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
 
 
@@ -94,14 +101,27 @@ class Pipeline:
     self.L = learner
     self.device = device
     self.comm = comm  # data-parallel: communicator of the metric read-out
-    # dedicated streams for both phases: work queued on the default stream does not run
-    # next to other streams
-    # (equal priorities: a high-priority stream for either phase was measured at 62 / 99
-    # instead of 43.5 ms per step)
-    self.s1 = torch.cuda.Stream(device)   # world-model phase
-    self.s2 = torch.cuda.Stream(device)   # behaviour phase
-    self.s3 = torch.cuda.Stream(device)   # metric read-out
-    self.pa1, self.pa2, self.pb = learner.capture_pipeline()
+    # Dedicated streams for both phases (work queued on the default stream does not run
+    # next to other streams; equal priorities: a high-priority stream for either phase was
+    # measured at 62 / 99 instead of 43.5 ms per step).  Which two streams matters: ROCm
+    # multiplexes HIP streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) in
+    # creation order, and the step time swings between 38 and 48 ms with the queues the
+    # two phases (and the graphs' internal branches) land on - it flipped from one to the
+    # other merely by initialising an RCCL process group.  So the pair can be chosen by
+    # measurement: tune() cycles through the ordered pairs of a small pool (3 real train
+    # steps each, timed by device events, each pair with its own captured graphs) and
+    # keeps the fastest.  It is an explicit call (bench.py, tools/train_c2.py); without it
+    # the first pair is used.
+    self.pool = [torch.cuda.Stream(device) for _ in range(4)]
+    self.cands = [(a, b) for a in range(4) for b in range(4) if a != b]
+    self.tuned = True
+    self.periods = {}
+    self.ticks = []
+    self.s3 = torch.cuda.Stream(device)             # metric read-out
+    # one set of captured graphs per stream pair: a graph executable is only ever
+    # launched on one stream (relaunching it on another one crashes the runtime)
+    self.plans = {}
+    self._use_pair(0, 1)
     self.ev_in = torch.cuda.Event()
     self.ev_a = torch.cuda.Event()
     self.ev_b = [torch.cuda.Event(), torch.cuda.Event()]
@@ -110,6 +130,13 @@ class Pipeline:
     self.pub_b = [{k: torch.empty_like(v) for k, v in live.items()} for _ in range(2)]
     self.k = 0
     self.pending = None  # parity of the step whose metrics have not been returned yet
+
+  def _use_pair(self, a, b):
+    if (a, b) not in self.plans:
+      torch.cuda.synchronize(self.device)
+      self.plans[(a, b)] = self.L.capture_pipeline()
+    self.pa1, self.pa2, self.pb = self.plans[(a, b)]
+    self.s1, self.s2 = self.pool[a], self.pool[b]
 
   @property
   def n_graphs(self):
@@ -120,13 +147,41 @@ class Pipeline:
       for k, v in self.L.metric_tensors().items():
         pub[k].copy_(v)
 
+  TRIAL = 3  # steps per candidate pair while tuning; the last period of a trial counts
+
+  def _tune(self):
+    """Pick the streams of step self.k; called before it is enqueued."""
+    c, r = divmod(self.k, self.TRIAL)
+    if r == 0 and c > 0 and (c - 1) < len(self.cands):
+      # the previous trial's last two ticks are complete once step k-2 has been read;
+      # tick of step k-1 may still be in flight: wait for it (tuning only)
+      t0, t1 = self.ticks[self.k - 2], self.ticks[self.k - 1]
+      t1.synchronize()
+      self.periods[self.cands[c - 1]] = t0.elapsed_time(t1)
+    if c < len(self.cands):
+      a, b = self.cands[c]
+    else:
+      a, b = min(self.periods, key=self.periods.get)
+      self.tuned = True
+      self.ticks = []
+    if (self.pool[a], self.pool[b]) != (self.s1, self.s2):
+      self.s1.synchronize()
+      self.s2.synchronize()
+      self._use_pair(a, b)
+    if self.tuned:
+      self.plans = {(a, b): self.plans[(a, b)]}  # drop the other candidates' graphs
+
   def step(self):
     """Enqueue one step; returns the metrics of the previous pipelined step (None for
     the first).  The caller's current stream holds the uploaded inputs."""
     cur = torch.cuda.current_stream(self.device)
+    if not self.tuned:
+      self._tune()
     s1, s2 = self.s1, self.s2
     par = self.k & 1
     s1.wait_stream(cur)                    # inputs / carry reset issued by the caller
+    if self.k > 0:
+      s1.wait_event(self.ev_a)             # (the previous step may have used other streams)
     self.pa1.replay_on(s1)
     self.ev_in.record(s1)
     if self.pending is not None:
@@ -135,13 +190,29 @@ class Pipeline:
     self._publish(self.pub_a[par], s1)
     self.ev_a.record(s1)
     s2.wait_event(self.ev_a)
+    if self.pending is not None:
+      s2.wait_event(self.ev_b[par ^ 1])
     self.pb.replay_on(s2)
     self._publish(self.pub_b[par], s2)
     self.ev_b[par].record(s2)
+    if not self.tuned:
+      tick = torch.cuda.Event(enable_timing=True)
+      tick.record(s2)
+      self.ticks.append(tick)
     cur.wait_event(self.ev_in)             # the next upload must not overtake A1's reads
     prev, self.pending = self.pending, par
     self.k += 1
     return None if prev is None else self._read(prev)
+
+  def tune(self, run_step):
+    """Select the stream pair by measurement: run_step() must perform one train step
+    (through step()); 12 candidate pairs x 3 steps."""
+    if os.environ.get('DD_PIPE_TUNE', '1') != '1':
+      return
+    self.flush()
+    self.k, self.periods, self.ticks, self.tuned = 0, {}, [], False
+    while not self.tuned:
+      run_step()
 
   def _read(self, par):
     L = self.L
@@ -156,7 +227,7 @@ class Pipeline:
       for k in ('sums', 'maxs'):
         merged[k] = a[k].clone()
         merged[k][rows] = b[k][rows]
-      if self.comm is not None and L.world > 1:
+      if self.comm is not None:
         self.comm.allreduce_sum(merged['sums'])
         self.comm.allreduce_max(merged['maxs'])
         for k in L.stat_prereduced:  # identical on every rank already
@@ -214,7 +285,10 @@ class Agent:
     self.rank, self.world, self.comm = 0, 1, None
     try:
       import torch.distributed as dist
-      if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+      # (DD_FORCE_DIST=1: run the collective code path even with a single rank - a smoke
+      # test of the RCCL / graph-cut / multi-communicator plumbing on a one-GPU box)
+      if dist.is_available() and dist.is_initialized() and (
+          dist.get_world_size() > 1 or os.environ.get('DD_FORCE_DIST') == '1'):
         self.comm = DistComm()
         self.rank, self.world = self.comm.rank, self.comm.world
     except ImportError:
@@ -365,6 +439,18 @@ class Agent:
     return outs, TrainState(L), metrics
 
   train_step = train  # BASELINE.json names the learner step `train_step`
+
+  def tune_pipeline(self, data, state=None):
+    """Optional, once: choose the pipeline's stream pair by measurement (36 real train
+    steps on `data`; see Pipeline).  Returns the recurrent state to continue from."""
+    box = [state]
+    for _ in range(2 if self._pipe is None else 0):   # eager step + pipeline creation
+      _, box[0], _ = self.train(data, box[0])
+    if self._pipe is not None:
+      def run():
+        _, box[0], _ = self.train(data, box[0])
+      self._pipe.tune(run)
+    return box[0]
 
   def flush(self):
     """Drain the two-stream pipeline (no-op otherwise); returns the metrics of the

@@ -28,6 +28,7 @@ Design (MI355X-first):
 """
 
 import contextlib
+import os
 import math
 
 import numpy as np
@@ -412,9 +413,12 @@ class Learner:
 
   def allreduce(self, t):
     """Sum over data-parallel ranks (RCCL); a graph cut point."""
-    if self.comm is not None and self.world > 1:
+    if self.comm is not None:
       comm = self.comm  # the phase's communicator at issue time (the cut runs at replay)
-      self.plan.cut(lambda: comm.allreduce_sum(t))
+      if os.environ.get('DD_DIST_CAPTURE') == '1':  # experiment: collective inside the graph
+        comm.allreduce_sum(t)
+      else:
+        self.plan.cut(lambda: comm.allreduce_sum(t))
 
   def lin_fwd(self, P, A, x, sel=None, defer=False):
     """Linear (+ LayerNorm + ELU).  The GEMM of a normed layer leaves a split-K sum to
@@ -1288,7 +1292,7 @@ class Learner:
     if host is None:
       sums = self.stat_sums.clone()
       maxs = self.stat_maxs.clone()
-      if self.comm is not None and self.world > 1:
+      if self.comm is not None:
         self.comm.allreduce_sum(sums)
         self.comm.allreduce_max(maxs)
         for k in self.stat_prereduced:  # identical on every rank already
