@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  PYTHONPATH=$GRAFT_REPO_ROOT timeout 300 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o b --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 3 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
+  DD_PIPE_TUNE=0 PYTHONPATH=$GRAFT_REPO_ROOT timeout 300 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o b --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 3 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
 done
 python - <<PY
 import csv, glob, collections, re
