@@ -170,3 +170,37 @@ def test_learner_matches_oracle_multicam_128():
                             imag_horizon=2)
   cfg = cfg.update({'decoder.cnn_kernels': [5, 5, 6, 6, 2]})
   run_pair(cfg, steps=1, image=128, cameras=2, vector=5, action=3, terminals=0.1)
+
+
+def test_metric_snapshots_and_arena_alignment():
+  """read_metrics(host=...) - the path the pipelined agent uses with per-phase snapshots -
+  equals the live read-out; parameter arenas keep every tensor on a 16-byte boundary, the
+  padding stays exactly zero through optimizer steps, and the behaviour phase's metric
+  slots are tracked."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=2, replay_chunk=4, imag_horizon=3)
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, image=64, vector=5, action=3)
+  L = learner_mod.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params, noise_seed=3,
+                          dtype=torch.float64)
+  for i in range(2):
+    L.upload(data)
+    L.train_step_device(use_carry=(i > 0))
+  live = L.read_metrics()
+  host = {k: v.cpu().numpy().copy() for k, v in L.metric_tensors().items()}
+  snap = L.read_metrics(host)
+  assert live.keys() == snap.keys()
+  for k in live:
+    assert np.array_equal(live[k], snap[k], equal_nan=True), k
+  names = [L.stat_names[k] for k in sorted(L.stat_b_slots)]
+  assert 'critic_loss' in names and 'kl_loss' not in names and 'image_loss' not in names
+  for g in L.groups.values():
+    used = torch.zeros(g.n, dtype=torch.bool)
+    for p in g.specs:
+      off = g.offset[p.name]
+      assert off % 4 == 0, (p.name, off)
+      assert not used[off:off + p.size].any()
+      used[off:off + p.size] = True
+    assert g.n % 4 == 0 and g.n_decay % 4 == 0
+    pad = ~used
+    assert float(g.flat[pad].abs().sum()) == 0.0
+    if hasattr(g, 'm'):
+      assert float(g.m[pad].abs().sum()) == 0.0 and float(g.gflat[pad].abs().sum()) == 0.0
