@@ -29,9 +29,6 @@ from . import replay as replay_mod
 from . import spec as spec_mod
 
 
-_FAKE_COMM = os.environ.get('DD_FAKE_COMM') == '1'  # experiment: collectives as no-ops
-
-
 class DistComm:
   """Sum / max all-reduce over the data-parallel group (RCCL on GPUs)."""
 
@@ -42,13 +39,9 @@ class DistComm:
     self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
   def allreduce_sum(self, t):
-    if _FAKE_COMM:
-      return
     self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
   def allreduce_max(self, t):
-    if _FAKE_COMM:
-      return
     self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
 
 

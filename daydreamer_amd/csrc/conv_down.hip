@@ -1,0 +1,29 @@
+// Stride-2 VALID convolution as an implicit GEMM (encoder forward, decoder backward-data).
+#include "gemm_core.h"
+
+extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const float* bias,
+                                 float* small, int n_img, int hb, int wb, int Cb,
+                                 int hs, int ws_, int Cs, int k, float in_scale,
+                                 float* wsp, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_down: geometry");
+  const int M = n_img * hs * ws_, N = Cs, K = k * k * Cb;
+  const int kwc = k * Cb;
+  const int vb = aligned16(w) && (Cs % 4 == 0);
+  if (big_is_u8) {
+    if (kwc % 4 == 0 && vb) {  // a float4 chunk of the patch row = 4 contiguous bytes
+      ConvDownA<unsigned char, true> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 1, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+      return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+    }
+    ConvDownA<unsigned char, false> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 0, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+    return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+  }
+  const int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
+  if (vec && vb) {
+    ConvDownA<float, true> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+    return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+  }
+  ConvDownA<float, false> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+  return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
+}
+

@@ -1,0 +1,29 @@
+// Filter gradient of the stride-2 convolutions.
+#include "gemm_core.h"
+
+extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float* dw,
+                                  int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
+                                  float in_scale, float beta, float* wsp, size_t ws_bytes,
+                                  void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_wgrad: geometry");
+  const int M = k * k * Cb, N = Cs, K = n_img * hs * ws_;
+  const int kwc = k * Cb;
+  const int vb = aligned16(small) && (Cs % 4 == 0);
+  if (big_is_u8) {
+    if (kwc % 4 == 0 && vb) {
+      ConvWgradA<unsigned char, true> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 1, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+      return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+    }
+    ConvWgradA<unsigned char, false> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 0, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+    return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+  }
+  const int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
+  if (vec && vb) {
+    ConvWgradA<float, true> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+    return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+  }
+  ConvWgradA<float, false> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+  return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
+}
+

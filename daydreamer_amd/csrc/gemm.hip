@@ -16,858 +16,9 @@
 // Global->register->LDS double buffering, one barrier per k-tile.
 // Split-K (deterministic: slabs in a caller workspace + a reduce pass) gives
 // small-M / huge-K problems enough workgroups to cover 256 CUs.
-#include "dd_common.h"
-#include <stdlib.h>
-#include <string.h>
-#include <type_traits>
-#include "../../include/daydreamer_hip.h"
+#include "gemm_core.h"
 
-namespace {
-
-// k-tile of the 128x128 tile (16 measured faster than 32: 109 vs 92 TF at 4096^3)
-#ifndef BKBIG
-#define BKBIG 16
-#endif
-
-// ---------------------------------------------------------------------------
-// Operand loaders.  load4(r, k, kend, v) returns four consecutive elements
-// along the operand's contiguous axis: KC = (r, k..k+3), RC = (r..r+3, k).
-// ---------------------------------------------------------------------------
-
-// F = true is the branch-free fast path (16-byte aligned, ld, R and K multiples of
-// 4): out-of-range rows are clamped (they only feed masked outputs), the K tail is zeroed
-// by a select.  Ablation: bounds-check branches in the loaders cost ~15% of GEMM time.
-template <bool F>
-struct MatKC {  // op(X)[r][k] = p[r*ld + k]
-  const float* p; long ld; int R; int vec;
-  template <bool FULL = false>
-  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
-    if constexpr (F) {
-      const int rr = min(r, R - 1), kk = FULL ? k : min(k, kend - 4);
-      float4 t = *reinterpret_cast<const float4*>(p + (long)rr * ld + kk);
-      const bool ok = FULL || k < kend;
-      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
-      return;
-    }
-    if (r < R) {
-      const float* q = p + (long)r * ld + k;
-      if (vec && k + 3 < kend) {
-        float4 t = *reinterpret_cast<const float4*>(q);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (k + j < kend) ? q[j] : 0.f;
-      }
-    } else {
-      v[0] = v[1] = v[2] = v[3] = 0.f;
-    }
-  }
-};
-
-template <bool F>
-struct MatRC {  // op(X)[r][k] = p[k*ld + r]
-  const float* p; long ld; int R; int vec;
-  template <bool FULL = false>
-  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
-    if constexpr (F) {
-      const int rr = min(r, R - 4), kk = FULL ? k : min(k, kend - 1);
-      float4 t = *reinterpret_cast<const float4*>(p + (long)kk * ld + rr);
-      const bool ok = FULL || k < kend;
-      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
-      return;
-    }
-    if (k < kend) {
-      const float* q = p + (long)k * ld + r;
-      if (vec && r + 3 < R) {
-        float4 t = *reinterpret_cast<const float4*>(q);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (r + j < R) ? q[j] : 0.f;
-      }
-    } else {
-      v[0] = v[1] = v[2] = v[3] = 0.f;
-    }
-  }
-};
-
-// Division by a launch-constant via multiply-high (valid for dividends < 2^31): the
-// gather loaders decode (image, y, x) / (tap, channel) from linear indices every load,
-// and a 32-bit integer division costs ~25 VALU instructions on gfx950.
-struct FastDiv {
-  unsigned mul, shr, d;
-  __host__ __device__ FastDiv() : mul(0), shr(0), d(1) {}
-  __host__ explicit FastDiv(int dd) {
-    d = (unsigned)(dd < 1 ? 1 : dd);
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    shr = l;
-  }
-  __device__ __forceinline__ int div(int n) const {
-    return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr);
-  }
-  __device__ __forceinline__ void divmod(int n, int& q, int& r) const {
-    q = div(n);
-    r = n - q * (int)d;
-  }
-};
-
-// four consecutive elements of a gather operand: one 16-byte load for float, one
-// (possibly 2-byte aligned) dword load + byte unpack for uint8 images
-typedef unsigned int __attribute__((aligned(1))) u32_unaligned;
-__device__ __forceinline__ void load4_elems(const float* p, float, float v[4]) {
-  float4 t = *reinterpret_cast<const float4*>(p);
-  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-}
-__device__ __forceinline__ void load4_elems(const unsigned char* p, float s, float v[4]) {
-  const unsigned w = *reinterpret_cast<const u32_unaligned*>(p);
-  v[0] = (float)(w & 255u) * s; v[1] = (float)((w >> 8) & 255u) * s;
-  v[2] = (float)((w >> 16) & 255u) * s; v[3] = (float)(w >> 24) * s;
-}
-
-__device__ __forceinline__ float cvt(float x, float) { return x; }
-__device__ __forceinline__ float cvt(unsigned char x, float s) { return (float)x * s; }
-
-// conv "down": rows = output pixels (n,sy,sx), k = (ky, kx*Cb + cb).
-template <typename T, bool F>
-struct ConvDownA {
-  const T* big; int npix, hs, ws, hb, wb, Cb, kwc; float scale; int vec;
-  FastDiv d_hw, d_w, d_kwc;
-  template <bool FULL = false>
-  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
-    if constexpr (F) {  // branch-free: clamp the pixel, zero the K tail
-      const int rr = min(r, npix - 1), kk = FULL ? k : min(k, kend - 4);
-      int n, rem, sy, sx, ky, o;
-      d_hw.divmod(rr, n, rem);
-      d_w.divmod(rem, sy, sx);
-      d_kwc.divmod(kk, ky, o);
-      load4_elems(big + (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o, scale, v);
-      if (!(FULL || k < kend)) v[0] = v[1] = v[2] = v[3] = 0.f;
-      return;
-    }
-    if (r >= npix) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
-    int n = r / (hs * ws); int rem = r - n * hs * ws;
-    int sy = rem / ws; int sx = rem - sy * ws;
-    long base = (((long)n * hb + 2 * sy) * wb + 2 * sx) * Cb;
-    long rowpitch = (long)wb * Cb;
-    if (vec && k + 3 < kend) {
-      int ky = k / kwc; int o = k - ky * kwc;
-      const float* q = reinterpret_cast<const float*>(big) + base + ky * rowpitch + o;
-      float4 t = *reinterpret_cast<const float4*>(q);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int kk = k + j;
-        if (kk < kend) {
-          int ky = kk / kwc; int o = kk - ky * kwc;
-          v[j] = cvt(big[base + ky * rowpitch + o], scale);
-        } else {
-          v[j] = 0.f;
-        }
-      }
-    }
-  }
-};
-
-// conv "up", one output-parity class: rows = class pixels (n,j,i), output
-// pixel (2j+py, 2i+px); k = (tap=(m,mx), cs) with source pixel (j-m, i-mx).
-template <bool F>
-struct ConvUpA {
-  const float* small; int npix, nj, ni, hs, ws, Cs, nkx; int vec;
-  FastDiv d_ji, d_i, d_cs, d_nkx;
-  template <bool FULL = false>
-  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
-    if constexpr (F) {  // branch-free: clamp pixel / tap source, zero by select
-      const int rr = min(r, npix - 1), kk = FULL ? k : min(k, kend - 4);
-      int n, rem, j, i, tap, c, m, mx;
-      d_ji.divmod(rr, n, rem);
-      d_i.divmod(rem, j, i);
-      d_cs.divmod(kk, tap, c);
-      d_nkx.divmod(tap, m, mx);
-      int sy = j - m, sx = i - mx;
-      const bool ok = (FULL || k < kend) && sy >= 0 && sy < hs && sx >= 0 && sx < ws;
-      sy = min(max(sy, 0), hs - 1); sx = min(max(sx, 0), ws - 1);
-      float4 t = *reinterpret_cast<const float4*>(small + (((long)n * hs + sy) * ws + sx) * Cs + c);
-      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
-      return;
-    }
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (r >= npix || k >= kend) return;
-    int n = r / (nj * ni); int rem = r - n * nj * ni;
-    int j = rem / ni; int i = rem - j * ni;
-    if (vec) {
-      int tap = k / Cs; int c = k - tap * Cs;
-      int m = tap / nkx; int mx = tap - m * nkx;
-      int sy = j - m, sx = i - mx;
-      if (sy < 0 || sy >= hs || sx < 0 || sx >= ws) return;
-      const float* q = small + (((long)n * hs + sy) * ws + sx) * Cs + c;
-      float4 t = *reinterpret_cast<const float4*>(q);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int kk = k + e;
-        if (kk >= kend) continue;
-        int tap = kk / Cs; int c = kk - tap * Cs;
-        int m = tap / nkx; int mx = tap - m * nkx;
-        int sy = j - m, sx = i - mx;
-        if (sy < 0 || sy >= hs || sx < 0 || sx >= ws) continue;
-        v[e] = small[(((long)n * hs + sy) * ws + sx) * Cs + c];
-      }
-    }
-  }
-};
-
-// conv "up" filter operand: B[k=(tap,cs)][n=cb] = W[ky][kx][cb][cs].
-template <bool F>
-struct ConvUpB {
-  const float* w; int Cb, Cs, kw, nkx, py, px; int vec;
-  FastDiv d_cs, d_nkx;
-  template <bool FULL = false>
-  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
-    if constexpr (F) {
-      const int rr = min(r, Cb - 1), kk = FULL ? k : min(k, kend - 4);
-      int tap, c, m, mx;
-      d_cs.divmod(kk, tap, c);
-      d_nkx.divmod(tap, m, mx);
-      int ky = py + 2 * m, kx = px + 2 * mx;
-      float4 t = *reinterpret_cast<const float4*>(w + (((long)ky * kw + kx) * Cb + rr) * Cs + c);
-      const bool ok = FULL || k < kend;
-      v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
-      return;
-    }
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (r >= Cb || k >= kend) return;
-    if (vec) {
-      int tap = k / Cs; int c = k - tap * Cs;
-      int m = tap / nkx; int mx = tap - m * nkx;
-      int ky = py + 2 * m, kx = px + 2 * mx;
-      const float* q = w + (((long)ky * kw + kx) * Cb + r) * Cs + c;
-      float4 t = *reinterpret_cast<const float4*>(q);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int kk = k + e;
-        if (kk >= kend) continue;
-        int tap = kk / Cs; int c = kk - tap * Cs;
-        int m = tap / nkx; int mx = tap - m * nkx;
-        int ky = py + 2 * m, kx = px + 2 * mx;
-        v[e] = w[(((long)ky * kw + kx) * Cb + r) * Cs + c];
-      }
-    }
-  }
-};
-
-// conv "up", all four output parities in one contraction (even k: every parity has the
-// same (k/2)^2 taps and, for class pixel (j,i), the same source pixels (j-m, i-mx); only the
-// filter taps differ).  The parity becomes part of the column index, n = (py,px,cb):
-// B[k=(m,mx,cs)][n] = W[py+2m][px+2mx][cb][cs].  One launch with N = 4*Cb instead of four
-// with N = Cb: full 128-wide tiles for 64-channel layers and a quarter of the gather traffic.
-struct ConvUpB4 {
-  const float* w; int Cb, Cs, kw, nkx, R;
-  FastDiv d_cs, d_nkx, d_cb;
-  template <bool FULL = false>
-  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
-    const int rr = min(r, R - 1), kk = FULL ? k : min(k, kend - 4);
-    int tap, c, m, mx, q, cb;
-    d_cs.divmod(kk, tap, c);
-    d_nkx.divmod(tap, m, mx);
-    d_cb.divmod(rr, q, cb);
-    const int ky = (q >> 1) + 2 * m, kx = (q & 1) + 2 * mx;
-    float4 t = *reinterpret_cast<const float4*>(w + (((long)ky * kw + kx) * Cb + cb) * Cs + c);
-    const bool ok = FULL || k < kend;
-    v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
-  }
-};
-
-// filter gradient: rows r = (ky, kx*Cb + cb) (contiguous in runs of kw*Cb),
-// k = small-side pixel (n,sy,sx).
-template <typename T, bool F>
-struct ConvWgradA {
-  const T* big; int hs, ws, hb, wb, Cb, kwc, R; float scale; int vec;
-  FastDiv d_hw, d_w, d_kwc;
-  template <bool FULL = false>
-  __device__ __forceinline__ void load4(int r, int k, int kend, float v[4]) const {
-    if constexpr (F) {  // branch-free (R % 4 == 0): clamp, zero the K tail by select
-      const int rr = min(r, R - 4), kk = FULL ? k : min(k, kend - 1);
-      int n, rem, sy, sx, ky, o;
-      d_hw.divmod(kk, n, rem);
-      d_w.divmod(rem, sy, sx);
-      d_kwc.divmod(rr, ky, o);
-      load4_elems(big + (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o, scale, v);
-      if (!(FULL || k < kend)) v[0] = v[1] = v[2] = v[3] = 0.f;
-      return;
-    }
-    if (k >= kend) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
-    int n = k / (hs * ws); int rem = k - n * hs * ws;
-    int sy = rem / ws; int sx = rem - sy * ws;
-    long base = (((long)n * hb + 2 * sy) * wb + 2 * sx) * Cb;
-    long rowpitch = (long)wb * Cb;
-    if (vec && r + 3 < R) {
-      int ky = r / kwc; int o = r - ky * kwc;
-      const float* q = reinterpret_cast<const float*>(big) + base + ky * rowpitch + o;
-      float4 t = *reinterpret_cast<const float4*>(q);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int rr = r + j;
-        if (rr < R) {
-          int ky = rr / kwc; int o = rr - ky * kwc;
-          v[j] = cvt(big[base + ky * rowpitch + o], scale);
-        } else {
-          v[j] = 0.f;
-        }
-      }
-    }
-  }
-};
-
-// ---------------------------------------------------------------------------
-// Epilogues: operator()(m, n, acc).
-// ---------------------------------------------------------------------------
-
-struct EpiMat {
-  float* C; long ldc; const float* bias; float alpha, beta; int M, N;
-  float* slab;  // non-null: split-K partial, raw accumulators
-  __device__ __forceinline__ void operator()(int m, int n, float v) const {
-    if (m >= M || n >= N) return;
-    if (slab) {
-      slab[((long)blockIdx.z * M + m) * N + n] = v;
-      return;
-    }
-    float r = alpha * v;
-    if (bias) r += bias[n];
-    long i = (long)m * ldc + n;
-    if (beta != 0.f) r += beta * C[i];
-    C[i] = r;
-  }
-};
-
-struct EpiConvUp {
-  float* big; const float* bias; int npix, nj, ni, hb, wb, Cb, py, px;
-  FastDiv d_ji, d_i;
-
-  __device__ __forceinline__ void operator()(int m, int n, float v) const {
-    if (m >= npix || n >= Cb) return;
-    int img, rem, j, i;
-    d_ji.divmod(m, img, rem);
-    d_i.divmod(rem, j, i);
-    long a = (((long)img * hb + 2 * j + py) * wb + 2 * i + px) * Cb + n;
-    big[a] = bias ? v + bias[n] : v;
-  }
-};
-
-struct EpiConvUp4 {  // column n = (py, px, cb)
-  float* big; const float* bias; int npix, nj, ni, hb, wb, Cb;
-  FastDiv d_ji, d_i, d_cb;
-  __device__ __forceinline__ void operator()(int m, int n, float v) const {
-    if (m >= npix || n >= 4 * Cb) return;
-    int img, rem, j, i, q, cb;
-    d_ji.divmod(m, img, rem);
-    d_i.divmod(rem, j, i);
-    d_cb.divmod(n, q, cb);
-    const int y = 2 * j + (q >> 1), x = 2 * i + (q & 1);
-    if (y >= hb || x >= wb) return;
-    big[(((long)img * hb + y) * wb + x) * Cb + cb] = bias ? v + bias[cb] : v;
-  }
-};
-
-// ---------------------------------------------------------------------------
-// Main loop.
-// ---------------------------------------------------------------------------
-
-// ST = global->register prefetch distance in k-tiles.  Few-tile problems (64x64 tiles,
-// about one workgroup per CU) are latency-bound on the global loads of the next k-tile;
-// keeping ST tiles in flight in registers hides that without needing more workgroups.
-template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int BK = 16,
-          int ST = (BM == 64 && BN == 64) ? 4 : 1>
-__global__ void __launch_bounds__(256, 2)
-k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
-  // row pitch of the k-major LDS tiles: +1 spreads the scalar transposing stores of a
-  // k-contiguous operand over all banks; +4 keeps 16-B alignment for float4 stores.
-  constexpr int PA = AKC ? BM + 1 : BM + 4, PB = BKC ? BN + 1 : BN + 4;
-  constexpr int KQ = BK / 4;  // float4 chunks along k per row
-  __shared__ __attribute__((aligned(16))) float As[2][BK * PA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * PB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
-  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
-  const int kb = blockIdx.z * kps;
-  const int ke = min(K, kb + kps);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;
-  static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  float ra_[ST][NA][4], rb_[ST][NB][4];
-
-  auto gload_t = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4], auto full) {
-    constexpr bool FULL = decltype(full)::value;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int id = tid + i * 256;
-      if (AKC) al.template load4<FULL>(m0 + id / KQ, k0 + (id % KQ) * 4, ke, ra[i]);
-      else     al.template load4<FULL>(m0 + (id % (BM / 4)) * 4, k0 + id / (BM / 4), ke, ra[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int id = tid + i * 256;
-      if (BKC) bl.template load4<FULL>(n0 + id / KQ, k0 + (id % KQ) * 4, ke, rb[i]);
-      else     bl.template load4<FULL>(n0 + (id % (BN / 4)) * 4, k0 + id / (BN / 4), ke, rb[i]);
-    }
-  };
-  // interior k-tiles take the path without any K-tail handling (wave-uniform branch)
-  auto gload = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4]) {
-    if (k0 + BK <= ke) gload_t(k0, ra, rb, std::true_type());
-    else gload_t(k0, ra, rb, std::false_type());
-  };
-  auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int id = tid + i * 256;
-      if (AKC) {
-        int r = id / KQ, kq = (id % KQ) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) As[buf][(kq + j) * PA + r] = ra[i][j];
-      } else {
-        int k = id / (BM / 4), r = (id % (BM / 4)) * 4;
-        *reinterpret_cast<float4*>(&As[buf][k * PA + r]) =
-            make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int id = tid + i * 256;
-      if (BKC) {
-        int r = id / KQ, kq = (id % KQ) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Bs[buf][(kq + j) * PB + r] = rb[i][j];
-      } else {
-        int k = id / (BN / 4), r = (id % (BN / 4)) * 4;
-        *reinterpret_cast<float4*>(&Bs[buf][k * PB + r]) =
-            make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
-      }
-    }
-  };
-
-  const int nk = (ke - kb + BK - 1) / BK;
-  // prologue: tiles 0..ST-1 in flight, tile 0 staged into LDS
-#pragma unroll
-  for (int s = 0; s < ST; ++s)
-    if (s < nk) gload(kb + s * BK, ra_[s], rb_[s]);
-  if (nk > 0) sstore(0, ra_[0], rb_[0]);
-  __syncthreads();
-  const int lk = lane >> 5, lr = lane & 31;
-  for (int t0 = 0; t0 < nk; t0 += ST) {
-#pragma unroll
-    for (int s = 0; s < ST; ++s) {
-      const int t = t0 + s;
-      if (t < nk) {
-        const int buf = t & 1;
-#ifndef EXP_NOLOAD  // ablation switches (tools/gemm_exp.py), see DESIGN.md section 5
-        // register slot s held tile t (already in LDS): refill it with tile t + ST
-        if (t + ST < nk) gload(kb + (t + ST) * BK, ra_[s], rb_[s]);
-#endif
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-          float af[TM], bf[TN];
-#pragma unroll
-          for (int a = 0; a < TM; ++a) af[a] = As[buf][(kk + lk) * PA + wm0 + a * 32 + lr];
-#pragma unroll
-          for (int b = 0; b < TN; ++b) bf[b] = Bs[buf][(kk + lk) * PB + wn0 + b * 32 + lr];
-#pragma unroll
-          for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-#ifndef EXP_NOSTORE
-        if (t + 1 < nk) sstore(buf ^ 1, ra_[(s + 1) % ST], rb_[(s + 1) % ST]);
-#endif
-#ifndef EXP_NOBARRIER
-        __syncthreads();
-#endif
-      }
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        int col = n0 + wn0 + b * 32 + lr;
-        ep(row, col, acc[a][b][r]);
-      }
-}
-
-// ---------------------------------------------------------------------------
-// Split-bf16 main loop: fp32 operands decomposed exactly into three bf16 terms
-// (x = hi + mid + lo, 8 significand bits each, by truncation), products on the bf16
-// matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the rate of the fp32 MFMA), fp32
-// accumulation.  NP = 6 keeps every cross term down to 2^-16 relative (hi*hi, hi*mid,
-// mid*hi, mid*mid, hi*lo, lo*hi): what is dropped is below 2^-22 of a product, i.e.
-// fp32-level accuracy at 16/6 the fp32-MFMA peak.  NP = 3 (hi*hi, hi*mid, mid*hi) is an
-// experiment switch only (2^-15 relative, reduced precision; never the default).
-//
-// LDS: three bit-planes per operand, laid out by the operand's contiguous axis so that
-// both the stores and the fragment reads are wide and conflict-free:
-//   k-contiguous operand   plane[koct][row] = 16-byte slot of 8 consecutive k; a staged
-//                          float4 (row, 4 k) is one ds_write_b64, the MFMA operand (row
-//                          l&31, k-octet l>>5) one ds_read_b128;
-//   row-contiguous operand plane[k][row] bf16; a staged float4 (4 rows, k) is one
-//                          ds_write_b64, the MFMA operand two ds_read_b64_tr_b16 (the
-//                          gfx950 LDS transpose read: a 16-lane group reads a 4(k) x 16(row)
-//                          block, lane i receives row i's four k).
-// Strides are padded to 64 mod 256 bytes (koct / k rows land on different bank quarters).
-// ---------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
-
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-  h = __float_as_uint(x) & 0xFFFF0000u;
-  const float r1 = x - __uint_as_float(h);          // exact
-  m = __float_as_uint(r1) & 0xFFFF0000u;
-  l = __float_as_uint(r1 - __uint_as_float(m));     // exact, <= 8 significant bits
-}
-// bf16(even) | bf16(odd) << 16 from the top halves of two words
-__device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) {
-  return __builtin_amdgcn_perm(odd, even, 0x07060302u);
-}
-
-template <int BX, bool KC, int BK>
-struct PlaneS3 {
-  // bytes per k-octet (KC) / per k (RC); the pad staggers bank quarters
-  static constexpr int STR = KC ? BX * 16 + (BK == 16 ? 64 : 32) : BX * 2 + 64;
-  static constexpr int BYTES = KC ? (BK / 8) * STR : BK * STR;
-  // float4 units staged per thread: KC chunks (row, 4 k); RC patches (4 rows, 2 k) = 2 units
-  static constexpr int UNITS = BX * BK / 4;            // float4s per tile
-  static constexpr int WORK = KC ? UNITS : UNITS / 2;  // chunks / patches per tile
-  static constexpr int N = (WORK >= 256 ? WORK / 256 : 1) * (KC ? 1 : 2);
-  static constexpr int ACTIVE = WORK >= 256 ? 256 : WORK;  // threads that stage
-  // unit u of thread tid -> (row, k) of its first element
-  static __device__ __forceinline__ void coord(int tid, int u, int& r, int& k) {
-    if constexpr (KC) {
-      const int id = tid + u * 256;
-      r = id / (BK / 4); k = (id % (BK / 4)) * 4;
-    } else {  // patch = units (2p, 2p+1): same rows, k and k+1
-      const int pp = tid + (u >> 1) * 256;
-      const int kp = pp / (BX / 4);
-      r = (pp % (BX / 4)) * 4; k = 2 * kp + (u & 1);
-    }
-  }
-  // staged float4 -> one 8-byte store per plane
-  template <int NPL>
-  static __device__ __forceinline__ void store(unsigned char* base, const float (&v)[4], int r, int k) {
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split3(v[j], h[j], m[j], l[j]);
-    const int o = KC ? (k >> 3) * STR + r * 16 + (k & 4) * 2 : k * STR + r * 2;
-    *reinterpret_cast<uint2*>(base + o) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
-    *reinterpret_cast<uint2*>(base + BYTES + o) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
-    if (NPL == 3)
-      *reinterpret_cast<uint2*>(base + 2 * BYTES + o) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
-  }
-  // MFMA operand of the 32-row block starting at row0, k-step ks (16 k each), this lane
-  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane, int row0, int ks, int lane) {
-    const int lk = lane >> 5;
-    if constexpr (KC) {
-      uint4 q = *reinterpret_cast<const uint4*>(plane + (2 * ks + lk) * STR + (row0 + (lane & 31)) * 16);
-      return __builtin_bit_cast(bf16x8, q);
-    } else {
-      const int i = lane & 15, g = (lane >> 4) & 1;
-      const unsigned char* p = plane + (16 * ks + 8 * lk + (i >> 2)) * STR + (row0 + 16 * g + 4 * (i & 3)) * 2;
-      typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
-      bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p));
-      bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p + 4 * STR));
-      uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
-      return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
-    }
-  }
-};
-
-template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int NP = 6, int BK = 16,
-          int ST = 1, bool IL = false>
-__global__ void __launch_bounds__(256, 2)
-k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
-  constexpr int NPL = NP == 3 ? 2 : 3;     // planes kept
-  using LA = PlaneS3<BM, AKC, BK>;
-  using LB = PlaneS3<BN, BKC, BK>;
-  __shared__ __attribute__((aligned(16))) unsigned char As[2][NPL * LA::BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NPL * LB::BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
-  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
-  const int kb = blockIdx.z * kps;
-  const int ke = min(K, kb + kps);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  constexpr int NA = LA::N, NB = LB::N;
-  const bool a_on = LA::ACTIVE >= 256 || tid < LA::ACTIVE;
-  const bool b_on = LB::ACTIVE >= 256 || tid < LB::ACTIVE;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  float ra_[ST][NA][4], rb_[ST][NB][4];
-
-  auto gload = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4], auto full) {
-    constexpr bool FULL = decltype(full)::value;
-    if (a_on) {
-#pragma unroll
-      for (int u = 0; u < NA; ++u) {
-        int r, k; LA::coord(tid, u, r, k);
-        al.template load4<FULL>(m0 + r, k0 + k, ke, ra[u]);
-      }
-    }
-    if (b_on) {
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        int r, k; LB::coord(tid, u, r, k);
-        bl.template load4<FULL>(n0 + r, k0 + k, ke, rb[u]);
-      }
-    }
-  };
-  auto gload_rt = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4]) {
-    if (k0 + BK <= ke) gload(k0, ra, rb, std::true_type());
-    else gload(k0, ra, rb, std::false_type());
-  };
-  auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
-    if (a_on) {
-#pragma unroll
-      for (int u = 0; u < NA; ++u) {
-        int r, k; LA::coord(tid, u, r, k);
-        LA::template store<NPL>(As[buf], ra[u], r, k);
-      }
-    }
-    if (b_on) {
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        int r, k; LB::coord(tid, u, r, k);
-        LB::template store<NPL>(Bs[buf], rb[u], r, k);
-      }
-    }
-  };
-  auto compute = [&](int buf) {
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 af[TM][NPL], bf[TN][NPL];
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, ks, lane);
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, ks, lane);
-      // product (pa, pb) of the bit-planes, smallest terms first; consecutive MFMAs go
-      // to different accumulators
-      constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
-#pragma unroll
-      for (int q = (NP == 6 ? 0 : 3); q < 6; ++q)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
-    }
-  };
-
-  // k-tiles 0..nfull-1 are whole, tile nfull (if any) is the K tail.  ST tiles are in
-  // flight in registers (slot = tile % ST), tile t+1 is staged into LDS while tile t is
-  // multiplied.  The steady-state loop has exactly one code path (whole-tile prefetch):
-  // with the tail variant inside it the register allocator shares load destinations
-  // between the variants and the hardware then waits for the prefetch before the MFMAs
-  // instead of after them.
-  const int nfull = (ke - kb) / BK, nk = (ke - kb + BK - 1) / BK;
-#pragma unroll
-  for (int s_ = 0; s_ < ST; ++s_)
-    if (s_ < nk) gload_rt(kb + s_ * BK, ra_[s_], rb_[s_]);
-  if (nk > 0) sstore(0, ra_[0], rb_[0]);
-  __syncthreads();
-  int t0 = 0;
-  for (; t0 + 2 * ST <= nfull; t0 += ST) {
-#pragma unroll
-    for (int s_ = 0; s_ < ST; ++s_) {
-      const int t = t0 + s_;
-      gload(kb + (t + ST) * BK, ra_[s_], rb_[s_], std::true_type());
-      // keep the prefetch issued ahead of the MFMA block (the scheduler otherwise sinks
-      // the loads next to their first use, behind the MFMAs, and exposes their latency)
-      __builtin_amdgcn_sched_barrier(0);
-      compute(t & 1);
-      if (!IL) __builtin_amdgcn_sched_barrier(0);
-      sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
-      if (IL) {  // tile t+1 arrived an iteration ago: split + stage it under the MFMAs
-        constexpr int NMF = TM * TN * NP * (BK / 16);
-#pragma unroll
-        for (int i = 0; i < NMF; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-          if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-    }
-  }
-  for (; t0 < nk; t0 += ST) {
-#pragma unroll
-    for (int s_ = 0; s_ < ST; ++s_) {
-      const int t = t0 + s_;
-      if (t < nk) {
-        if (t + ST < nk) gload_rt(kb + (t + ST) * BK, ra_[s_], rb_[s_]);
-        compute(t & 1);
-        if (t + 1 < nk) sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
-        __syncthreads();
-      }
-    }
-  }
-
-  const int lk = lane >> 5, lr = lane & 31;
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        int col = n0 + wn0 + b * 32 + lr;
-        ep(row, col, acc[a][b][r]);
-      }
-}
-
-// 0 = native fp32 MFMA, 6 = split-bf16 with six products (fp32-level accuracy),
-// 3 = split-bf16 with three products (experiment only: reduced precision).
 int g_gemm_mode = -1;
-inline int gemm_mode() {
-  if (g_gemm_mode < 0) {
-    const char* e = getenv("DD_GEMM_MODE");
-    g_gemm_mode = e ? atoi(e) : 6;
-  }
-  return g_gemm_mode;
-}
-
-// launch the main loop for one tile shape in the selected arithmetic mode.  Measured
-// variants of the split-bf16 loop (tools/gemm_modes.py, bench.py): 128-row tiles: prefetch
-// distance 2 with the split of tile t+1 interleaved under the MFMAs of tile t (52.6 vs
-// 53.2 ms/step for distance 1, no interleave); 64x64 tiles (latency-bound, about one
-// workgroup per CU): distance 4 (BK 16) beats BK 32 x distance 2 and the fp32 loop.
-template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP>
-void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps, int tm) {
-  if (gemm_mode() == 0) {
-    k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-    return;
-  }
-  if constexpr (BM == 64 && BN == 64)
-    k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-  else
-    k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 2, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-}
-
-__global__ void k_splitk_reduce(const float* __restrict__ slab, int S, long MN, int N,
-                                float* C, long ldc, const float* bias, float alpha, float beta) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN;
-       i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slab[(long)z * MN + i];
-    long m = i / N; int n = (int)(i - m * N);
-    float r = alpha * s;
-    if (bias) r += bias[n];
-    long o = m * ldc + n;
-    if (beta != 0.f) r += beta * C[o];
-    C[o] = r;
-  }
-}
-
-inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-
-// Split-K factor: enough workgroups to cover the chip, bounded by K and the
-// caller's workspace.
-int pick_split(long tiles, int K, long MN, size_t ws_bytes) {
-  static const int min_tiles = getenv("DD_SPLIT_MIN_TILES") ? atoi(getenv("DD_SPLIT_MIN_TILES")) : 192;
-  if (tiles >= min_tiles || K < 128) return 1;
-  // measured (2500x256xK): with >= 100 tiles a short K loop beats split + reduce
-  if (tiles >= 100 && K <= 384) return 1;
-  static const int kmin = getenv("DD_SPLIT_KMIN") ? atoi(getenv("DD_SPLIT_KMIN")) : 64;
-  static const int target = getenv("DD_SPLIT_TARGET") ? atoi(getenv("DD_SPLIT_TARGET")) : 512;
-  long s = (target + tiles - 1) / tiles;
-  long maxs = K / kmin;
-  if (s > maxs) s = maxs;
-  while (s > 1 && (size_t)s * MN * sizeof(float) > ws_bytes) --s;
-  return (int)(s < 1 ? 1 : s);
-}
-
-template <bool AKC, bool BKC, class AL, class BL>
-int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* bias,
-            float alpha, float beta, float* ws, size_t ws_bytes, hipStream_t st,
-            const char* name, int* deferred = nullptr) {
-  if (M <= 0 || N <= 0) return 0;
-  // tiles: 128x128 for large problems, 128x64 for narrow outputs, 64x64 for few rows;
-  // mid-size problems drop to smaller tiles until the grid covers the 256 CUs.
-  int TMS = (M > 64) ? 128 : 64;
-  int TNS = (M > 64 && N > 64) ? 128 : 64;
-  // (deep-K problems keep the big tile and get their parallelism from split-K)
-  const bool shallow = K <= 1536;
-  if (shallow && TMS == 128 && TNS == 128 && (long)dd_ceil_div(M, 128) * dd_ceil_div(N, 128) < 256) TNS = 64;
-  // (measured on 2500-row problems: 64x64 wins up to ~500 128x64-tiles for K <= 768,
-  // 128x64 wins for deeper K unless it leaves most CUs idle)
-  if (shallow && TMS == 128 && TNS == 64 &&
-      (long)dd_ceil_div(M, 128) * dd_ceil_div(N, 64) < (K > 768 ? 128 : 512)) TMS = 64;
-  {  // experimentation hook: DD_FORCE_TILE=128x128|128x64|64x64
-    static const char* force = getenv("DD_FORCE_TILE");
-    if (force && M > 64) {
-      if (!strcmp(force, "128x128")) { TMS = 128; TNS = 128; }
-      else if (!strcmp(force, "128x64")) { TMS = 128; TNS = 64; }
-      else if (!strcmp(force, "64x64")) { TMS = 64; TNS = 64; }
-    }
-  }
-  const int tm = dd_ceil_div(M, TMS), tn = dd_ceil_div(N, TNS);
-  const long MN = (long)M * N;
-  int S = pick_split((long)tm * tn, K, MN, ws ? ws_bytes : 0);
-  int kps = ((dd_ceil_div(K > 0 ? K : 1, S) + BKBIG - 1) / BKBIG) * BKBIG;
-  S = K > 0 ? dd_ceil_div(K, kps) : 1;
-  EpiMat ep{C, ldc, bias, alpha, beta, M, N, S > 1 ? ws : nullptr};
-  dim3 grid(tm * tn, 1, S);
-  if (TMS == 128 && TNS == 128)
-    launch_tile<128, 128, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
-  else if (TMS == 128)
-    launch_tile<128, 64, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
-  else
-    launch_tile<64, 64, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
-  DD_CHECK_LAUNCH(name);
-  if (deferred) *deferred = 0;
-  if (S > 1 && deferred) {
-    *deferred = S;  // the consumer kernel adds the slabs (PreSum)
-    return 0;
-  }
-  if (S > 1) {
-    int blocks = (int)((MN + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    k_splitk_reduce<<<blocks, 256, 0, st>>>(ws, S, MN, N, C, ldc, bias, alpha, beta);
-    DD_CHECK_LAUNCH("dd_gemm_f32(split-k reduce)");
-  }
-  return 0;
-}
-
-}  // namespace
 
 extern "C" int dd_gemm_set_mode(int mode) {
   const int prev = gemm_mode();
@@ -919,171 +70,3 @@ extern "C" int dd_gemm_f32(const float* A, const float* B, float* C, int M, int 
 #undef DD_RUN
 }
 
-extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const float* bias,
-                                 float* small, int n_img, int hb, int wb, int Cb,
-                                 int hs, int ws_, int Cs, int k, float in_scale,
-                                 float* wsp, size_t ws_bytes, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_down: geometry");
-  const int M = n_img * hs * ws_, N = Cs, K = k * k * Cb;
-  const int kwc = k * Cb;
-  const int vb = aligned16(w) && (Cs % 4 == 0);
-  if (big_is_u8) {
-    if (kwc % 4 == 0 && vb) {  // a float4 chunk of the patch row = 4 contiguous bytes
-      ConvDownA<unsigned char, true> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 1, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
-      return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
-    }
-    ConvDownA<unsigned char, false> al{(const unsigned char*)big, M, hs, ws_, hb, wb, Cb, kwc, in_scale, 0, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
-    return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
-  }
-  const int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
-  if (vec && vb) {
-    ConvDownA<float, true> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
-    return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
-  }
-  ConvDownA<float, false> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
-  return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
-}
-
-// col2im for the GEMM + col2im form of the transposed conv (few output channels):
-// big[n,by,bx,cb] = bias[cb] + sum_{ky,kx : (by-ky),(bx-kx) even, in range} cols[(n,sy,sx),(ky,kx,cb)]
-__global__ void k_col2im_s2(const float* __restrict__ cols, const float* __restrict__ bias,
-                            float* __restrict__ big, long n_img, int hs, int ws_, int hb, int wb,
-                            int Cb, int k) {
-  const long total = n_img * hb * wb * Cb;
-  const int kkc = k * k * Cb;
-  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
-       id += (long)gridDim.x * blockDim.x) {
-    int cb = (int)(id % Cb); long r = id / Cb;
-    int bx = (int)(r % wb); r /= wb;
-    int by = (int)(r % hb); long n = r / hb;
-    float acc = bias ? bias[cb] : 0.f;
-    for (int ky = by & 1; ky < k; ky += 2) {
-      int sy = (by - ky) >> 1;
-      if (by < ky || sy >= hs) continue;
-      for (int kx = bx & 1; kx < k; kx += 2) {
-        int sx = (bx - kx) >> 1;
-        if (bx < kx || sx >= ws_) continue;
-        acc += cols[((n * hs + sy) * ws_ + sx) * kkc + (ky * k + kx) * Cb + cb];
-      }
-    }
-    big[id] = acc;
-  }
-}
-
-extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* bias, float* big,
-                               int n_img, int hs, int ws_, int Cs, int hb, int wb, int Cb, int k,
-                               float* wsp, size_t ws_bytes, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_up: geometry");
-  const int kkc = k * k * Cb;
-  const size_t per_img = (size_t)hs * ws_ * kkc * sizeof(float);
-  // GEMM + col2im instead of the implicit parity form when (a) there are few output
-  // channels (image layer: an MFMA tile would be >90% padding in N), or (b) the
-  // column buffer is small enough (<= 1 GiB) that its HBM round trip costs less than
-  // the parity form's out-of-range taps (13-55% of its MFMA work at these sizes).
-  const size_t cols_bytes = per_img * (size_t)n_img;
-  // (c) with an even k the one-launch parity form below is the faster implicit path, so
-  // the column buffer only pays up to 512 MiB (measured: 6x6x256 -> 14x14x128 k4, 737 MB of
-  // columns: 986 us here vs 864 us implicit; 2x2x512 -> 6x6x256 k4, 118 MB: 351 vs 640 us).
-  const bool uni_ok = aligned16(small) && aligned16(w) && (Cs % 4 == 0) && k % 2 == 0 && 4 * Cb >= 64;
-  const size_t cols_max = uni_ok ? ((size_t)512 << 20) : ((size_t)1 << 30);
-  if (wsp && ws_bytes >= 2 * per_img &&
-      (Cb <= 8 || (cols_bytes <= cols_max && cols_bytes <= ws_bytes / 2))) {
-    // cols = small[npix,Cs] @ W^T[Cs, k*k*Cb] (dense GEMM), then a gather.
-    const int chunk = (int)((ws_bytes / 2) / per_img);  // second half: split-K scratch
-    float* cols = wsp;
-    float* ws2 = wsp + (ws_bytes / 2) / sizeof(float);
-    for (int n0 = 0; n0 < n_img; n0 += chunk) {
-      const int nn = (n_img - n0 < chunk) ? (n_img - n0) : chunk;
-      const int M = nn * hs * ws_;
-      const float* a = small + (size_t)n0 * hs * ws_ * Cs;
-      const int vc = aligned16(a) && aligned16(w) && (Cs % 4 == 0);
-      int rc = vc ? run_mat<true, true>(MatKC<true>{a, Cs, M, 1}, MatKC<true>{w, Cs, kkc, 1}, M, kkc,
-                                        Cs, cols, kkc, nullptr, 1.f, 0.f, ws2, ws_bytes / 2, st,
-                                        "dd_conv2d_s2_up(cols)")
-                  : run_mat<true, true>(MatKC<false>{a, Cs, M, 0}, MatKC<false>{w, Cs, kkc, 0}, M,
-                                        kkc, Cs, cols, kkc, nullptr, 1.f, 0.f, ws2, ws_bytes / 2, st,
-                                        "dd_conv2d_s2_up(cols)");
-      if (rc) return rc;
-      const long total = (long)nn * hb * wb * Cb;
-      int blocks = (int)((total + 255) / 256);
-      if (blocks > 8192) blocks = 8192;
-      k_col2im_s2<<<blocks, 256, 0, st>>>(cols, bias, big + (size_t)n0 * hb * wb * Cb, nn, hs, ws_, hb, wb, Cb, k);
-      DD_CHECK_LAUNCH("dd_conv2d_s2_up(col2im)");
-    }
-    return 0;
-  }
-  const int vec = aligned16(small) && aligned16(w) && (Cs % 4 == 0);
-  if (uni_ok) {  // all parities in one contraction
-    const int nj = (hb + 1) / 2, ni = (wb + 1) / 2, nk = k / 2;
-    const int M = n_img * nj * ni, N = 4 * Cb, K = nk * nk * Cs;
-    EpiConvUp4 ep{big, bias, M, nj, ni, hb, wb, Cb, FastDiv(nj * ni), FastDiv(ni), FastDiv(Cb)};
-    ConvUpA<true> al{small, M, nj, ni, hs, ws_, Cs, nk, vec, FastDiv(nj * ni), FastDiv(ni), FastDiv(Cs), FastDiv(nk)};
-    ConvUpB4 bl{w, Cb, Cs, k, nk, N, FastDiv(Cs), FastDiv(nk), FastDiv(Cb)};
-    const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
-    const int tm = dd_ceil_div(M, 128);
-    if (N > 64)
-      launch_tile<128, 128, true, true>(dim3(tm * dd_ceil_div(N, 128), 1, 1), st, al, bl, ep, K, kps, tm);
-    else
-      launch_tile<128, 64, true, true>(dim3(tm, 1, 1), st, al, bl, ep, K, kps, tm);
-    DD_CHECK_LAUNCH("dd_conv2d_s2_up");
-    return 0;
-  }
-  auto launch = [&](auto fast) -> int {
-    constexpr bool FF = decltype(fast)::value;
-    using AT = ConvUpA<FF>;
-    using BT = ConvUpB<FF>;
-    for (int py = 0; py < 2; ++py)
-      for (int px = 0; px < 2; ++px) {
-        const int nj = (hb - py + 1) / 2, ni = (wb - px + 1) / 2;  // pixels of this parity
-        const int nky = (k - py + 1) / 2, nkx = (k - px + 1) / 2;  // taps of this parity
-        if (nj <= 0 || ni <= 0) continue;
-        const int M = n_img * nj * ni, N = Cb;
-        const int K = (nky > 0 && nkx > 0) ? nky * nkx * Cs : 0;  // K = 0: bias only
-        EpiConvUp ep{big, bias, M, nj, ni, hb, wb, Cb, py, px, FastDiv(nj * ni), FastDiv(ni)};
-        AT al{small, M, nj, ni, hs, ws_, Cs, nkx > 0 ? nkx : 1, vec, FastDiv(nj * ni), FastDiv(ni), FastDiv(Cs), FastDiv(nkx > 0 ? nkx : 1)};
-        BT bl{w, Cb, Cs, k, nkx > 0 ? nkx : 1, py, px, vec, FastDiv(Cs), FastDiv(nkx > 0 ? nkx : 1)};
-        const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
-        if (M > 64 && N > 64) {
-          int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 128);
-          launch_tile<128, 128, true, true>(dim3(tm * tn, 1, 1), st, al, bl, ep, K, kps, tm);
-        } else if (M > 64) {
-          int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 64);
-          launch_tile<128, 64, true, true>(dim3(tm * tn, 1, 1), st, al, bl, ep, K, kps, tm);
-        } else {
-          int tm = dd_ceil_div(M, 64), tn = dd_ceil_div(N, 64);
-          launch_tile<64, 64, true, true>(dim3(tm * tn, 1, 1), st, al, bl, ep, K, kps, tm);
-        }
-        DD_CHECK_LAUNCH("dd_conv2d_s2_up");
-      }
-    return 0;
-  };
-  return vec ? launch(std::true_type()) : launch(std::false_type());
-}
-
-extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float* dw,
-                                  int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
-                                  float in_scale, float beta, float* wsp, size_t ws_bytes,
-                                  void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_wgrad: geometry");
-  const int M = k * k * Cb, N = Cs, K = n_img * hs * ws_;
-  const int kwc = k * Cb;
-  const int vb = aligned16(small) && (Cs % 4 == 0);
-  if (big_is_u8) {
-    if (kwc % 4 == 0 && vb) {
-      ConvWgradA<unsigned char, true> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 1, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
-      return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
-    }
-    ConvWgradA<unsigned char, false> al{(const unsigned char*)big, hs, ws_, hb, wb, Cb, kwc, M, in_scale, 0, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
-    return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
-  }
-  const int vec = aligned16(big) && (Cb % 4 == 0) && (kwc % 4 == 0);
-  if (vec && vb) {
-    ConvWgradA<float, true> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
-    return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
-  }
-  ConvWgradA<float, false> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
-  return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
-}
