@@ -46,22 +46,51 @@ class DistComm:
 
 
 class Batcher:
-  """`batch_size` replay generators zipped into [B,T,...] numpy batches with a
-  prefetch thread (role of embodied.Prefetch, reference core/prefetch.py)."""
+  """`batch_size` replay generators zipped into [B,T,...] minibatches by a prefetch thread
+  (role of embodied.Prefetch, reference core/prefetch.py:15-67).  With a GPU `device` the
+  thread also stages the minibatch: it stacks into rotating pinned host buffers and issues
+  the host-to-device copies on its own stream, so `Agent.train` receives device tensors
+  (its own upload becomes a device-to-device copy) and the PCIe transfer of minibatch k+1
+  overlaps the train step of minibatch k."""
 
-  def __init__(self, generator_fn, batch_size, prefetch=2):
+  def __init__(self, generator_fn, batch_size, prefetch=2, device=None):
     self._gens = [generator_fn() for _ in range(batch_size)]
     self._queue = queue.Queue(maxsize=prefetch)
     self._error = None
+    self._device = device if (device is not None and torch.device(device).type == 'cuda') else None
+    self._sets = prefetch + 2  # pinned buffer sets in rotation
     self._thread = threading.Thread(target=self._work, daemon=True)
     self._thread.start()
 
   def _work(self):
     try:
+      if self._device is None:
+        while True:
+          items = [next(g) for g in self._gens]
+          self._queue.put({k: np.stack([it[k] for it in items], 0) for k in items[0]})
+      torch.cuda.set_device(self._device)
+      stream = torch.cuda.Stream(self._device)
+      pinned, done = [None] * self._sets, [None] * self._sets
+      n = 0
       while True:
         items = [next(g) for g in self._gens]
-        batch = {k: np.stack([it[k] for it in items], 0) for k in items[0]}
-        self._queue.put(batch)
+        i = n % self._sets
+        n += 1
+        if done[i] is not None:
+          done[i].synchronize()  # the copy out of this pinned set has finished
+        if pinned[i] is None:
+          pinned[i] = {
+              k: torch.empty((len(items),) + np.shape(v), dtype=torch.from_numpy(np.asarray(v)[None]).dtype
+                             ).pin_memory() for k, v in items[0].items()}
+        host = pinned[i]
+        for k, t in host.items():
+          np.stack([it[k] for it in items], 0, out=t.numpy())
+        with torch.cuda.stream(stream):
+          dev = {k: t.to(self._device, non_blocking=True) for k, t in host.items()}
+          ev = torch.cuda.Event()
+          ev.record(stream)
+        done[i] = ev
+        self._queue.put((dev, ev))
     except Exception as e:  # surfaced on the consumer side
       self._error = e
       self._queue.put(None)
@@ -73,7 +102,14 @@ class Batcher:
     batch = self._queue.get()
     if batch is None:
       raise self._error
-    return batch
+    if self._device is None:
+      return batch
+    dev, ev = batch
+    cur = torch.cuda.current_stream(self._device)
+    cur.wait_event(ev)
+    for t in dev.values():
+      t.record_stream(cur)  # allocated on the copy stream, consumed on this one
+    return dev
 
 
 class Pipeline:
@@ -374,7 +410,7 @@ class Agent:
     owner = getattr(generator_fn, '__self__', None)
     if isinstance(owner, replay_mod.DeviceReplay):
       return owner.batches(self.cfg['batch_size'])
-    return Batcher(generator_fn, self.cfg['batch_size'])
+    return Batcher(generator_fn, self.cfg['batch_size'], device=self.device)
 
   def train(self, data, state=None):
     data = {k: (v if isinstance(v, torch.Tensor) else np.asarray(v))

@@ -266,3 +266,31 @@ def test_pipelined_steps_equal_sequential(hip):
   for i, (x, y) in enumerate(zip(ma, mb)):
     for k in x:
       assert np.array_equal(x[k], y[k], equal_nan=True), (i, k)
+
+
+def test_dataset_stages_minibatches_on_device(hip):
+  """Agent.dataset over an ordinary host generator (reference Prefetch role): the prefetch
+  thread stacks into pinned buffers and uploads on its own stream; train() gets device
+  tensors with the wire dtypes and the same values as the host stack."""
+  import itertools
+  import numpy as np
+  from daydreamer_amd import agent as agent_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=6, imag_horizon=3)
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  ag = agent_mod.Agent(obs, act, None, cfg)
+  def gen():
+    for s in itertools.count():
+      ep = synthetic.make_batch(obs, act, 1, 6, seed=s % 5, smooth_images=True)
+      yield {k: v[0] for k, v in ep.items()}
+  ds = iter(ag.dataset(gen))
+  state = None
+  for i in range(8):
+    batch = next(ds)
+    assert batch['image'].is_cuda and batch['image'].dtype == torch.uint8
+    assert batch['is_first'].dtype == torch.bool and batch['reward'].dtype == torch.float32
+    if i == 0:
+      ref = [next(gen()) for _ in range(1)][0]   # every generator starts with seed 0
+      for k, v in ref.items():
+        assert np.array_equal(batch[k][0].cpu().numpy(), v), k
+    _, state, mets = ag.train(batch, state)
+    assert all(np.isfinite(v) for v in mets.values())
