@@ -21,6 +21,10 @@ class EagerPlan:
   def cut(self, fn):
     fn()
 
+  def conditional(self, pred, fn):
+    if pred():
+      fn()
+
 
 class GraphPlan:
 
@@ -68,27 +72,47 @@ class GraphPlan:
     self.items.append(('eager', fn))
     self._begin()
 
+  def conditional(self, pred, fn):
+    """A segment whose execution is decided on the host at replay time (pred() is
+    evaluated after the preceding cut functions ran): fn() is captured into its own
+    graph; it must not contain cut points."""
+    if not self.capturing:
+      if pred():
+        fn()
+      return
+    self._end()
+    self._begin()
+    n = len(self.items)
+    fn()
+    assert len(self.items) == n, 'cut point inside a conditional segment'
+    self._end()
+    kind, g = self.items.pop()
+    self.items.append(('cond', (pred, g)))
+    self._begin()
+
+  def _run(self):
+    for kind, item in self.items:
+      if kind == 'graph':
+        item.replay()
+      elif kind == 'cond':
+        if item[0]():
+          item[1].replay()
+      else:
+        item()
+
   def replay(self):
     cur = torch.cuda.current_stream(self.device)
     self.stream.wait_stream(cur)
     with torch.cuda.stream(self.stream):
-      for kind, item in self.items:
-        if kind == 'graph':
-          item.replay()
-        else:
-          item()
+      self._run()
     cur.wait_stream(self.stream)
 
   def replay_on(self, stream):
     """Enqueue the plan on `stream` and return without joining any other stream (the
     caller orders streams with events: agent.Agent's two-stream pipeline)."""
     with torch.cuda.stream(stream):
-      for kind, item in self.items:
-        if kind == 'graph':
-          item.replay()
-        else:
-          item()
+      self._run()
 
   @property
   def n_graphs(self):
-    return sum(1 for k, _ in self.items if k == 'graph')
+    return sum(1 for k, _ in self.items if k in ('graph', 'cond'))

@@ -125,6 +125,7 @@ class Learner:
     # can run on its own stream next to the next step's world-model phase (pipeline)
     self.ops_a, self.ops_b = ops, (ops_b if ops_b is not None else ops)
     self._in_b = False
+    self.slow_copied = True
     self.stat_b_slots = set()  # metric slots written by the behaviour phase
     self.comm_a, self.comm_b = comm, (comm_b if comm_b is not None else comm)
     # ops2: a second kernel-launch context with its own scratch workspace, used on
@@ -1009,7 +1010,8 @@ class Learner:
     if not cfg['slow_target']:
       return
     init = self.slow_updates == -1
-    if init or self.slow_updates >= cfg['slow_target_update']:
+    self.slow_copied = bool(init or self.slow_updates >= cfg['slow_target_update'])
+    if self.slow_copied:
       self.slow_updates = 0
       mix = 1.0 if init else cfg['slow_target_fraction']
       src, dst = self.groups['critic'], self.groups['critic_target']
@@ -1027,8 +1029,13 @@ class Learner:
     dfeat = dtraj.view(M, F + A)[:, :F]
     ca = cfg['actor']
     lo, hi = ca['minstd'], ca['maxstd']
-    # score with the post-update slow critic (reference agent.py:329-344)
-    (val,) = self.head_fwd('critic_target', self.acts_im['critic_target'], feat)
+    # score with the post-update slow critic (reference agent.py:329-344).  It changes only
+    # when update_slow copied (every slow_target_update steps): otherwise its values over
+    # the trajectory are the ones phase_imagine left in the activation buffers, bit for bit
+    self.plan.conditional(
+        lambda: self.slow_copied,
+        lambda: self.head_fwd('critic_target', self.acts_im['critic_target'], feat))
+    val = self.acts_im['critic_target'][1][0].z
     rew = self.acts_im['reward'][1][0].z
     cont = self.acts_im['cont'][1][0].z
     ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont_b'],
