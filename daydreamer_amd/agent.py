@@ -259,6 +259,8 @@ class Pipeline:
       if self.comm is not None:
         self.comm.allreduce_sum(merged['sums'])
         self.comm.allreduce_max(merged['maxs'])
+        merged['bal'] = merged['bal'].clone()
+        self.comm.allreduce_sum(merged['bal'])
         for k in L.stat_prereduced:  # identical on every rank already
           merged['sums'][k] /= L.world
       host = {k: v.cpu().numpy() for k, v in merged.items()}

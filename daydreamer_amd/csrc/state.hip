@@ -161,6 +161,49 @@ __global__ void k_scalar_mul(float* dst, const float* a, const float* b, float c
   if (i < n) dst[i] = a[i] * (b ? b[i] : 1.f) * c;
 }
 
+// y = (accumulate ? y : 0) + alpha * (alpha_dev ? alpha_dev[0] : 1) * x
+__global__ void k_axpy(const float* __restrict__ x, float alpha, const float* __restrict__ alpha_dev,
+                       float* __restrict__ y, long n, int accumulate) {
+  const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.f);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = (accumulate ? y[i] : 0.f) + a * x[i];
+}
+
+// tfutils.balance_stats (tfutils.py:395-411) as seven sums: loss*pos, loss*neg, pred*pos,
+// (1-pred)*neg, pos, target, mean; pos = target > thres, pred = mean > thres, mean =
+// symexp(out) (kind 0) or sigmoid(out) (kind 1).  Two deterministic stages.
+__global__ void __launch_bounds__(256)
+k_balance_partial(const float* __restrict__ out, const float* __restrict__ target,
+                  const float* __restrict__ loss, long n, float thres, int kind,
+                  double* __restrict__ partial) {
+  double a[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float t = target[i], l = loss[i];
+    const float m = kind == 0 ? symexpf_(out[i]) : sigmoidf_(out[i]);
+    const float pos = t > thres ? 1.f : 0.f, pr = m > thres ? 1.f : 0.f;
+    a[0] += l * pos; a[1] += l * (1.f - pos); a[2] += pr * pos; a[3] += (1.f - pr) * (1.f - pos);
+    a[4] += pos; a[5] += t; a[6] += m;
+  }
+  __shared__ double sh[4][7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    double v = wave_sum_d(a[j]);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7)
+    partial[(long)blockIdx.x * 7 + threadIdx.x] =
+        sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ void k_balance_final(const double* __restrict__ partial, int P, double* __restrict__ out7) {
+  const int j = threadIdx.x;
+  if (j >= 7) return;
+  double t = 0.0;
+  for (int p = 0; p < P; ++p) t += partial[(long)p * 7 + j];
+  out7[j] = t;
+}
+
 // ---- optimizer ---------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_sumsq_partial(const float* __restrict__ g, long n, double* __restrict__ partial) {
@@ -385,6 +428,28 @@ extern "C" int dd_adam_step(float* p, const float* g, float* m, float* v, long n
   if (n <= 0) return 0;
   k_adam<<<gsz(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, n_decay, opt_state, lr, wd, eps, b1, b2, clip);
   DD_CHECK_LAUNCH("dd_adam_step");
+  return 0;
+}
+
+extern "C" int dd_axpy(const float* x, float alpha, const float* alpha_dev, float* y, long n,
+                       int accumulate, void* stream) {
+  if (n <= 0) return 0;
+  k_axpy<<<gsz(n), 256, 0, (hipStream_t)stream>>>(x, alpha, alpha_dev, y, n, accumulate);
+  DD_CHECK_LAUNCH("dd_axpy");
+  return 0;
+}
+
+extern "C" int dd_balance_stats(const float* out, const float* target, const float* loss, long n,
+                                float thres, int kind, double* out7, double* ws, size_t ws_bytes,
+                                void* stream) {
+  if (n <= 0) return 0;
+  int P = (int)((n + 2047) / 2048);
+  if (P > 256) P = 256;
+  DD_REQUIRE(ws && (size_t)P * 7 * sizeof(double) <= ws_bytes, "dd_balance_stats: workspace too small");
+  k_balance_partial<<<P, 256, 0, (hipStream_t)stream>>>(out, target, loss, n, thres, kind, ws);
+  DD_CHECK_LAUNCH("dd_balance_stats");
+  k_balance_final<<<1, 64, 0, (hipStream_t)stream>>>(ws, P, out7);
+  DD_CHECK_LAUNCH("dd_balance_stats(final)");
   return 0;
 }
 

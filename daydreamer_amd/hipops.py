@@ -68,6 +68,8 @@ _SIGS = {
     'dd_fill': [c_p, c_l, c_f, c_p],
     'dd_reset_mask2': [c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_l, c_p],
     'dd_reset_mask_bwd2': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p],
+    'dd_axpy': [c_p, c_f, c_p, c_p, c_l, c_i, c_p],
+    'dd_balance_stats': [c_p, c_p, c_p, c_l, c_f, c_i, c_p, c_p, c_z, c_p],
     'dd_replay_gather': [c_p, c_l, c_p, c_i, c_i, c_p, c_i, c_p],
     'dd_copy2d': [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
     'dd_reset_mask': [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_l, c_i, c_p],
@@ -478,6 +480,17 @@ class HipOps:
     self._check(self.lib.dd_scalar_mul(
         dst.data_ptr(), a.data_ptr(), _ptr(b), c, dst.numel(), self.stream),
         'dd_scalar_mul')
+
+  def axpy(self, x, alpha, alpha_dev, y, accumulate=True):
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    self._check(self.lib.dd_axpy(x.data_ptr(), alpha, _ptr(alpha_dev), y.data_ptr(),
+                                 x.numel(), int(accumulate), self.stream), 'dd_axpy')
+
+  def balance_stats(self, out, target, loss, thres, kind, out7):
+    assert out.is_contiguous() and target.is_contiguous() and loss.is_contiguous()
+    self._check(self.lib.dd_balance_stats(
+        out.data_ptr(), target.data_ptr(), loss.data_ptr(), out.numel(), thres, kind,
+        out7.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_balance_stats')
 
   def grad_norm(self, g, opt_state):
     self._check(self.lib.dd_grad_norm(

@@ -125,6 +125,8 @@ class Learner:
     # can run on its own stream next to the next step's world-model phase (pipeline)
     self.ops_a, self.ops_b = ops, (ops_b if ops_b is not None else ops)
     self._in_b = False
+    # tfutils.balance_stats sums of the reward / cont heads (read_metrics)
+    self.bal = torch.zeros(2, 7, dtype=torch.float64, device=self.device)
     self.slow_copied = True
     self.stat_b_slots = set()  # metric slots written by the behaviour phase
     self.comm_a, self.comm_b = comm, (comm_b if comm_b is not None else comm)
@@ -281,6 +283,7 @@ class Learner:
     b['first'] = z(N)
     b['cont'] = z(N)
     b['cont_b'] = z(N)  # snapshot for the behaviour phase
+    b['loss_total'] = z(N)  # summed, scaled world-model loss map (its std is a metric)
     # ---- noise
     b['u_prior'] = z(B, T, G)      # batch-major: consumed in bulk after the scan
     b['u_post'] = z(T, B, G)
@@ -908,6 +911,19 @@ class Learner:
       self.stat(f'{kk}_loss', b['loss_image'][kk])
     for kk in self.spec.dec_mlp_keys:
       self.stat(f'{kk}_loss', b['loss_vec'][kk])
+    # metrics only: balance statistics of the two scalar heads (agent.py:204-209) and the
+    # summed scaled loss map whose std is reported (agent.py:186-190, 202-203)
+    ops.balance_stats(rew.view(-1), b['reward'], b['loss_reward'], 0.1, 0, self.bal[0])
+    ops.balance_stats(cont.view(-1), b['cont'], b['loss_cont'], 0.5, 1, self.bal[1])
+    tot = b['loss_total']
+    ops.axpy(b['kl'], ls.get('kl', 1.0), self.wmkl_scale, tot, accumulate=False)
+    ops.axpy(b['loss_reward'], ls.get('reward', 1.0), None, tot)
+    ops.axpy(b['loss_cont'], ls.get('cont', 1.0), None, tot)
+    for kk in (self.spec.dec_cnn_keys if self.spec.dec_convs else ()):
+      ops.axpy(b['loss_image'][kk], ls.get(kk, 1.0), None, tot)
+    for kk in self.spec.dec_mlp_keys:
+      ops.axpy(b['loss_vec'][kk], ls.get(kk, 1.0), None, tot)
+    self.stat('model_total', tot)
 
   def phase_wm_bwd(self):
     ops, b, cfg = self.ops, self.b, self.cfg
@@ -1279,7 +1295,7 @@ class Learner:
   def metric_tensors(self):
     """The device tensors a metrics read-out needs (name -> tensor)."""
     t = dict(sums=self.stat_sums, maxs=self.stat_maxs, wmkl=self.wmkl_scale, sc=self.sc,
-             actent_scale=self.actent_scale)
+             actent_scale=self.actent_scale, bal=self.bal)
     for g in ('model', 'critic', 'actor'):
       t[f'opt_{g}'] = self.groups[g].opt_state
     if not self.discrete:
@@ -1306,6 +1322,10 @@ class Learner:
           sums[k] /= self.world
       host = {k: v.cpu().numpy() for k, v in self.metric_tensors().items()}
       host['sums'], host['maxs'] = sums.cpu().numpy(), maxs.cpu().numpy()
+      if self.comm is not None:
+        bal = self.bal.clone()
+        self.comm.allreduce_sum(bal)
+        host['bal'] = bal.cpu().numpy()
     sums, maxs = host['sums'], host['maxs']
     N, H, w = self.N, self.H, self.world
     counts = dict(imag_value=(H + 1) * N * w)
@@ -1344,6 +1364,18 @@ class Learner:
     mets['post_ent_min'] = st['post_ent']['min']
     mets['model_loss_mean'] = model_loss
     mets['model_loss'] = model_loss
+    mets['model_loss_std'] = st['model_total']['std']
+    with np.errstate(divide='ignore', invalid='ignore'):  # NaN without positives / negatives
+      for i, head in enumerate(('reward', 'cont')):
+        s_ = host['bal'][i].astype(np.float64)
+        n_ = float(N * w)
+        mets[f'{head}_pos_loss'] = np.float64(s_[0]) / s_[4]
+        mets[f'{head}_neg_loss'] = np.float64(s_[1]) / (n_ - s_[4])
+        mets[f'{head}_pos_acc'] = np.float64(s_[2]) / s_[4]
+        mets[f'{head}_neg_acc'] = np.float64(s_[3]) / (n_ - s_[4])
+        mets[f'{head}_rate'] = s_[4] / n_
+        mets[f'{head}_avg'] = s_[5] / n_
+        mets[f'{head}_pred'] = s_[6] / n_
     for gname, pre in (('model', ''), ('critic', 'extr_'), ('actor', '')):
       o = host[f'opt_{gname}']
       mets[f'{pre}{gname}_grad_norm'] = o[1]

@@ -224,6 +224,16 @@ int dd_adam_step(float* p, const float* g, float* m, float* v, long n, long n_de
                  const double* opt_state, float lr, float wd, float eps, float b1,
                  float b2, float clip, void* stream);
 int dd_fill(float* p, long n, float v, void* stream);
+/* y = (accumulate ? y : 0) + alpha * (alpha_dev ? alpha_dev[0] : 1) * x: the summed, scaled
+ * world-model loss map of agent.py:186-190 (its mean / std are metrics). */
+int dd_axpy(const float* x, float alpha, const float* alpha_dev, float* y, long n,
+            int accumulate, void* stream);
+/* tfutils.balance_stats tfutils.py:395-411 of a scalar head (kind 0: symlog-MSE head, mean =
+ * symexp(out); kind 1: Bernoulli head, mean = sigmoid(out)) as seven float64 sums out7 =
+ * {loss*pos, loss*neg, pred*pos, (1-pred)*neg, pos, target, mean}. */
+int dd_balance_stats(const float* out, const float* target, const float* loss, long n,
+                     float thres, int kind, double* out7, double* ws, size_t ws_bytes,
+                     void* stream);
 int dd_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, void* stream);
 /* is_first reset of RSSM.obs_step nets.py:100-107 and its gradient. */
 int dd_reset_mask(const float* prev, long ldp, const float* first, long fstride,

@@ -613,6 +613,15 @@ class RefAgent:
     metrics['post_ent_min'] = categorical_entropy(post['logit']).min()
     metrics['model_loss_mean'] = model_loss.mean()
     metrics['model_loss_std'] = model_loss.std(unbiased=False)
+    # agent.py:204-209 (tf.debug_nans False)
+    for k, v in balance_stats(symexp(rew), lambda t: -((rew - symlog(t)) ** 2),
+                              data['reward'], 0.1).items():
+      metrics[f'reward_{k}'] = v
+    for k, v in balance_stats(
+        torch.sigmoid(cont),
+        lambda t: t * F.logsigmoid(cont) + (1 - t) * F.logsigmoid(-cont),
+        data['cont'], 0.5).items():
+      metrics[f'cont_{k}'] = v
     last_state = {k: v[:, -1].detach() for k, v in post.items()}
     out = dict(embed=embed, post=post, prior=prior, idxs=idxs,
                losses=losses)

@@ -488,6 +488,17 @@ class RefOps:
   def scalar_mul(self, dst, a, b, c):
     dst.copy_(a * (b if b is not None else 1.0) * c)
 
+  def axpy(self, x, alpha, alpha_dev, y, accumulate=True):
+    a = alpha * (alpha_dev.reshape(-1)[0] if alpha_dev is not None else 1.0)
+    y.copy_((y if accumulate else 0.0) + a * x)
+
+  def balance_stats(self, out, target, loss, thres, kind, out7):
+    m = _symexp(out) if kind == 0 else torch.sigmoid(out)
+    pos = (target > thres).to(loss.dtype)
+    pr = (m > thres).to(loss.dtype)
+    vals = [loss * pos, loss * (1 - pos), pr * pos, (1 - pr) * (1 - pos), pos, target, m]
+    out7.copy_(torch.stack([v.double().sum() for v in vals]))
+
   def grad_norm(self, g, opt_state):
     norm = math.sqrt(float((g.double() ** 2).sum()))
     opt_state[1] = norm

@@ -77,3 +77,10 @@ def rel_err(a, b):
   a = np.asarray(a, np.float64)
   b = np.asarray(b, np.float64)
   return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def metrics_finite(mets):
+  """Every metric finite, except the balance statistics that are NaN by definition when a
+  minibatch has no positives / negatives (tfutils.py:396-398)."""
+  legal_nan = ('_pos_loss', '_neg_loss', '_pos_acc', '_neg_acc')
+  return all(np.isfinite(v) or k.endswith(legal_nan) for k, v in mets.items())

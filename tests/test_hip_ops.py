@@ -527,3 +527,22 @@ def test_native_fp32_mode(hip, ref):
     close(*res[0], what='native conv_down')
   finally:
     assert hip.lib.dd_gemm_set_mode(6) == 0
+
+
+def test_axpy_and_balance_stats(hip, ref):
+  x, y, s = rnd(5000, seed=1), rnd(5000, seed=2), torch.tensor([0.37])
+  def f1(ops, x, y, s):
+    ops.axpy(x, 2.0, s, y, accumulate=False)
+    ops.axpy(x, -0.5, None, y)
+  res = both(hip, ref, f1, [x, y, s], [1])
+  close(*res[0], rtol=1e-6, what='axpy')
+  for kind, thres in ((0, 0.1), (1, 0.5)):
+    out = rnd(40000, seed=3)
+    tgt = rnd(40000, seed=4) if kind == 0 else (torch.rand(40000) > 0.02).float()
+    loss = rnd(40000, seed=5).abs()
+    o7 = torch.zeros(7, dtype=torch.float64)
+    res = both(hip, ref, lambda ops, out, tgt, loss, o7: ops.balance_stats(out, tgt, loss, thres, kind, o7),
+               [out, tgt, loss, o7], [3])
+    g, c = res[0]
+    assert torch.equal(g.cpu()[4], c[4]) and torch.equal(g.cpu()[2:4], c[2:4])  # counts are exact
+    close(g, c, rtol=1e-6, what=f'balance_stats kind {kind}')

@@ -47,10 +47,16 @@ def run_pair(cfg, steps=2, side=False, **kw):
               'extr_score_mean', 'extr_score_std', 'extr_score_mag', 'extr_score_max',
               'prior_ent_mean', 'post_ent_mean', 'prior_ent_min', 'post_ent_min',
               'extr_imag_reward_mean', 'extr_imag_return_std', 'kl_loss_std',
-              'reward_loss_std', 'actent_std'):
+              'reward_loss_std', 'actent_std', 'model_loss_std', 'reward_pos_loss',
+              'reward_neg_loss', 'reward_pos_acc', 'reward_neg_acc', 'reward_rate', 'reward_avg',
+              'reward_pred', 'cont_pos_loss', 'cont_neg_loss', 'cont_pos_acc', 'cont_neg_acc',
+              'cont_rate', 'cont_avg', 'cont_pred'):
       if k not in omets:
         continue
       a, o = float(mets[k]), float(omets[k])
+      if np.isnan(o):
+        assert np.isnan(a), f'step {i} metric {k}: {a} vs nan'
+        continue
       assert abs(a - o) <= 2e-6 * max(1.0, abs(o)), f'step {i} metric {k}: {a} vs {o}'
   return out
 

@@ -190,7 +190,7 @@ def test_training_reduces_loss_through_agent(hip):
   state, first, last = None, None, None
   for i in range(40):
     _, state, mets = ag.train(data, state)
-    assert all(np.isfinite(v) for v in mets.values()), i
+    assert helpers.metrics_finite(mets), i
     first = first if first is not None else float(mets['model_loss'])
     last = float(mets['model_loss'])
   mets = ag.flush() or mets  # pipelined: train() hands out the previous step's metrics
@@ -231,7 +231,7 @@ def test_training_from_device_replay(hip):
     assert np.array_equal(m1[k], m2[k], equal_nan=True), k
   for i in range(6):  # graph replay on fresh device minibatches
     _, state, mets = ag.train(next(ds), state)
-    assert all(np.isfinite(v) for v in mets.values()), i
+    assert helpers.metrics_finite(mets), i
   assert ag._plan is not None
 
 
@@ -293,4 +293,4 @@ def test_dataset_stages_minibatches_on_device(hip):
       for k, v in ref.items():
         assert np.array_equal(batch[k][0].cpu().numpy(), v), k
     _, state, mets = ag.train(batch, state)
-    assert all(np.isfinite(v) for v in mets.values())
+    assert helpers.metrics_finite(mets)
