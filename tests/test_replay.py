@@ -168,3 +168,34 @@ def test_agent_trains_from_device_minibatches():
   assert m1.keys() == m2.keys()
   for k in m1:
     assert np.array_equal(m1[k], m2[k], equal_nan=True), k
+
+
+def test_edge_cases(tmp_path):
+  """Empty replay, unbounded capacity, oversize episodes, key mismatch, capacity cut-off on
+  load (DiskStore.sync keeps the newest episodes), prioritize() is a no-op."""
+  rep = make(None, 4, ring_steps=64)
+  assert len(rep) == 0 and rep.stats == {'replay_steps': 0, 'replay_trajs': 0}
+  with pytest.raises(RuntimeError):
+    rep.sample_batch(2)
+  with pytest.raises(ValueError):
+    rep.add_traj(next(episodes([80])))
+  a, b = list(episodes([10, 12]))
+  rep.add_traj(a)
+  with pytest.raises(KeyError):
+    rep.add_traj({k: v for k, v in b.items() if k != 'vector'})
+  rep.add_traj(b)
+  assert rep.prioritize(['x'], [1.0]) is None
+  assert rep.stats == {'replay_steps': 22, 'replay_trajs': 2}   # no capacity: nothing evicted
+  out = rep.sample_batch(3)
+  assert out['image'].shape == (3, 4, 8, 8, 3) and out['is_first'][:, 0].all()
+  # newest-first selection up to the capacity when loading a directory
+  src = make(1000, 4, directory=tmp_path)
+  import time
+  for traj in episodes([10, 11, 12, 13]):
+    src.add_traj(traj)
+    src.save()
+    time.sleep(1.05)   # file names carry a one-second time stamp
+  dst = make(30, 4, directory=tmp_path)
+  dst.load()
+  assert sorted(n for _, n in dst.table.values()) == [12, 13]
+  assert len(dst) == 25
