@@ -10,6 +10,8 @@
 // the sub-wave.  The draw is inverse-CDF: idx = #{c < C-1 : cdf_c <= u*cdf_{C-1}}
 // with a Kogge-Stone inclusive scan over the (unimixed) probabilities.
 #include "dd_common.h"
+#include "sampler_core.h"
+#include <math.h>
 #include <type_traits>
 #include "../../include/daydreamer_hip.h"
 
@@ -55,12 +57,11 @@ k_stats_fwd(float* __restrict__ x, long ldx, const float* __restrict__ u, long l
         xv = *xp;
       }
     }
+    // (the arithmetic below is sampler_core.h, shared with dd_onehot_sample_host)
     float m = sub_max<LW>(xv);
-    float e = ok ? expf(xv - m) : 0.f;
+    float e = ok ? dd_exp_det(xv - m) : 0.f;
     float s = sub_sum<LW>(e);
-    float p = e / s;
-    float pm = (1.f - unimix) * p + unimix / (float)C;
-    if (!ok) pm = 0.f;
+    float pm = ok ? dd_unimix_prob(e, s, unimix, C) : 0.f;
     float lg = unimix > 0.f ? logf(pm) : (xv - m) - logf(s);
     int idx;
     if (mode == 1) {
@@ -78,7 +79,7 @@ k_stats_fwd(float* __restrict__ x, long ldx, const float* __restrict__ u, long l
       }
       float tot = __shfl(cdf, C - 1, LW);
       float uu = live ? u[row * ldu + g] : 0.f;
-      float thr = uu * tot;
+      float thr = dd_draw_threshold(uu, tot);
       float flag = (ok && c < C - 1 && cdf <= thr) ? 1.f : 0.f;
       idx = (int)sub_sum<LW>(flag);
     }
@@ -110,10 +111,10 @@ k_stats_bwd(const float* __restrict__ x, long ldx, const float* __restrict__ dlo
     const long col = (long)g * C + c;
     float xv = ok ? x[row * ldx + col] : -INFINITY;
     float m = sub_max<LW>(xv);
-    float e = ok ? expf(xv - m) : 0.f;
+    float e = ok ? dd_exp_det(xv - m) : 0.f;
     float s = sub_sum<LW>(e);
     float p = e / s;
-    float pm = (1.f - unimix) * p + unimix / (float)C;
+    float pm = dd_unimix_prob(e, s, unimix, C);
     float dpm = 0.f;
     if (ok) {
       if (dstoch) dpm += dstoch[row * lds + col];
@@ -235,6 +236,60 @@ extern "C" int dd_stats_sample_fwd(float* x, long ldx, const float* u, long ldu,
     DD_CHECK_LAUNCH("dd_stats_sample_fwd");
     return 0;
   });
+}
+
+// Host twin of k_stats_fwd: the same arithmetic (sampler_core.h) in the same order - the
+// butterfly sum of the LW-lane sub-wave, the Kogge-Stone scan - on the host cores, so
+// a (statistics, uniform) pair yields the same class index as on the device, bit for bit.
+// logit / stoch / index are optional outputs (logit goes through libm's logf: equal to the
+// device's only to the last bit or two; the draw never reads it).
+extern "C" int dd_onehot_sample_host(const float* x, long ldx, const float* u, long ldu,
+                                     float* logit, long ldl, float* stoch, long lds,
+                                     int* index, long ldi, int rows, int G, int C,
+                                     float unimix, int mode) {
+  if (rows <= 0) return 0;
+  DD_REQUIRE(C >= 2 && C <= 64, "dd_onehot_sample_host: classes must be in [2,64]");
+  DD_REQUIRE(mode == 1 || u != nullptr, "dd_onehot_sample_host: noise required");
+  int LW = 8;
+  while (LW < C) LW *= 2;
+  float e[64], t[64], pm[64], cdf[64];
+  for (long row = 0; row < rows; ++row)
+    for (int g = 0; g < G; ++g) {
+      const float* xp = x + row * ldx + (long)g * C;
+      float m = -INFINITY;
+      for (int c = 0; c < C; ++c) m = fmaxf(m, xp[c]);
+      for (int c = 0; c < LW; ++c) e[c] = c < C ? dd_exp_det(xp[c] - m) : 0.f;
+      // sub_sum<LW>: v += shfl_xor(v, o) for o = LW/2 .. 1 (every lane ends with lane 0's value)
+      for (int c = 0; c < LW; ++c) t[c] = e[c];
+      for (int o = LW / 2; o > 0; o >>= 1) {
+        float n[64];
+        for (int c = 0; c < LW; ++c) n[c] = t[c] + t[c ^ o];
+        for (int c = 0; c < LW; ++c) t[c] = n[c];
+      }
+      const float s = t[0];
+      for (int c = 0; c < LW; ++c) pm[c] = c < C ? dd_unimix_prob(e[c], s, unimix, C) : 0.f;
+      int idx = 0;
+      if (mode == 1) {
+        float best = -1.f;
+        for (int c = 0; c < C; ++c) best = fmaxf(best, pm[c]);
+        while (pm[idx] != best) ++idx;
+      } else {
+        for (int c = 0; c < LW; ++c) cdf[c] = pm[c];
+        for (int o = 1; o < LW; o <<= 1) {
+          float n[64];
+          for (int c = 0; c < LW; ++c) n[c] = c >= o ? cdf[c] + cdf[c - o] : cdf[c];
+          for (int c = 0; c < LW; ++c) cdf[c] = n[c];
+        }
+        const float thr = dd_draw_threshold(u[row * ldu + g], cdf[C - 1]);
+        for (int c = 0; c < C - 1; ++c) idx += cdf[c] <= thr ? 1 : 0;
+      }
+      if (index) index[row * ldi + g] = idx;
+      for (int c = 0; c < C; ++c) {
+        if (logit) logit[row * ldl + (long)g * C + c] = unimix > 0.f ? logf(pm[c]) : (xp[c] - m) - logf(s);
+        if (stoch) stoch[row * lds + (long)g * C + c] = c == idx ? 1.f : 0.f;
+      }
+    }
+  return 0;
 }
 
 extern "C" int dd_stats_sample_bwd(const float* x, long ldx, const float* dlogit, long ldl,

@@ -41,6 +41,7 @@ _SIGS = {
     'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_i, c_f, c_p],
     'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_f, c_p, c_p],
+    'dd_onehot_sample_host': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i],
     'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
     'dd_cat_kl_fwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     'dd_cat_kl_bwd': [c_p, c_l, c_p, c_l, c_p, c_f, c_f, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
@@ -118,6 +119,27 @@ def _vec(t):
   """(ptr, stride) of a 1-D view."""
   assert t.dim() == 1, t.shape
   return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else 1)
+
+
+def onehot_sample_host(x, u, G, C, unimix, mode=0):
+  """Host twin of `HipOps.stats_fwd`'s draw (dd_onehot_sample_host): x [rows, G*C] float32 and
+  u [rows, G] float32 CPU tensors -> (index int32 [rows, G], stoch [rows, G*C], logit).  Runs on
+  the host cores from the kernel's own source, so indices equal the device's bit for bit."""
+  lib = load_library()
+  x = x.detach().to('cpu', torch.float32).contiguous()
+  rows = x.shape[0]
+  assert x.shape == (rows, G * C)
+  if u is not None:
+    u = u.detach().to('cpu', torch.float32).contiguous()
+    assert u.shape == (rows, G)
+  idx = torch.zeros(rows, G, dtype=torch.int32)
+  stoch, logit = torch.zeros(rows, G * C), torch.zeros(rows, G * C)
+  rc = lib.dd_onehot_sample_host(
+      x.data_ptr(), G * C, _ptr(u), G, logit.data_ptr(), G * C, stoch.data_ptr(), G * C,
+      idx.data_ptr(), G, rows, G, C, unimix, mode)
+  if rc != 0:
+    raise RuntimeError(f'dd_onehot_sample_host failed ({rc}): {lib.dd_last_error().decode()}')
+  return idx, stoch, logit
 
 
 class Slabs:

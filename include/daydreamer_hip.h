@@ -130,6 +130,16 @@ int dd_stats_sample_fwd(float* x, long ldx, const float* u, long ldu,
                         int rows, int G, int C, float unimix, int mode,
                         const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
                         void* stream);
+/* Host twin of dd_stats_sample_fwd (no GPU, no stream): the categorical draw on the host
+ * cores from the same source as the kernel (csrc/sampler_core.h: deterministic exp, the
+ * sub-wave's butterfly sum and Kogge-Stone scan orders), so the class index of every
+ * (row, group) equals the device's bit for bit given the same x and u.  Optional outputs:
+ * logit / stoch as the kernel writes them, index int[rows, G] (row stride ldi).
+ * OneHotDist.sample tfutils.py:368-378 (tf.random.categorical :374). */
+int dd_onehot_sample_host(const float* x, long ldx, const float* u, long ldu,
+                          float* logit, long ldl, float* stoch, long lds,
+                          int* index, long ldi, int rows, int G, int C,
+                          float unimix, int mode);
 /* dx from dlogit (NULL ok) and the straight-through dstoch (NULL ok),
  * tfutils.py:380-381. */
 int dd_stats_sample_bwd(const float* x, long ldx, const float* dlogit, long ldl,

@@ -59,6 +59,9 @@ def symexp(x):  # tfutils.py:81-82
 
 
 SAMPLE_TOL = [1e-5]  # near-boundary tolerance for forced draws (tests may widen)
+# bookkeeping of forced draws: how many were compared / adopted from the device (tests print
+# and bound the fraction; reset with SAMPLE_STATS.update(draws=0, adopted=0))
+SAMPLE_STATS = dict(draws=0, adopted=0)
 
 
 def sample_onehot(probs, u, forced=None, tol=None):
@@ -76,6 +79,8 @@ def sample_onehot(probs, u, forced=None, tol=None):
   if forced is not None:
     forced = torch.as_tensor(forced, dtype=torch.int64)
     differ = idx != forced
+    SAMPLE_STATS['draws'] += int(differ.numel())
+    SAMPLE_STATS['adopted'] += int(differ.sum())
     if differ.any():
       gap = torch.abs(cdf - thr).min(-1).values
       near = gap < tol

@@ -73,6 +73,67 @@ def philox_field(outer, inner, cols, inner_global, inner_offset, seed, step,
   return np.ascontiguousarray(v)
 
 
+def exp_det(x):
+  """csrc/sampler_core.h dd_exp_det restated in numpy float32 (every operation rounds to
+  float32 exactly as the device / host code does: no fused multiply-add anywhere)."""
+  f = np.float32
+  x = np.asarray(x, np.float32)
+  with np.errstate(invalid='ignore', over='ignore'):
+    live = x >= f(-86.0)
+    xs = np.where(live, x, f(0.0)).astype(np.float32)
+    fn = np.floor(f(1.44269504088896341) * xs + f(0.5)).astype(np.float32)
+    r = (xs - fn * f(0.693359375)).astype(np.float32)
+    r = (r - fn * f(-2.12194440e-4)).astype(np.float32)
+    z = r * r
+    p = np.full_like(r, f(1.9875691500e-4))
+    for c in (1.3981999507e-3, 8.3334519073e-3, 4.1665795894e-2, 1.6666665459e-1,
+              5.0000001201e-1):
+      p = p * r + f(c)
+    y = (p * z + r) + f(1.0)
+    scale = ((fn.astype(np.int64) + 127).astype(np.uint32) << np.uint32(23)).view(np.float32)
+    out = (y * scale).astype(np.float32)
+  return np.where(live, out, f(0.0)).astype(np.float32)
+
+
+def sample_twin_np(x, u, G, C, unimix, mode=0):
+  """The categorical draw of k_stats_fwd / dd_onehot_sample_host restated in numpy float32,
+  operation for operation (deterministic exp, the LW-lane butterfly sum, the Kogge-Stone
+  scan): x [rows, G*C], u [rows, G] -> (index int64 [rows, G], mixed probs [rows, G, C]).
+  Replaces tf.random.categorical (reference tfutils.py:374)."""
+  f = np.float32
+  x = np.asarray(x, np.float32)
+  rows = x.shape[0]
+  xv = x.reshape(rows, G, C)
+  LW = 8
+  while LW < C:
+    LW *= 2
+  m = xv.max(-1, keepdims=True)
+  e = np.zeros((rows, G, LW), np.float32)
+  e[..., :C] = exp_det(xv - m)
+  t = e.copy()
+  lanes = np.arange(LW)
+  o = LW // 2
+  while o > 0:
+    t = (t + t[..., lanes ^ o]).astype(np.float32)
+    o //= 2
+  s = t[..., :1]
+  pm = np.zeros_like(e)
+  pm[..., :C] = (f(1.0) - f(unimix)) * (e[..., :C] / s) + f(unimix) / f(C)
+  pm = pm.astype(np.float32)
+  if mode == 1:
+    return pm[..., :C].argmax(-1), pm[..., :C]
+  cdf = pm.copy()
+  o = 1
+  while o < LW:
+    n = cdf.copy()
+    n[..., o:] = cdf[..., o:] + cdf[..., :-o]
+    cdf = n.astype(np.float32)
+    o *= 2
+  thr = (np.asarray(u, np.float32) * cdf[..., C - 1])[..., None]
+  idx = (cdf[..., :C - 1] <= thr).sum(-1)
+  return idx, pm[..., :C]
+
+
 class RefOps:
 
   name = 'ref'
@@ -235,6 +296,20 @@ class RefOps:
   def stats_fwd(self, x, u, logit, stoch, G, C, unimix, mode=0, pre=None):
     assert pre is None
     rows = x.shape[0]
+    if x.dtype == torch.float32:
+      # float32: the device's own arithmetic (bit-exact draw), see sample_twin_np
+      idx, pm = sample_twin_np(x.detach().numpy(), None if u is None else u.detach().numpy(),
+                               G, C, unimix, mode)
+      pm = torch.from_numpy(pm)
+      if unimix > 0:
+        lg = torch.log(pm)
+      else:
+        xv = x.reshape(rows, G, C)
+        m = xv.max(-1, keepdim=True).values
+        lg = (xv - m) - torch.log(torch.from_numpy(exp_det((xv - m).numpy())).sum(-1, keepdim=True))
+      logit.copy_(lg.reshape(rows, G * C))
+      stoch.copy_(F.one_hot(torch.from_numpy(idx), C).to(x.dtype).reshape(rows, G * C))
+      return
     xv = x.reshape(rows, G, C)
     m = xv.max(-1, keepdim=True).values
     e = torch.exp(xv - m)
