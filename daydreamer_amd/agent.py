@@ -45,6 +45,11 @@ class DistComm:
     self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
 
 
+class ShardedBatch(dict):
+  """A minibatch that already is this rank's rows of the global batch (produced by a
+  rank-sharded `Agent.dataset`): `Agent.train` takes it whole."""
+
+
 class Batcher:
   """`batch_size` replay generators zipped into [B,T,...] minibatches by a prefetch thread
   (role of embodied.Prefetch, reference core/prefetch.py:15-67).  With a GPU `device` the
@@ -53,7 +58,10 @@ class Batcher:
   (its own upload becomes a device-to-device copy) and the PCIe transfer of minibatch k+1
   overlaps the train step of minibatch k."""
 
-  def __init__(self, generator_fn, batch_size, prefetch=2, device=None):
+  def __init__(self, generator_fn, batch_size, prefetch=2, device=None, sharded=False):
+    # `sharded`: batch_size is this rank's share of the global batch; minibatches are
+    # marked so that Agent.train does not slice them again (class ShardedBatch)
+    self._sharded = sharded
     self._gens = [generator_fn() for _ in range(batch_size)]
     self._queue = queue.Queue(maxsize=prefetch)
     self._error = None
@@ -67,7 +75,7 @@ class Batcher:
       if self._device is None:
         while True:
           items = [next(g) for g in self._gens]
-          self._queue.put({k: np.stack([it[k] for it in items], 0) for k in items[0]})
+          self._queue.put(self._mark({k: np.stack([it[k] for it in items], 0) for k in items[0]}))
       torch.cuda.set_device(self._device)
       stream = torch.cuda.Stream(self._device)
       pinned, done = [None] * self._sets, [None] * self._sets
@@ -90,10 +98,13 @@ class Batcher:
           ev = torch.cuda.Event()
           ev.record(stream)
         done[i] = ev
-        self._queue.put((dev, ev))
+        self._queue.put((self._mark(dev), ev))
     except Exception as e:  # surfaced on the consumer side
       self._error = e
       self._queue.put(None)
+
+  def _mark(self, batch):
+    return ShardedBatch(batch) if self._sharded else batch
 
   def __iter__(self):
     return self
@@ -141,16 +152,24 @@ class Pipeline:
     # steps each, timed by device events, each pair with its own captured graphs) and
     # keeps the fastest.  It is an explicit call (bench.py, tools/train_c2.py); without it
     # the first pair is used.
-    self.pool = [torch.cuda.Stream(device) for _ in range(4)]
+    # The pool and the selected pair are per process and device (Pipeline.POOLS / BEST): every
+    # agent of the process runs on the same streams, the selection is measured once (by the
+    # first pipelined agent, inside its first train calls - `tune`) and reused, and no
+    # candidate's graphs are destroyed while their owner is alive.
+    key = str(torch.device(device))
+    if key not in Pipeline.POOLS:
+      Pipeline.POOLS[key] = ([torch.cuda.Stream(device) for _ in range(4)],
+                             torch.cuda.Stream(device))
+    self.key = key
+    self.pool, self.s3 = Pipeline.POOLS[key]          # s3: metric read-out
     self.cands = [(a, b) for a in range(4) for b in range(4) if a != b]
-    self.tuned = True
     self.periods = {}
     self.ticks = []
-    self.s3 = torch.cuda.Stream(device)             # metric read-out
     # one set of captured graphs per stream pair: a graph executable is only ever
     # launched on one stream (relaunching it on another one crashes the runtime)
     self.plans = {}
-    self._use_pair(0, 1)
+    self.tuned = key in Pipeline.BEST or os.environ.get('DD_PIPE_TUNE', '1') != '1'
+    self._use_pair(*Pipeline.BEST.get(key, (0, 1)))
     self.ev_in = torch.cuda.Event()
     self.ev_a = torch.cuda.Event()
     self.ev_b = [torch.cuda.Event(), torch.cuda.Event()]
@@ -159,6 +178,9 @@ class Pipeline:
     self.pub_b = [{k: torch.empty_like(v) for k, v in live.items()} for _ in range(2)]
     self.k = 0
     self.pending = None  # parity of the step whose metrics have not been returned yet
+
+  POOLS = {}  # device -> ([4 phase streams], read-out stream)
+  BEST = {}   # device -> selected (world-model stream, behaviour stream) indices
 
   def _use_pair(self, a, b):
     if (a, b) not in self.plans:
@@ -193,19 +215,18 @@ class Pipeline:
       a, b = min(self.periods, key=self.periods.get)
       self.tuned = True
       self.ticks = []
+      Pipeline.BEST[self.key] = (a, b)
     if (self.pool[a], self.pool[b]) != (self.s1, self.s2):
       self.s1.synchronize()
       self.s2.synchronize()
       self._use_pair(a, b)
-    if self.tuned:
-      self.plans = {(a, b): self.plans[(a, b)]}  # drop the other candidates' graphs
 
   def step(self):
     """Enqueue one step; returns the metrics of the previous pipelined step (None for
     the first).  The caller's current stream holds the uploaded inputs."""
     cur = torch.cuda.current_stream(self.device)
     if not self.tuned:
-      self._tune()
+      self._tune()   # (first pipelined agent of the process: measure the stream pairs)
     s1, s2 = self.s1, self.s2
     par = self.k & 1
     s1.wait_stream(cur)                    # inputs / carry reset issued by the caller
@@ -234,8 +255,9 @@ class Pipeline:
     return None if prev is None else self._read(prev)
 
   def tune(self, run_step):
-    """Select the stream pair by measurement: run_step() must perform one train step
-    (through step()); 12 candidate pairs x 3 steps."""
+    """Force a (re-)selection of the stream pair now: run_step() must perform one train step
+    (through step()); 12 candidate pairs x 3 steps.  Without this call the selection
+    happens by itself during the first 36 pipelined train calls of the process."""
     if os.environ.get('DD_PIPE_TUNE', '1') != '1':
       return
     self.flush()
@@ -344,7 +366,9 @@ class Agent:
     self._use_graph = bool(hip.get('graph', True)) and self.device.type == 'cuda'
     self._noise_seed = int(hip.get('noise_seed', 0))
     # two-stream pipeline of consecutive steps (class Pipeline); single process only
-    self._pipeline = bool(hip.get('pipeline', True)) and self._use_graph
+    self._pipeline = bool(hip.get('pipeline', False)) and self._use_graph
+    # rank-sharded prefetch: every rank assembles and uploads only its own rows
+    self._shard_dataset = bool(hip.get('shard_dataset', True))
     self.comm_b = self.comm_m = None
     if self._pipeline:
       from . import hipops
@@ -396,7 +420,7 @@ class Agent:
       self._bootstrap = True
 
   def _shard(self, data):
-    if self.world == 1:
+    if self.world == 1 or isinstance(data, ShardedBatch):
       return data
     B = len(data['is_first'])
     per = B // self.world
@@ -410,25 +434,35 @@ class Agent:
     `DeviceReplay.dataset` generator is recognised and replaced by minibatches
     gathered in HBM (no host staging); any other generator is zipped on the host."""
     owner = getattr(generator_fn, '__self__', None)
+    B = self.cfg['batch_size']
+    sharded = self.world > 1 and self._shard_dataset
+    if sharded:  # tfagent.py:113: the global batch must divide over the replicas
+      assert B % self.world == 0, (B, self.world)
+      B //= self.world
     if isinstance(owner, replay_mod.DeviceReplay):
-      return owner.batches(self.cfg['batch_size'])
-    return Batcher(generator_fn, self.cfg['batch_size'], device=self.device)
+      it = owner.batches(B)
+      return (ShardedBatch(b) for b in it) if sharded else it
+    return Batcher(generator_fn, B, device=self.device, sharded=sharded)
 
   def train(self, data, state=None):
-    data = {k: (v if isinstance(v, torch.Tensor) else np.asarray(v))
-            for k, v in data.items() if not k.startswith('log_')}
+    cls = ShardedBatch if isinstance(data, ShardedBatch) else dict
+    data = cls({k: (v if isinstance(v, torch.Tensor) else np.asarray(v))
+                for k, v in data.items() if not k.startswith('log_')})
     B, T = data['is_first'].shape[:2]
+    if isinstance(data, ShardedBatch):
+      B *= self.world   # this rank's rows of the global batch
     L = self.learner
     if L is None or getattr(self, '_bootstrap', False) or (L.Bg, L.T) != (B, T):
       self.flush()
-      saved = None
-      if L is not None and not getattr(self, '_bootstrap', False):
-        saved = self.save()  # controller state lives in the learner
+      # controller state (AutoAdapt scales, Normalize moments, slow-critic counter, noise
+      # step) lives in the learner instance: carry it over - also out of the bootstrap
+      # learner, which is where a load() before the first train() put the checkpoint's
+      saved = L.export_state() if L is not None else None
       self._bootstrap = False
       self.learner = None
       self._build_learner(B, T)
       if saved is not None:
-        self._apply_load(saved)
+        self.learner.import_state(saved)
       L = self.learner
       self._plan, self._pipe, self._train_calls = None, None, 0
     carry = isinstance(state, TrainState) and state.owner is L
@@ -494,10 +528,15 @@ class Agent:
     return mets
 
   def policy(self, obs, state=None, mode='train'):
-    obs = {k: np.asarray(v) for k, v in obs.items() if not k.startswith('log_')}
+    """reference agent.py:42-65: one obs_step from the carried latent, the actor's sample
+    ('train' / 'explore'; expl_behavior None = the task behaviour) or mode ('eval'), then
+    tfutils.action_noise with expl_noise / eval_noise."""
+    assert mode in ('train', 'eval', 'explore'), mode
+    obs = {k: (v if isinstance(v, torch.Tensor) else np.asarray(v))
+           for k, v in obs.items() if not k.startswith('log_')}
     n = len(obs['is_first'])
     self._ensure_params()
-    self.flush()
+    self.flush()  # (pipelined mode: the behaviour phase in flight still writes the actor)
     P = self._policies.get(n)
     if P is None:
       P = learner_mod.Learner(
@@ -514,32 +553,36 @@ class Agent:
     else:
       P.reset_carry()
       data['action'] = np.zeros((n, self.act_dim), np.float32)
-    P.upload({k: (v[:, None] if isinstance(v, np.ndarray) else v)
-              for k, v in data.items()})
+    P.upload({k: v[:, None] for k, v in data.items()})
     if isinstance(state, PolicyState):
       b['action'].copy_(state.action_dev)
     noise = self.cfg['eval_noise'] if mode == 'eval' else self.cfg['expl_noise']
-    if noise:
-      raise NotImplementedError('expl_noise / eval_noise != 0')
-    act = P.policy_device(sample=(mode != 'eval'))
+    act = P.policy_device(sample=(mode != 'eval'), noise=float(noise))
     st = PolicyState(b['carry'].clone(), None)
     st.action_dev = act.clone()
-    action = act.cpu().numpy().copy().reshape((n,) + tuple(self.act_space.shape))
+    action = act.cpu().numpy().astype(np.float32).reshape((n,) + tuple(self.act_space.shape))
     st.action = action
     return {'action': action}, st
 
+  REPORT_SEQS, REPORT_CTX = 6, 5   # reference agent.py:269-271, behaviors.py:34-36
+
   def report(self, data):
-    """WorldModel.report (reference agent.py:266-282): world-model loss metrics
-    on the batch without updating anything, plus per image key the open-loop
-    video grid `openl_<key>` = [truth | reconstruction(5 steps)+open-loop
-    prediction | error] for the first 6 sequences, shape [T, 3H, 6W, C]."""
-    data = {k: np.asarray(v) for k, v in data.items()
-            if not k.startswith('log_')}
+    """Agent.report (reference agent.py:95-106) = WorldModel.report (agent.py:266-282) +
+    Greedy.report under the `task_` prefix (behaviors.py:32-46), nothing is updated:
+      * the world-model loss metrics on the batch (WorldModel.loss's metrics dict);
+      * `openl_<key>` per image key: [truth | reconstruction of the first 5 steps followed by
+        the open-loop prediction from the recorded actions | error] of the first 6
+        sequences, tfutils.video_grid layout [T, 3H, 6W, C];
+      * `task_imag_<key>`: the decoded imagined rollout of the policy from the 6 states after
+        the 5 context steps, [horizon + 1, H, 6W, C].
+    `data` may hold numpy arrays or device tensors (Agent.dataset yields the latter)."""
+    data = {k: (v if isinstance(v, torch.Tensor) else np.asarray(v))
+            for k, v in data.items() if not k.startswith('log_')}
     B, T = data['is_first'].shape[:2]
     self.flush()
+    self._ensure_params()
     key = ('report', B, T)
     R = self._policies.get(key)
-    self._ensure_params()
     if R is None:
       R = learner_mod.Learner(
           self.spec, self.ops, self.device, B, T, groups=self.groups,
@@ -551,25 +594,48 @@ class Agent:
     R.phase_prep()
     R.phase_prep_b()  # prior-sample noise of the open-loop rollout
     R.phase_wm_fwd(True, training=False)
-    sums = R.stat_sums.cpu().numpy()
-    out = {}
-    n = R.N
-    for i, name in enumerate(R.stat_names):
-      out[f'{name}_mean'] = np.float32(sums[i, 0] / n)
-    ctx = 5
-    if self.spec.dec_convs and T > ctx and R.H * R.N >= (T - ctx) * B:
-      z = R.openloop_device(ctx).cpu().numpy()[:6]
-      model = 1.0 / (1.0 + np.exp(-z.astype(np.float64)))
+    out = dict(R.read_metrics(wm_only=True))
+    nseq, ctx = min(self.REPORT_SEQS, B), self.REPORT_CTX
+    if not self.spec.dec_convs or T <= ctx:
+      return out
+    def host(x):
+      return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x
+    def grid(video):   # tfutils.video_grid, tfutils.py:390-392
+      b_, t_, h_, w_, c_ = video.shape
+      return video.transpose(1, 2, 0, 3, 4).reshape(t_, h_, b_ * w_, c_).astype(np.float32)
+    def split(model):  # per image key channel slices of the decoder output
       c0 = 0
       for k, shp in self.spec.dec_cnn_keys.items():
-        truth = data[k][:6].astype(np.float64) / 255.0
-        m = model[..., c0:c0 + shp[2]]
+        yield k, model[..., c0:c0 + shp[2]]
         c0 += shp[2]
+    if R.H * R.N >= (T - ctx) * B:
+      z = host(R.openloop_device(ctx))[:nseq]
+      model = 1.0 / (1.0 + np.exp(-z.astype(np.float64)))
+      for k, m in split(model):
+        truth = host(data[k][:nseq]).astype(np.float64) / 255.0
         error = (m - truth + 1) / 2
-        video = np.concatenate([truth, m, error], 2)        # [B,T,3H,W,C]
-        b_, t_, h_, w_, c_ = video.shape
-        out[f'openl_{k}'] = video.transpose(1, 2, 0, 3, 4).reshape(
-            t_, h_, b_ * w_, c_).astype(np.float32)         # tfutils.video_grid
+        out[f'openl_{k}'] = grid(np.concatenate([truth, m, error], 2))
+    # Greedy.report: imagine with the policy from the states after the context steps
+    H = R.H
+    key = ('imag', nseq)
+    I = self._policies.get(key)
+    if I is None:
+      I = (learner_mod.Learner(self.spec, self.ops, self.device, nseq, 1, groups=self.groups,
+                               noise_seed=self._noise_seed + 3, dtype=self._dtype),
+           learner_mod.Learner(self.spec, self.ops, self.device, H + 1, nseq, groups=self.groups,
+                               noise_seed=self._noise_seed + 3, dtype=self._dtype))
+      self._policies[key] = I
+    roll, dec = I
+    post = R.b['post'].view(B, T, R.F)
+    self.ops.copy2d(post[:nseq, ctx - 1], roll.b['traj'][0][:, :R.F])
+    roll.phase_prep_b()
+    roll.imagine_rollout()
+    dec.decoder_fwd(roll.b['traj'].view(-1, R.F + R.A)[:, :R.F])
+    z = host(dec.dec_act[-1]['z'])
+    z = z.reshape((H + 1, nseq) + z.shape[1:])
+    model = 1.0 / (1.0 + np.exp(-z.astype(np.float64)))
+    for k, m in split(model):
+      out[f'task_imag_{k}'] = grid(m.transpose(1, 0, 2, 3, 4))
     return out
 
   # ------------------------------------------------------------- checkpointing

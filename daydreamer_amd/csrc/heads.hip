@@ -91,6 +91,32 @@ __global__ void k_normal_head_fwd(const float* __restrict__ om, long ldm,
   act[r * lda + a] = v;
 }
 
+// tfutils.action_noise (reference tfutils.py:85-93) on a policy's action rows, in place:
+//   continuous: a <- clip(a + amount * eps, -1, 1)          (Normal(a, amount).sample())
+//   discrete:   probs = amount / A + (1 - amount) * a (a one-hot), a <- one_hot(draw) with the
+//               inverse-CDF rule of the latent sampler (idx = #{c < A-1 : cdf_c <= u * cdf_{A-1}},
+//               sequential fp32 sum).  One thread per row (rows = number of environments).
+__global__ void k_action_noise(float* __restrict__ act, long lda, const float* __restrict__ noise,
+                               long ldn, int rows, int A, float amount, int discrete) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float* a = act + (long)r * lda;
+  if (!discrete) {
+    for (int j = 0; j < A; ++j) a[j] = fminf(fmaxf(a[j] + amount * noise[(long)r * ldn + j], -1.f), 1.f);
+    return;
+  }
+  float tot = 0.f;
+  for (int j = 0; j < A; ++j) tot += amount / (float)A + (1.f - amount) * a[j];
+  const float thr = noise[(long)r * ldn] * tot;
+  float cdf = 0.f;
+  int idx = 0;
+  for (int j = 0; j < A - 1; ++j) {
+    cdf += amount / (float)A + (1.f - amount) * a[j];
+    idx += cdf <= thr ? 1 : 0;
+  }
+  for (int j = 0; j < A; ++j) a[j] = j == idx ? 1.f : 0.f;
+}
+
 // Backward of the sampled action and of the (normalised) entropy bonus.
 // rows_ent: rows [0, rows_ent) carry the entropy term weighted by w[row].
 // d loss/d log(std_a) = -scale_a * w * ent_coef, ent_coef = 1/(count*(hi_ent-lo_ent)).
@@ -361,6 +387,15 @@ extern "C" int dd_normal_head_fwd(const float* om, long ldm, const float* os, lo
   if (rows <= 0) return 0;
   k_normal_head_fwd<<<nblk((long)rows * A), 256, 0, (hipStream_t)stream>>>(om, ldm, os, ldsd, eps, lde, act, lda, rows, A, lo, hi);
   DD_CHECK_LAUNCH("dd_normal_head_fwd");
+  return 0;
+}
+
+extern "C" int dd_action_noise(float* act, long lda, const float* noise, long ldn, int rows, int A,
+                               float amount, int discrete, void* stream) {
+  if (rows <= 0 || amount == 0.f) return 0;
+  DD_REQUIRE(noise != nullptr && A >= 1, "dd_action_noise: noise required");
+  k_action_noise<<<(rows + 63) / 64, 64, 0, (hipStream_t)stream>>>(act, lda, noise, ldn, rows, A, amount, discrete);
+  DD_CHECK_LAUNCH("dd_action_noise");
   return 0;
 }
 

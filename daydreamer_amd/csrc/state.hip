@@ -109,14 +109,20 @@ k_reduce_stats(const float* __restrict__ x, long n, long stride, double* __restr
   }
 }
 
-// AutoAdapt 'mult' (tfutils.py:460-474): scale[i] updated from avg_i =
-// sums[i] / count.
+// AutoAdapt 'mult' (impl 0, tfutils.py:460-474) and 'prop' (impl 1, tfutils.py:475-480):
+// scale[i] updated from avg_i = sums[i] / count.
 __global__ void k_autoadapt(float* __restrict__ scale, const double* __restrict__ sums, int n,
                             double count, float target, float thres, float vel, float lo,
-                            float hi, int inverse) {
+                            float hi, int inverse, int impl) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float avg = (float)(sums[i] / count);
+  if (impl == 1) {
+    float dir = avg - target;
+    if (inverse) dir = -dir;
+    scale[i] = fminf(fmaxf(scale[i] + vel * dir, lo), hi);
+    return;
+  }
   bool below = avg < (1.f / (1.f + thres)) * target;
   bool above = avg > (1.f + thres) * target;
   if (inverse) { bool t = below; below = above; above = t; }
@@ -391,8 +397,9 @@ extern "C" int dd_reduce_stats(const float* x, long n, long stride, double* sums
 
 extern "C" int dd_autoadapt_update(float* scale, const double* sums, int n, double count,
                                    float target, float thres, float vel, float lo, float hi,
-                                   int inverse, void* stream) {
-  k_autoadapt<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(scale, sums, n, count, target, thres, vel, lo, hi, inverse);
+                                   int inverse, int impl, void* stream) {
+  DD_REQUIRE(impl == 0 || impl == 1, "dd_autoadapt_update: impl must be 0 (mult) or 1 (prop)");
+  k_autoadapt<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(scale, sums, n, count, target, thres, vel, lo, hi, inverse, impl);
   DD_CHECK_LAUNCH("dd_autoadapt_update");
   return 0;
 }

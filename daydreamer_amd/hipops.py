@@ -50,6 +50,7 @@ _SIGS = {
     'dd_scalar_loss': [c_p, c_p, c_p, c_p, c_l, c_f, c_i, c_p],
     'dd_normal_head_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_f, c_p],
     'dd_normal_head_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p],
+    'dd_action_noise': [c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_i, c_p],
     'dd_actent_stats': [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p, c_z, c_p],
     'dd_imag_returns_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_p],
     'dd_imag_returns_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_p],
@@ -61,7 +62,7 @@ _SIGS = {
     'dd_philox': [c_p, c_l, c_l, c_i, c_l, c_l, c_ull, c_p, c_u, c_i, c_p],
     'dd_counter_add': [c_p, c_ull, c_p],
     'dd_reduce_stats': [c_p, c_l, c_l, c_p, c_p, c_p],
-    'dd_autoadapt_update': [c_p, c_p, c_i, c_d, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
+    'dd_autoadapt_update': [c_p, c_p, c_i, c_d, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_p],
     'dd_normalize_update': [c_p, c_p, c_d, c_p, c_d, c_d, c_i, c_i, c_p, c_p],
     'dd_scalar_mul': [c_p, c_p, c_p, c_f, c_i, c_p],
     'dd_grad_norm': [c_p, c_l, c_p, c_p, c_z, c_p],
@@ -409,6 +410,13 @@ class HipOps:
         _ptr(ent_row), rows, rows_ent, A, lo, hi, ent_coef, ent_lo, ent_div,
         self.stream), 'dd_normal_head_bwd')
 
+  def action_noise(self, act, noise, amount, discrete):
+    rows, A = act.shape
+    a, lda = _mat(act)
+    n, ldn = _mat(noise)
+    self._check(self.lib.dd_action_noise(a, lda, n, ldn, rows, A, amount, int(discrete),
+                                         self.stream), 'dd_action_noise')
+
   def actent_stats(self, os, rows, lo, hi, ent_lo, ent_div, out):
     b, ldb = _mat(os)
     self._check(self.lib.dd_actent_stats(
@@ -486,10 +494,11 @@ class HipOps:
         'dd_reduce_stats')
 
   def autoadapt_update(self, scale, sums, count, target, thres, vel, lo, hi,
-                       inverse):
+                       inverse, impl='mult'):
     self._check(self.lib.dd_autoadapt_update(
         scale.data_ptr(), sums.data_ptr(), scale.numel(), count, target, thres,
-        vel, lo, hi, int(inverse), self.stream), 'dd_autoadapt_update')
+        vel, lo, hi, int(inverse), {'mult': 0, 'prop': 1}[impl], self.stream),
+        'dd_autoadapt_update')
 
   def normalize_update(self, state, sums, count, in_scale_dev, decay, maxv,
                        impl, do_update, out):

@@ -157,6 +157,11 @@ class Learner:
         (list(s.dec_cnn_keys), s.enc_cnn_keys)
     self.discrete = bool(s.act_discrete)
     assert cfg['critic_type'] == 'vfunction'
+    # options of the reference this learner does not implement are rejected, never ignored
+    assert cfg.get('transform_rewards', 'off') in ('off', False), cfg['transform_rewards']
+    assert cfg.get('train_wm', True), 'train_wm: False'
+    assert str(cfg.get('expl_behavior', 'None')) == 'None', cfg['expl_behavior']
+    assert not cfg.get('priority_correct', 0.0), 'priority_correct'
     if self.discrete:
       assert cfg['actor_grad_disc'] == 'reinforce' and cfg['actor_dist_disc'] == 'onehot'
     else:
@@ -183,8 +188,13 @@ class Learner:
     # the behaviour phase keeps its own copy of the step number (it may run while the
     # next world-model phase has already advanced step_ctr)
     self.step_ctr_b = torch.zeros(1, dtype=torch.int64, device=self.device)
-    self.wmkl_scale = torch.ones(1, dtype=dtype, device=self.device)
-    self.actent_scale = torch.ones(self.A, dtype=dtype, device=self.device)
+    # AutoAdapt state (tfutils.py:427-432): 'mult' / 'prop' start at one, 'fixed' is the
+    # configured scale and never updated
+    for k in ('wmkl', 'actent'):
+      assert cfg[k]['impl'] in ('mult', 'prop', 'fixed'), (k, cfg[k]['impl'])
+    init = lambda c: float(c['scale']) if c['impl'] == 'fixed' else 1.0
+    self.wmkl_scale = torch.full((1,), init(cfg['wmkl']), dtype=dtype, device=self.device)
+    self.actent_scale = torch.full((self.A,), init(cfg['actent']), dtype=dtype, device=self.device)
     self.norm_state = {k: torch.zeros(3, dtype=torch.float64, device=self.device)
                        for k in ('ret', 'score', 'adv')}
     self.norm_os = {k: torch.zeros(2, dtype=dtype, device=self.device)
@@ -900,9 +910,9 @@ class Learner:
     self.allreduce(self.stat_sums[k])
     self.stat_prereduced.add(k)
     c = cfg['wmkl']
-    if c['impl'] == 'mult' and training:
+    if c['impl'] != 'fixed' and training:
       ops.autoadapt_update(self.wmkl_scale, self.stat_sums[k], float(self.Ng),
-                           c['target'], 0.1, c['vel'], c['min'], c['max'], False)
+                           c['target'], 0.1, c['vel'], c['min'], c['max'], False, c['impl'])
     self.stat('post_ent', b['ent_post'])
     self.stat('prior_ent', b['ent_prior'])
     self.stat('reward_loss', b['loss_reward'])
@@ -972,13 +982,14 @@ class Learner:
     ops.copy2d(b['post'], b['traj'][0][:, :self.F])
     ops.copy2d(b['cont'].view(1, -1), b['cont_b'].view(1, -1))
 
-  def phase_imagine(self):
+  def imagine_rollout(self):
+    """WorldModel.imagine (reference agent.py:234-254): H img_steps from the start states in
+    traj[0][:, :F] with the actor's sampled actions; fills traj [H+1, N, deter|stoch|action]."""
     ops, b, cfg = self.ops, self.b, self.cfg
     N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
     traj = b['traj']
     ca = cfg['actor']
     lo, hi = ca['minstd'], ca['maxstd']
-    la, oa = self.acts_im['actor']  # traj[0][:, :F] = start states, set by phase_wm_opt
     for t in range(H + 1):
       st = lambda buf, t_=t: buf.view(H + 1, N, -1)[t_]
       if self.discrete:
@@ -996,6 +1007,12 @@ class Learner:
                             self.ai_img_stats, si)
         ops.stats_fwd(xs, b['u_img'][t], b['ilogit'], traj[t + 1][:, D:F],
                       self.G, self.C, self.unimix, 0)
+
+  def phase_imagine(self):
+    ops, b, cfg = self.ops, self.b, self.cfg
+    N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
+    traj = b['traj']  # traj[0][:, :F] = start states, set by phase_wm_opt
+    self.imagine_rollout()
     feat = traj.view(M, F + A)[:, :F]
     (rew,) = self.head_fwd('reward', self.acts_im['reward'], feat)
     (cont,) = self.head_fwd('cont', self.acts_im['cont'], feat)
@@ -1100,9 +1117,9 @@ class Learner:
     self.allreduce(self.stat_sums[k])
     self.stat_prereduced.add(k)
     c = cfg['actent']
-    if c['impl'] == 'mult':
+    if c['impl'] != 'fixed':
       ops.autoadapt_update(self.actent_scale[0:1], self.stat_sums[k], cnt,
-                           c['target'], 0.1, c['vel'], c['min'], c['max'], True)
+                           c['target'], 0.1, c['vel'], c['min'], c['max'], True, c['impl'])
     ops.onehot_policy_grad(b['alogit'], act, b['i_ret2'], b['i_value2'],
                            b['i_weight'], self.sc, self.actent_scale[0:1],
                            b['dalogit'], b['i_actor_loss'], b['i_ent_row'], HN,
@@ -1133,9 +1150,9 @@ class Learner:
     ops.actent_stats(os_all, HN, lo, hi, ent_lo, ent_div, self.actent_sums)
     self.allreduce(self.actent_sums)
     c = cfg['actent']
-    if c['impl'] == 'mult':
+    if c['impl'] != 'fixed':
       ops.autoadapt_update(self.actent_scale, self.actent_sums, cnt, c['target'],
-                           0.1, c['vel'], c['min'], c['max'], True)
+                           0.1, c['vel'], c['min'], c['max'], True, c['impl'])
     # seeds: d loss / d ret, d loss / d baseline
     ops.actor_seed(b['i_ret2'][:HN], b['i_value2'][:HN], b['i_weight'][:HN],
                    None, self.sc, b['i_actor_loss'][:HN], b['i_dret'][:HN],
@@ -1206,10 +1223,11 @@ class Learner:
 
   # ------------------------------------------------------------------ policy
 
-  def policy_device(self, sample):
+  def policy_device(self, sample, noise=0.0):
     """Agent.policy (reference agent.py:42-65) on a [n, 1] batch held by this
     learner: encoder, one obs_step from the carried latent, actor, then sample
-    (train / explore) or mode (eval).  The new latent replaces the carry; the
+    (train / explore) or mode (eval), then tfutils.action_noise with amount `noise`
+    (expl_noise / eval_noise, agent.py:50-63).  The new latent replaces the carry; the
     action is returned as a device view [n, A]."""
     ops, b, cfg = self.ops, self.b, self.cfg
     B, G, A, F, S = self.B, self.G, self.A, self.F, self.S
@@ -1236,6 +1254,11 @@ class Learner:
       om, os_ = self.head_fwd('actor', self.acts_im['actor'], t0[:, :F], sel)
       ops.normal_head_fwd(om, os_, b['eps'][0] if sample else None, t0[:, F:],
                           ca['minstd'], ca['maxstd'])
+    if noise:  # tfutils.py:85-93
+      nz = b.setdefault('act_noise', self.zeros(B, A))
+      ops.philox(nz, 1, B, A, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 3,
+                 0 if self.discrete else 1)
+      ops.action_noise(t0[:, F:], nz, float(noise), self.discrete)
     ops.copy2d(b['post'], b['carry'])
     return t0[:, F:]
 
@@ -1306,11 +1329,12 @@ class Learner:
   # sums / maxs are split by row: stat_b_slots)
   METRIC_B = ('sc', 'actent_scale', 'opt_critic', 'opt_actor', 'actent_sums')
 
-  def read_metrics(self, host=None):
+  def read_metrics(self, host=None, wm_only=False):
     """One device->host transfer of the statistics slabs -> metrics dict with
     the reference's names (agent.py:184-203, 339-342, 407-415, tfutils.py
     :208,250,266,445-446).  `host`: already fetched numpy copies of metric_tensors()
-    (the pipelined agent snapshots them per phase)."""
+    (the pipelined agent snapshots them per phase).  wm_only: the world-model loss metrics
+    alone (WorldModel.loss's metrics dict, what Agent.report starts from, agent.py:268)."""
     cfg = self.cfg
     if host is None:
       sums = self.stat_sums.clone()
@@ -1376,6 +1400,8 @@ class Learner:
         mets[f'{head}_rate'] = s_[4] / n_
         mets[f'{head}_avg'] = s_[5] / n_
         mets[f'{head}_pred'] = s_[6] / n_
+    if wm_only:
+      return {k: np.asarray(v, f) for k, v in mets.items()}
     for gname, pre in (('model', ''), ('critic', 'extr_'), ('actor', '')):
       o = host[f'opt_{gname}']
       mets[f'{pre}{gname}_grad_norm'] = o[1]
@@ -1415,6 +1441,23 @@ class Learner:
     return {k: np.asarray(v, f) for k, v in mets.items()}
 
   # ----------------------------------------------------------------- export
+
+  CONTROLLER = ('wmkl_scale', 'actent_scale', 'step_ctr', 'step_ctr_b')
+
+  def export_state(self):
+    """Controller state that lives in this learner instance (not in the shared parameter
+    arenas): AutoAdapt scales, Normalize moments, slow-critic counter, noise step."""
+    st = {k: getattr(self, k).clone() for k in self.CONTROLLER}
+    st.update({f'norm/{k}': v.clone() for k, v in self.norm_state.items()})
+    st['slow_updates'] = self.slow_updates
+    return st
+
+  def import_state(self, st):
+    for k in self.CONTROLLER:
+      getattr(self, k).copy_(st[k])
+    for k, v in self.norm_state.items():
+      v.copy_(st[f'norm/{k}'])
+    self.slow_updates = int(st['slow_updates'])
 
   def export_params(self):
     out = {}

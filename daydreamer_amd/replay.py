@@ -28,6 +28,7 @@ Episodes travel between processes in the reference's on-disk format
 `load(directory)` write and read `<time>-<uuid>-len<L>-rew<R>.npz`.
 """
 
+import calendar
 import collections
 import io
 import pathlib
@@ -37,24 +38,22 @@ import uuid
 import numpy as np
 import torch
 
-_CONVERSION = (
-    (np.floating, np.float32),
-    (np.signedinteger, np.int64),
-    (np.uint8, np.uint8),
-    (bool, bool),
-)
+# wire dtypes of a replay key by numpy kind (the table of reference core/convert.py:4-9):
+# floats -> float32, signed integers -> int64, uint8 and bool unchanged
+_WIRE = {'f': np.float32, 'i': np.int64, 'b': np.bool_}
 
 
 def convert(value):
-  """core/convert.py:12-23."""
-  if not isinstance(value, np.ndarray):
-    value = np.array(value)
-  if value.dtype in (np.float32, np.int64, np.uint8, np.bool_):
-    return value
-  for src, dst in _CONVERSION:
-    if np.issubdtype(value.dtype, src):
-      return value.astype(dst)
-  raise TypeError(f'Unsupported dtype: {value.dtype}')
+  """Canonical wire dtype of one replay value (behaviour of `embodied.convert`,
+  reference core/convert.py:12-23); anything else (unsigned ints wider than a byte, complex,
+  strings, objects) is rejected."""
+  arr = value if isinstance(value, np.ndarray) else np.array(value)
+  if arr.dtype == np.uint8:
+    return arr
+  want = _WIRE.get(arr.dtype.kind)
+  if want is None:
+    raise TypeError(f'Unsupported dtype: {arr.dtype}')
+  return arr if arr.dtype == want else arr.astype(want)
 
 
 class DeviceReplay:
@@ -84,6 +83,8 @@ class DeviceReplay:
     self.head = 0
     self.ongoing = collections.defaultdict(lambda: collections.defaultdict(list))
     self._saved = set()
+    self.stamps = {}             # episode id -> insertion time (epoch seconds, strictly increasing)
+    self._seq = 0
     self._out = {}               # batch size -> output buffers
 
   # ------------------------------------------------------------ embodied.Replay
@@ -96,16 +97,25 @@ class DeviceReplay:
     return {'replay_steps': self.steps, 'replay_trajs': len(self.table)}
 
   def add(self, tran, worker=0):
+    """One transition of `worker`'s running episode (FixedLength.add, reference
+    replay/fixed_length.py:38-44): a transition flagged is_first starts the episode over,
+    is_last - or reaching `length` steps when set - hands it to add_traj."""
+    episode = self.ongoing[worker]
     if tran['is_first']:
-      self.ongoing[worker].clear()
-    ep = self.ongoing[worker]
-    [ep[k].append(v) for k, v in tran.items()]
-    if tran['is_last'] or (self.length and len(ep['is_first']) >= self.length):
-      self.add_traj(self.ongoing.pop(worker))
+      episode.clear()
+    for name, value in tran.items():
+      episode[name].append(value)
+    steps = len(episode['is_first'])
+    if tran['is_last'] or (self.length and steps >= self.length):
+      del self.ongoing[worker]
+      self.add_traj(episode)
 
-  def add_traj(self, traj, key=None):
-    length = len(next(iter(traj.values())))
-    if length < self.chunk or length < self.minlen:
+  def add_traj(self, traj, key=None, stamp=None):
+    """Store one whole episode {key: [steps, ...]} (FixedLength.add_traj, reference
+    replay/fixed_length.py:46-52); returns its id, or None when it is shorter than a chunk
+    (or `minlen`) and therefore skipped."""
+    length = min(len(v) for v in traj.values())
+    if length < max(self.chunk, self.minlen):
       print(f'Skipping short trajectory of length {length}.')
       return None
     traj = {k: convert(v) for k, v in traj.items() if not k.startswith('log_')}
@@ -129,6 +139,13 @@ class DeviceReplay:
       self.rings[k][lo:hi].copy_(src.reshape(self.rings[k][lo:hi].shape))
     key = key or uuid.uuid4().hex
     self.table[key] = (lo, length)
+    # insertion time (DiskStore stamps a file when the episode is inserted, store.py:141-145),
+    # kept per episode and made strictly increasing (episodes arriving within one second get
+    # consecutive seconds), so that save() names files in insertion order and sorted(glob) -
+    # the order DiskStore.sync / load() reads them back in - is that order.  The format stays
+    # the reference's parseable '%Y%m%dT%H%M%S'.
+    self._seq = max(int(timelib.time()), self._seq + 1) if stamp is None else max(stamp, self._seq)
+    self.stamps[key] = self._seq
     self.steps += length
     self.head = hi
     while self.capacity and len(self.table) > 1 and self.steps > self.capacity:
@@ -163,7 +180,7 @@ class DeviceReplay:
       if key in self._saved:
         continue
       traj = {k: r[off:off + n].cpu().numpy() for k, r in self.rings.items()}
-      stamp = timelib.strftime('%Y%m%dT%H%M%S', timelib.gmtime(timelib.time()))
+      stamp = timelib.strftime('%Y%m%dT%H%M%S', timelib.gmtime(self.stamps[key]))
       reward = str(int(traj['reward'].sum())).replace('-', 'm') if 'reward' in traj else '0'
       with io.BytesIO() as stream:
         np.savez_compressed(stream, **traj)
@@ -190,7 +207,8 @@ class DeviceReplay:
         continue
       with np.load(filename) as f:
         traj = {k: f[k] for k in f.keys()}
-      if self.add_traj(traj, key=key) is not None:
+      stamp = calendar.timegm(timelib.strptime(filename.stem.split('-')[0], '%Y%m%dT%H%M%S'))
+      if self.add_traj(traj, key=key, stamp=stamp) is not None:
         self._saved.add(key)
 
   # ------------------------------------------------------------------- native
@@ -206,6 +224,7 @@ class DeviceReplay:
     _, n = self.table.pop(key)
     self.steps -= n
     self._saved.discard(key)
+    self.stamps.pop(key, None)
 
   def _pick(self):
     """FixedLength._sample, fixed_length.py:64-77: (episode id, first ring row)."""

@@ -169,6 +169,12 @@ int dd_mse_loss(const float* pred, long ldp, const float* tgt, long ldt, float* 
 /* kind 0 SymlogDist tfutils.py:347-356; kind 1 Bernoulli(logits) nets.py:469-471 */
 int dd_scalar_loss(const float* pred, const float* tgt, float* loss, float* dpred,
                    long n, float coef, int kind, void* stream);
+/* tfutils.action_noise tfutils.py:85-93 (Agent.policy's expl_noise / eval_noise, agent.py:62-63),
+ * in place on act[rows, A]: continuous (discrete = 0) a <- clip(a + amount*noise, -1, 1) with
+ * noise[rows, A] standard normals; discrete a <- one_hot(draw from amount/A + (1-amount)*a) with
+ * one uniform per row in noise[:, 0].  amount == 0: no-op. */
+int dd_action_noise(float* act, long lda, const float* noise, long ldn, int rows, int A,
+                    float amount, int discrete, void* stream);
 /* Normal head nets.py:461-468 with reparameterised sample (eps NULL: mode). */
 int dd_normal_head_fwd(const float* om, long ldm, const float* os, long ldsd,
                        const float* eps, long lde, float* act, long lda,
@@ -221,7 +227,7 @@ int dd_counter_add(unsigned long long* counter, unsigned long long v, void* stre
 int dd_reduce_stats(const float* x, long n, long stride, double* sums, float* maxs, void* stream);
 int dd_autoadapt_update(float* scale, const double* sums, int n, double count,
                         float target, float thres, float vel, float lo, float hi,
-                        int inverse, void* stream);
+                        int inverse, int impl, void* stream);
 int dd_normalize_update(double* state, const double* sums, double count,
                         const float* in_scale_dev, double decay, double maxv, int impl,
                         int do_update, float* out_off_scale, void* stream);

@@ -107,6 +107,11 @@ def onehot_mode(logit):
   return F.one_hot(idx, logit.shape[-1]).to(logit.dtype)
 
 
+def video_grid(video):  # tfutils.py:390-392
+  B, T, H, W, C = video.shape
+  return video.permute(1, 2, 0, 3, 4).reshape(T, H, B * W, C)
+
+
 def categorical_kl(a, b):
   """tfd.kl_divergence(Independent(OneHotCategorical(a),1), ...(b)),
   nets.py:181-182 via get_dist nets.py:88-91: sum over classes then groups."""
@@ -121,7 +126,7 @@ def categorical_entropy(a):
 
 
 class AutoAdapt:
-  """tfutils.py:414-482 ('mult' and 'fixed' impls)."""
+  """tfutils.py:414-482 ('fixed', 'mult' and 'prop' impls)."""
 
   def __init__(self, shape, impl, scale, target, min, max, vel=0.1,
                thres=0.1, inverse=False):
@@ -130,8 +135,8 @@ class AutoAdapt:
     self.vel, self.thres, self.inverse = vel, thres, inverse
     if impl == 'fixed':
       self.scale = torch.tensor(float(scale), dtype=torch.float32)
-    elif impl == 'mult':
-      self.scale = torch.ones(self.shape, dtype=torch.float32)  # :430
+    elif impl in ('mult', 'prop'):
+      self.scale = torch.ones(self.shape, dtype=torch.float32)  # :430-432
     else:
       raise NotImplementedError(impl)
 
@@ -151,6 +156,12 @@ class AutoAdapt:
       return
     dims = list(range(reg.dim() - len(self.shape)))
     avg = reg.detach().mean(dims).float()
+    if self.impl == 'prop':  # :475-480
+      direction = avg - self.target
+      if self.inverse:
+        direction = -direction
+      self.scale = torch.clamp(self.scale + self.vel * direction, self.min, self.max)
+      return
     below = avg < (1 / (1 + self.thres)) * self.target
     above = avg > (1 + self.thres) * self.target
     if self.inverse:
@@ -580,7 +591,9 @@ class RefAgent:
     obs['cont'] = 1.0 - obs['is_terminal']
     return obs
 
-  def wm_loss(self, data, state, noise, forced=None):  # agent.py:165-212
+  def wm_loss(self, data, state, noise, forced=None, update=True):  # agent.py:165-212
+    # (update=False: the AutoAdapt scale is read but not adapted - Agent.report never
+    # applies gradients or keeps variable updates; see RefAgent.report)
     cfg = self.cfg
     metrics = {}
     embed = self.encoder(data)
@@ -592,7 +605,7 @@ class RefAgent:
     gh = cfg['grad_heads']
     losses = {}
     kl = self.rssm.kl_loss(post, prior, cfg['wmkl_balance'])
-    kl, mets = self.wmkl(kl, update=True)
+    kl, mets = self.wmkl(kl, update=update)
     losses['kl'] = kl
     metrics.update({f'wmkl_{k}': v for k, v in mets.items()})
     means = self.decoder(feat if 'decoder' in gh else feat_const)
@@ -792,8 +805,13 @@ class RefAgent:
                for k, v in metrics.items()}
     return {}, state, metrics
 
-  def policy(self, obs, state, noise, mode='train'):  # agent.py:42-65
+  def policy(self, obs, state, noise, mode='train', forced=None):  # agent.py:42-65
+    """noise: u_prior / u_post [n, G] uniforms of the obs_step, eps [n, A] (continuous) or
+    u_act [n] (discrete) for the action sample, act_noise ([n, A] normals / [n] uniforms) for
+    tfutils.action_noise when expl_noise / eval_noise is set.  forced: optional device draws
+    {'post': [n, G], 'act': [n], 'act_noise': [n]} adopted near CDF edges (sample_onehot)."""
     obs = self.preprocess(obs)
+    forced = forced or {}
     n = len(obs['is_first'])
     if state is None:
       latent = self.rssm.initial(n)
@@ -805,21 +823,76 @@ class RefAgent:
     u = torch.tensor(np.asarray(noise['u_post']), dtype=self.dtype)
     up = torch.tensor(np.asarray(noise['u_prior']), dtype=self.dtype)
     latent, _, _, _ = self.rssm.obs_step(
-        latent, action, embed, obs['is_first'], up, u)
+        latent, action, embed, obs['is_first'], up, u, None, forced.get('post'))
     latent = {k: v.detach() for k, v in latent.items()}
     mean, std = self.actor(feat_of(latent))
+    amount = self.cfg['eval_noise'] if mode == 'eval' else self.cfg['expl_noise']
     if self.discrete:
       if mode == 'eval':
         action = onehot_mode(mean)
       else:
         ua = torch.tensor(np.asarray(noise['u_act']), dtype=self.dtype)
-        action, _ = onehot_straight_through(mean, ua)
-    elif mode == 'eval':
-      action = mean  # Normal.mode()
+        action, _ = onehot_straight_through(mean, ua, forced.get('act'))
+      if amount:  # tfutils.action_noise, tfutils.py:89-91
+        un = torch.tensor(np.asarray(noise['act_noise']), dtype=self.dtype)
+        probs = amount / action.shape[-1] + (1 - amount) * action.detach()
+        idx = sample_onehot(probs, un, forced.get('act_noise'))
+        action = F.one_hot(idx, action.shape[-1]).to(self.dtype)
     else:
-      eps = torch.tensor(np.asarray(noise['eps']), dtype=self.dtype)
-      action = mean + std * eps
+      if mode == 'eval':
+        action = mean  # Normal.mode()
+      else:
+        eps = torch.tensor(np.asarray(noise['eps']), dtype=self.dtype)
+        action = mean + std * eps
+      if amount:  # tfutils.py:92-93
+        en = torch.tensor(np.asarray(noise['act_noise']), dtype=self.dtype)
+        action = torch.clamp(action + amount * en, -1.0, 1.0)
     return {'action': action.detach()}, (latent, action.detach())
+
+  def report(self, data, noise, forced=None):
+    """Agent.report (agent.py:95-106) = WorldModel.report (agent.py:266-282) + Greedy.report
+    under the `task_` prefix (behaviors.py:32-46).  noise: u_obs_prior / u_obs_post [T,B,G]
+    for the observe pass (reused by the reference's second observe over [:6, :5]: same draws),
+    u_openl [T-5, 6, G] for RSSM.imagine's prior samples, and for the policy rollout
+    u_img [H, 6, G] with eps_act [H+1, 6, A] (or u_act [H+1, 6]).  forced: optional device
+    draws {obs_prior, obs_post, openl, img, act}."""
+    cfg = self.cfg
+    forced = forced or {}
+    noise = {k: torch.tensor(np.asarray(v), dtype=self.dtype) for k, v in noise.items()}
+    with torch.no_grad():
+      data = self.preprocess(data)
+      _, _, wm_out, mets = self.wm_loss(data, None, noise, forced or None, update=False)
+      report = {k: v for k, v in mets.items()}
+      post = wm_out['post']
+      n, ctx = min(6, data['is_first'].shape[0]), 5
+      T = data['is_first'].shape[1]
+      if not self.dec_cnn or T <= ctx:
+        return report
+      context = {k: v[:n, :ctx] for k, v in post.items()}
+      start = {k: v[:, -1] for k, v in context.items()}
+      recon = self.decoder(feat_of(context))
+      # RSSM.imagine, nets.py:78-86: prior rollout with the recorded actions
+      state, states = start, []
+      for i, t in enumerate(range(ctx, T)):
+        f = forced.get('openl')
+        state, _ = self.rssm.img_step(state, data['action'][:n, t], noise['u_openl'][i],
+                                      None if f is None else f[i])
+        states.append(state)
+      prior = {k: torch.stack([s[k] for s in states], 1) for k in start}
+      openl = self.decoder(feat_of(prior))
+      for key in self.dec_cnn:
+        truth = data[key][:n]
+        model = torch.cat([recon[key][:, :ctx], openl[key]], 1)
+        error = (model - truth + 1) / 2
+        report[f'openl_{key}'] = video_grid(torch.cat([truth, model, error], 2))
+      # Greedy.report, behaviors.py:32-46: imagined rollout of the policy
+      H = cfg['imag_horizon']
+      first_cont = 1.0 - data['is_terminal'][:n, ctx - 1]
+      traj = self.imagine(start, first_cont, noise, H, forced if forced else None)
+      dists = self.decoder(feat_of({k: traj[k] for k in ('deter', 'stoch')}))
+      for key in self.dec_cnn:
+        report[f'task_imag_{key}'] = video_grid(dists[key].permute(1, 0, 2, 3, 4))
+    return report
 
   def export_params(self):
     return {k: v.detach().numpy().copy() for k, v in self.p.items()}

@@ -392,6 +392,24 @@ class RefOps:
       v = v + ((hi - lo) * torch.sigmoid(os) + lo) * eps
     act.copy_(v)
 
+  def action_noise(self, act, noise, amount, discrete):
+    """tfutils.action_noise, reference tfutils.py:85-93 (in place)."""
+    if amount == 0:
+      return
+    if not discrete:
+      act.copy_(torch.clamp(act + amount * noise, -1.0, 1.0))
+      return
+    A = act.shape[1]
+    probs = amount / A + (1 - amount) * act
+    cdf = torch.zeros_like(probs)
+    run = torch.zeros_like(probs[:, 0])
+    for j in range(A):  # the kernel's sequential fp32 sum
+      run = run + probs[:, j]
+      cdf[:, j] = run
+    thr = (noise[:, 0] * cdf[:, -1])[:, None]
+    idx = (cdf[:, :-1] <= thr).sum(-1)
+    act.copy_(F.one_hot(idx, A).to(act.dtype))
+
   def normal_head_bwd(self, om, os, eps, dact, w, scale, dom, dos, ent_row,
                       rows_ent, lo, hi, ent_coef, ent_lo, ent_div):
     rows = om.shape[0]
@@ -524,9 +542,14 @@ class RefOps:
     maxs[2] = x.abs().max()
 
   def autoadapt_update(self, scale, sums, count, target, thres, vel, lo, hi,
-                       inverse):
+                       inverse, impl='mult'):
     n = scale.numel()
     avg = (sums[:n] / count).float()
+    if impl == 'prop':  # tfutils.py:475-480
+      d = avg - np.float32(target)
+      d = -d if inverse else d
+      scale.copy_(torch.clamp(scale.float() + np.float32(vel) * d, np.float32(lo), np.float32(hi)))
+      return
     below = avg < np.float32(1.0 / (1.0 + thres)) * np.float32(target)
     above = avg > np.float32(1.0 + thres) * np.float32(target)
     if inverse:
