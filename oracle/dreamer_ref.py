@@ -61,7 +61,7 @@ def symexp(x):  # tfutils.py:81-82
 SAMPLE_TOL = [1e-5]  # near-boundary tolerance for forced draws (tests may widen)
 # bookkeeping of forced draws: how many were compared / adopted from the device (tests print
 # and bound the fraction; reset with SAMPLE_STATS.update(draws=0, adopted=0))
-SAMPLE_STATS = dict(draws=0, adopted=0)
+SAMPLE_STATS = dict(draws=0, adopted=0, max_gap=0.0)
 
 
 def sample_onehot(probs, u, forced=None, tol=None):
@@ -83,6 +83,7 @@ def sample_onehot(probs, u, forced=None, tol=None):
     SAMPLE_STATS['adopted'] += int(differ.sum())
     if differ.any():
       gap = torch.abs(cdf - thr).min(-1).values
+      SAMPLE_STATS['max_gap'] = max(SAMPLE_STATS['max_gap'], float(gap[differ].max()))
       near = gap < tol
       bad = differ & ~near
       assert not bad.any(), (

@@ -1,0 +1,61 @@
+"""Worker of tests/test_dp_gpu.py: one data-parallel rank on the HIP kernels.  All ranks share
+the one visible GPU (LOCAL_RANK forced to 0); collectives run on device tensors through the
+backend in DD_DIST_BACKEND (gloo by default; nccl = RCCL where two ranks may share a device).
+
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P \\
+      tests/dp_gpu_worker.py OUTDIR
+"""
+import os
+import sys
+import pathlib
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+os.environ['LOCAL_RANK'] = '0'
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from daydreamer_amd import agent as agent_mod, synthetic  # noqa: E402
+import helpers  # noqa: E402
+
+
+def main():
+  outdir = sys.argv[1]
+  dist.init_process_group(os.environ.get('DD_DIST_BACKEND', 'gloo'))
+  rank, world = dist.get_rank(), dist.get_world_size()
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=6, replay_chunk=8, imag_horizon=4)
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  batches = [synthetic.make_batch(obs, act, 6, 8, seed=s, smooth_images=True, terminals=0.1)
+             for s in range(3)]
+  res = {}
+  for mode in (False, True):
+    ag = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': mode}))
+    assert ag.world == world and ag.rank == rank and ag.ops.name == 'hip'
+    state = None
+    for i in range(6):
+      batch = batches[i % 3]
+      if i >= 3:  # rank-sharded minibatches, as a sharded Agent.dataset yields them
+        per = 6 // world
+        batch = agent_mod.ShardedBatch({k: v[rank * per:(rank + 1) * per] for k, v in batch.items()})
+      _, state, m = ag.train(batch, state)
+    last = ag.flush()
+    res[mode] = (ag.save(), last if mode else m)
+  a, b = res[False][0], res[True][0]
+  bad = [k for k in a if not np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True)]
+  ma, mb = res[False][1], res[True][1]
+  badm = [k for k in ma if not np.array_equal(ma[k], mb[k], equal_nan=True)]
+  print(f'rank {rank}/{world}: pipelined vs sequential: {len(bad)} arrays / {len(badm)} metrics '
+        f'differ {bad[:3]} {badm[:3]}', flush=True)
+  if rank == 0:
+    np.savez(os.path.join(outdir, 'dp_gpu.npz'), **{f'p/{k}': np.asarray(v) for k, v in a.items()},
+             **{f'm/{k}': v for k, v in ma.items()})
+  dist.barrier()
+  dist.destroy_process_group()
+  sys.exit(1 if bad or badm else 0)
+
+
+if __name__ == '__main__':
+  main()

@@ -45,6 +45,30 @@ def make_problem(cfg, image=64, vector=5, action=3, batch=None, length=None,
   return plain, sp, shapes, params, data, B, T
 
 
+def make_named_problem(name, batch, length, seed=0, terminals=0.01, horizon=None, **overrides):
+  """A BASELINE.json workload by config block name (synthetic.config_spaces) with its own
+  networks at full width; batch / length / horizon are the per-GPU shard under test."""
+  cfg = make_config((name,), **overrides)
+  if horizon is not None:
+    cfg = cfg.update({'imag_horizon': horizon})
+  plain = config.to_plain(cfg)
+  obs, act = synthetic.config_spaces(name)
+  shapes = {k: v.shape for k, v in obs.items()}
+  adim = act['action'].shape[0]
+  discrete = bool(getattr(act['action'], 'discrete', False))
+  sp = spec.build_spec(plain, shapes, adim, discrete)
+  params = spec.init_params(sp, seed)
+  rng = np.random.RandomState(seed + 1)
+  for p in sp.params:
+    if p.init == 'ones':
+      params[p.name] = (1 + 0.1 * rng.randn(*p.shape)).astype(np.float32)
+    elif p.init == 'zeros':
+      params[p.name] = (0.1 * rng.randn(*p.shape)).astype(np.float32)
+  data = synthetic.make_batch(obs, act, batch, length, seed=seed + 2, terminals=terminals,
+                              smooth_images=True)
+  return plain, sp, shapes, params, data
+
+
 def forced_from_learner(L):
   """Sample indices the learner drew, in the oracle's layout."""
   b = L.b

@@ -210,3 +210,30 @@ def test_metric_snapshots_and_arena_alignment():
     assert float(g.flat[pad].abs().sum()) == 0.0
     if hasattr(g, 'm'):
       assert float(g.m[pad].abs().sum()) == 0.0 and float(g.gflat[pad].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('name', ['xarm', 'ur5_multicam'])
+def test_named_workload_plumbing(name):
+  """The BASELINE robot workloads as synthetic.config_spaces defines them (several image keys,
+  five proprio keys concatenated for the encoder and decoded per key, one-hot actions) through
+  the host logic at a tiny batch with shrunk networks; the full-width networks run on the GPU
+  (tests/test_learner_gpu.py::test_full_size_*)."""
+  plain, sp, shapes, params, data = helpers.make_named_problem(
+      name, 2, 3, horizon=2, **{'rssm.deter': 32, 'rssm.units': 32, 'rssm.stoch': 4, 'rssm.classes': 4,
+                                'encoder.cnn_depth': 4, 'decoder.cnn_depth': 4, '.*\\.layers': 1,
+                                '.*\\.units': 16, 'encoder.mlp_layers': 1, 'decoder.mlp_layers': 1})
+  L = learner_mod.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', 2, 3, params=params, dtype=torch.float64)
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64,
+                            act_discrete=sp.act_discrete)
+  L.upload(data)
+  L.train_step_device(use_carry=False)
+  mets = L.read_metrics()
+  _, _, omets = ag.train(data, helpers.noise_from_learner(L), None, helpers.forced_from_learner(L))
+  keys = ['model_loss', 'actor_loss', 'extr_critic_loss'] + [
+      f'{k}_loss_mean' for k in list(sp.dec_cnn_keys) + list(sp.dec_mlp_keys)]
+  assert len(sp.dec_mlp_keys) == 5 and len(sp.dec_cnn_keys) == 2
+  for k in keys:
+    assert abs(float(mets[k]) - float(omets[k])) <= 2e-6 * max(1, abs(float(omets[k]))), k
+  grads = L.export_grads()
+  for n, g in ag.last['grads'].items():
+    assert helpers.rel_err(grads[n], g.numpy()) < 1e-6, n
