@@ -254,14 +254,15 @@ class Pipeline:
     self.k += 1
     return None if prev is None else self._read(prev)
 
-  def tune(self, run_step):
-    """Force a (re-)selection of the stream pair now: run_step() must perform one train step
-    (through step()); 12 candidate pairs x 3 steps.  Without this call the selection
-    happens by itself during the first 36 pipelined train calls of the process."""
+  def tune(self, run_step, force=False):
+    """Finish the stream-pair selection now (instead of inside the next train calls):
+    run_step() must perform one train step (through step()); 12 candidate pairs x 3 steps.
+    No-op once a pair has been selected in this process, unless `force` re-measures."""
     if os.environ.get('DD_PIPE_TUNE', '1') != '1':
       return
-    self.flush()
-    self.k, self.periods, self.ticks, self.tuned = 0, {}, [], False
+    if force:
+      self.flush()
+      self.k, self.periods, self.ticks, self.tuned = 0, {}, [], False
     while not self.tuned:
       run_step()
 
