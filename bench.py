@@ -110,6 +110,8 @@ def main():
   ap.add_argument('--length', type=int, default=0, help='override the config sequence length')
   ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--precision', choices=('float32', 'bfloat16'), default='float32',
+                  help='hip.precision; bfloat16 is the opt-in reduced-precision mode (not the parity mode)')
   ap.add_argument('--pipeline', type=int, default=1,
                   help='hip.pipeline (opt-in two-stream pipeline of consecutive steps)')
   args = ap.parse_args()
@@ -122,6 +124,8 @@ def main():
   assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
   ndev = torch.cuda.device_count()
   shared_devices = ndev < world
+  if shared_devices:  # plumbing check only: skip the pipeline's stream-pair measurement
+    os.environ['DD_PIPE_TUNE'] = '0'
   local = local % max(ndev, 1)
   os.environ['LOCAL_RANK'] = str(local)
   torch.cuda.set_device(local)
@@ -135,7 +139,8 @@ def main():
     else:
       dist.init_process_group(backend)
 
-  cfg = make_config(args.config).update({'hip.pipeline': bool(args.pipeline)})
+  cfg = make_config(args.config).update({'hip.pipeline': bool(args.pipeline),
+                                         'hip.precision': args.precision})
   if args.batch:
     cfg = cfg.update({'batch_size': args.batch})
   if args.length:
@@ -292,7 +297,8 @@ def main():
         metric='imagined env-steps/sec (learner)',
         value=round(value, 1), unit='imagined_env_steps/s', n_gpus=world,
         steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3),
-        higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype='f32',
+        higher_is_better=True, scaling=args.scaling, vs_baseline=None,
+        dtype='f32' if args.precision == 'float32' else 'bf16 inputs, f32 accumulate (opt-in reduced precision)',
         data='synthetic',
         config=dict(
             workload=(f'{args.config} (BASELINE.json configs): batch {Bg} ({B} per GPU) x seq {T} x '

@@ -354,6 +354,13 @@ class Agent:
       self.device = torch.device(_device or f'cuda:{local}')
       torch.cuda.set_device(self.device)
       self.ops = hipops.HipOps(self.device)
+      # arithmetic of every contraction (process-wide library switch): float32 = exact 3-way
+      # bf16 split with six products (fp32-level accuracy, default); bfloat16 = the opt-in
+      # reduced-precision mode (operands rounded to bf16, fp32 accumulation and storage), the
+      # counterpart of the reference's tf.precision: float16 (tfagent.py:161-168)
+      prec = str(self.cfg.get('hip', {}).get('precision', 'float32'))
+      assert prec in ('float32', 'bfloat16'), prec
+      self.ops.set_gemm_mode(1 if prec == 'bfloat16' else int(os.environ.get('DD_GEMM_MODE', 6)))
       # second launch context (own scratch workspace) for the side stream
       self.ops2 = hipops.HipOps(self.device, ws_bytes=1024 << 20)
       self.ops_b = None

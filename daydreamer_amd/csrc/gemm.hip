@@ -22,7 +22,7 @@ int g_gemm_mode = -1;
 
 extern "C" int dd_gemm_set_mode(int mode) {
   const int prev = gemm_mode();
-  DD_REQUIRE(mode == 0 || mode == 6, "dd_gemm_set_mode: mode must be 0 or 6");
+  DD_REQUIRE(mode == 0 || mode == 6 || mode == 1, "dd_gemm_set_mode: mode must be 0, 1 or 6");
   g_gemm_mode = mode;
   return prev;
 }

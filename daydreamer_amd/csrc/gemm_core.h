@@ -534,6 +534,12 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
   m = __float_as_uint(r1) & 0xFFFF0000u;
   l = __float_as_uint(r1 - __uint_as_float(m));     // exact, <= 8 significant bits
 }
+// round-to-nearest-even bf16 of an fp32 word, kept in the top half (the single-plane mode
+// NP = 1: truncation would bias every product by up to 2^-8)
+__device__ __forceinline__ unsigned rne_bf16(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
 // bf16(even) | bf16(odd) << 16 from the top halves of two words
 __device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) {
   return __builtin_amdgcn_perm(odd, even, 0x07060302u);
@@ -564,9 +570,15 @@ struct PlaneS3 {
   template <int NPL>
   static __device__ __forceinline__ void store(unsigned char* base, const float (&v)[4], int r, int k) {
     unsigned h[4], m[4], l[4];
+    const int o = KC ? (k >> 3) * STR + r * 16 + (k & 4) * 2 : k * STR + r * 2;
+    if constexpr (NPL == 1) {  // bf16-input mode: one rounded plane
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = rne_bf16(v[j]);
+      *reinterpret_cast<uint2*>(base + o) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) split3(v[j], h[j], m[j], l[j]);
-    const int o = KC ? (k >> 3) * STR + r * 16 + (k & 4) * 2 : k * STR + r * 2;
     *reinterpret_cast<uint2*>(base + o) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
     *reinterpret_cast<uint2*>(base + BYTES + o) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
     if (NPL == 3)
@@ -594,7 +606,7 @@ template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int 
           int ST = 1, bool IL = false>
 __global__ void __launch_bounds__(256, 2)
 k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
-  constexpr int NPL = NP == 3 ? 2 : 3;     // planes kept
+  constexpr int NPL = NP == 1 ? 1 : (NP == 3 ? 2 : 3);     // planes kept
   using LA = PlaneS3<BM, AKC, BK>;
   using LB = PlaneS3<BN, BKC, BK>;
   __shared__ __attribute__((aligned(16))) unsigned char As[2][NPL * LA::BYTES];
@@ -673,7 +685,7 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       // to different accumulators
       constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
 #pragma unroll
-      for (int q = (NP == 6 ? 0 : 3); q < 6; ++q)
+      for (int q = (NP == 6 ? 0 : (NP == 3 ? 3 : 5)); q < 6; ++q)
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -745,8 +757,10 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       }
 }
 
-// 0 = native fp32 MFMA, 6 = split-bf16 with six products (fp32-level accuracy),
-// 3 = split-bf16 with three products (experiment only: reduced precision).
+// 0 = native fp32 MFMA, 6 = split-bf16 with six products (fp32-level accuracy, default),
+// 1 = bf16 inputs (operands rounded to bf16, one product, fp32 accumulation): the opt-in
+//     reduced-precision mode `hip.precision: bfloat16`, the counterpart of the reference's
+//     tf.precision float16 (tfagent.py:161-168, tfutils.py:164-167), separately toleranced.
 inline int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("DD_GEMM_MODE");
@@ -764,6 +778,13 @@ template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP>
 void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps, int tm) {
   if (gemm_mode() == 0) {
     k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+    return;
+  }
+  if (gemm_mode() == 1) {
+    if constexpr (BM == 64 && BN == 64)
+      k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 1, 16, 4, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+    else
+      k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 1, 16, 2, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
     return;
   }
   if constexpr (BM == 64 && BN == 64)

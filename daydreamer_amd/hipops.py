@@ -163,6 +163,14 @@ class HipOps:
     self.ws_bytes = ws_bytes
     self.trace = None  # list of (label, flops, start_event, end_event) when profiling
 
+  def set_gemm_mode(self, mode):
+    """Arithmetic of all contractions of the process (dd_gemm_set_mode): 6 exact-split fp32
+    (default), 0 native fp32 MFMA, 1 bf16 inputs (reduced precision, opt-in)."""
+    prev = self.lib.dd_gemm_set_mode(int(mode))
+    if prev < 0:
+      raise RuntimeError(f'dd_gemm_set_mode({mode}): {self.lib.dd_last_error().decode()}')
+    return prev
+
   def _traced(self, label, flops, fn):
     """Bracket one contraction launch with HIP events on the launch stream
     (bench.py's live roofline measurement)."""

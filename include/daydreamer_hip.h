@@ -51,8 +51,13 @@ int dd_splitk_finish(const float* slabs, int n_slabs, float* C, long ldc, int M,
 /* Arithmetic of every contraction below: 6 (default) = fp32 operands split exactly into
  * three bf16 terms, six cross products on the bf16 matrix pipe with fp32 accumulation
  * (fp32-level accuracy: measured max error 3.3e-6 of the output scale at K = 4096 vs
- * 3.1e-6 for mode 0); 0 = native fp32 MFMA.  Also settable with the environment variable
- * DD_GEMM_MODE before the first call.  Returns the previous mode, -1 for an invalid one. */
+ * 3.1e-6 for mode 0); 0 = native fp32 MFMA; 1 = REDUCED precision, opt-in only
+ * (`hip.precision: bfloat16`): operands rounded to bf16 (nearest even), one product per pair,
+ * fp32 accumulation and fp32 storage - the counterpart of the reference's tf.precision
+ * float16 compute dtype (tfagent.py:161-168, tfutils.py:164-167; bf16 keeps the fp32 exponent
+ * range, so no loss scaling is needed), with its own looser parity tolerance.  Also settable
+ * with the environment variable DD_GEMM_MODE before the first call.  Returns the previous
+ * mode, -1 for an invalid one. */
 int dd_gemm_set_mode(int mode);
 
 /* Stride-2 VALID convolution family over NHWC tensors.  "big" is the

@@ -52,6 +52,36 @@ def test_gemm(hip, ref, M, N, K, ta, tb):
     close(g, c, what=f'gemm {M}x{N}x{K} ta{ta} tb{tb} beta{beta}')
 
 
+def test_gemm_bf16_input_mode(hip, ref):
+  """dd_gemm_set_mode(1): the opt-in reduced-precision arithmetic (operands rounded to bf16,
+  one product, fp32 accumulation).  Its error is that of bf16 inputs - relative 2^-9 per
+  operand, averaging down with K - far above the default mode's, far below 1e-2 of the
+  output scale; results must equal a float64 product of the bf16-ROUNDED operands to fp32
+  accumulation accuracy (i.e. the only loss is the documented input rounding)."""
+  prev = hip.set_gemm_mode(1)
+  try:
+    for (M, N, K, ta, tb) in [(2500, 512, 1280, 0, 0), (200, 300, 1000, 0, 1), (1280, 512, 4000, 1, 0)]:
+      A = rnd(*((K, M) if ta else (M, K)), seed=1)
+      B = rnd(*((N, K) if tb else (K, N)), seed=2)
+      C = torch.zeros(M, N).cuda()
+      hip.gemm(A.cuda(), B.cuda(), C, bool(ta), bool(tb))
+      torch.cuda.synchronize()
+      opA, opB = (A.T if ta else A), (B.T if tb else B)
+      exact = opA.double() @ opB.double()
+      rounded = opA.bfloat16().double() @ opB.bfloat16().double()
+      scale = float(exact.abs().max())
+      e_mode = float((C.cpu().double() - exact).abs().max()) / scale
+      e_acc = float((C.cpu().double() - rounded).abs().max()) / scale
+      print(f'bf16-input gemm {M}x{N}x{K}: err vs exact {e_mode:.2e}, vs rounded operands {e_acc:.2e}')
+      assert e_acc < 2e-6 and 1e-5 < e_mode < 1e-2, (e_mode, e_acc)
+  finally:
+    hip.set_gemm_mode(prev)
+  # back in the default mode: fp32-level accuracy again
+  A, B, C = rnd(300, 700, seed=1), rnd(700, 200, seed=2), torch.zeros(300, 200).cuda()
+  hip.gemm(A.cuda(), B.cuda(), C)
+  close(C, A.double() @ B.double(), rtol=5e-6, what='default mode restored')
+
+
 def test_gemm_views(hip, ref):
   """Column slices of wider buffers as operands and output (ld != cols)."""
   Abuf, Bbuf, Cbuf = rnd(100, 300, seed=1), rnd(80, 64, seed=2), rnd(100, 200, seed=3)
@@ -182,7 +212,7 @@ def test_ln_act_views(hip, ref):
   close(g, c, rtol=1e-5, what='ln views')
 
 
-@pytest.mark.parametrize('rows,D', [(50, 256), (2500, 256), (17, 64), (5, 1024), (9, 96)])
+@pytest.mark.parametrize('rows,D', [(50, 256), (2500, 256), (17, 64), (5, 1024), (9, 96), (33, 512)])
 def test_gru(hip, ref, rows, D):
   z3, gamma, beta = rnd(rows, 3 * D, seed=1, scale=2.0), 1 + 0.1 * rnd(3 * D, seed=2), 0.1 * rnd(3 * D, seed=3)
   h, hn, stats, dhn = rnd(rows, D, seed=4), torch.zeros(rows, D), torch.zeros(rows, 2), rnd(rows, D, seed=5)
