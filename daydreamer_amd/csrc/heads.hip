@@ -196,7 +196,8 @@ __global__ void k_imag_returns_fwd(const float* __restrict__ rew_raw, const floa
                                    const float* __restrict__ cont_raw, const float* __restrict__ first_cont,
                                    float* __restrict__ reward, float* __restrict__ value,
                                    float* __restrict__ cont, float* __restrict__ weight,
-                                   float* __restrict__ ret, int H, long N, float gamma, float lam) {
+                                   float* __restrict__ ret, int H, long N, float gamma, float lam,
+                                   int gae) {
   long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float wprod = 1.f;
@@ -207,6 +208,18 @@ __global__ void k_imag_returns_fwd(const float* __restrict__ rew_raw, const floa
     if (weight) weight[t * N + n] = wprod / gamma;
     value[t * N + n] = symexpf_(val_raw[t * N + n]);
     if (t > 0) reward[(t - 1) * N + n] = symexpf_(rew_raw[t * N + n]);
+  }
+  if (gae) {  // VFunction.target 'gae' (agent.py:428-433): the same return, summed as advantages
+    float adv = 0.f;
+    for (int t = H - 1; t >= 0; --t) {
+      float c = sigmoidf_(cont_raw[(t + 1) * N + n]);
+      float d = c * gamma;
+      float r = symexpf_(rew_raw[(t + 1) * N + n]);
+      float delta = r + d * value[(t + 1) * N + n] - value[t * N + n];
+      adv = delta + d * lam * adv;
+      ret[t * N + n] = adv + value[t * N + n];
+    }
+    return;
   }
   float R = value[H * N + n];
   for (int t = H - 1; t >= 0; --t) {
@@ -434,9 +447,9 @@ extern "C" int dd_actent_stats(const float* os, long ldsd, int rows, int A, floa
 extern "C" int dd_imag_returns_fwd(const float* rew_raw, const float* val_raw, const float* cont_raw,
                                    const float* first_cont, float* reward, float* value,
                                    float* cont, float* weight, float* ret, int H, long N,
-                                   float gamma, float lam, void* stream) {
+                                   float gamma, float lam, int gae, void* stream) {
   if (N <= 0) return 0;
-  k_imag_returns_fwd<<<nblk(N), 256, 0, (hipStream_t)stream>>>(rew_raw, val_raw, cont_raw, first_cont, reward, value, cont, weight, ret, H, N, gamma, lam);
+  k_imag_returns_fwd<<<nblk(N), 256, 0, (hipStream_t)stream>>>(rew_raw, val_raw, cont_raw, first_cont, reward, value, cont, weight, ret, H, N, gamma, lam, gae);
   DD_CHECK_LAUNCH("dd_imag_returns_fwd");
   return 0;
 }

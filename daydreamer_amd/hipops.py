@@ -52,7 +52,7 @@ _SIGS = {
     'dd_normal_head_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p],
     'dd_action_noise': [c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_i, c_p],
     'dd_actent_stats': [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p, c_z, c_p],
-    'dd_imag_returns_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_p],
+    'dd_imag_returns_fwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_i, c_p],
     'dd_imag_returns_bwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_f, c_f, c_p],
     'dd_critic_loss': [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
     'dd_actor_seed': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
@@ -432,12 +432,12 @@ class HipOps:
         self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_actent_stats')
 
   def imag_returns_fwd(self, rew_raw, val_raw, cont_raw, first_cont, reward,
-                       value, cont, weight, ret, H, N, gamma, lam):
+                       value, cont, weight, ret, H, N, gamma, lam, impl='gve'):
     self._check(self.lib.dd_imag_returns_fwd(
         rew_raw.data_ptr(), val_raw.data_ptr(), cont_raw.data_ptr(),
         first_cont.data_ptr(), reward.data_ptr(), value.data_ptr(),
         _ptr(cont), _ptr(weight), ret.data_ptr(), H, N, gamma, lam,
-        self.stream), 'dd_imag_returns_fwd')
+        {'gve': 0, 'gae': 1}[impl], self.stream), 'dd_imag_returns_fwd')
 
   def imag_returns_bwd(self, dret, dbase, rew_raw, val_raw, cont_raw, value,
                        ret, d_rew_raw, d_val_raw, d_cont_raw, H, N, gamma, lam):

@@ -166,7 +166,7 @@ class Learner:
       assert cfg['actor_grad_disc'] == 'reinforce' and cfg['actor_dist_disc'] == 'onehot'
     else:
       assert cfg['actor_grad_cont'] == 'backprop' and cfg['actor_dist_cont'] == 'normal'
-    assert cfg['actor_return'] == 'gve' and cfg['critic_return'] == 'gve'
+    assert cfg['actor_return'] in ('gve', 'gae') and cfg['critic_return'] in ('gve', 'gae')
     assert cfg['scorenorm']['impl'] in ('off', 'std')
     for k in ('model_opt', 'actor_opt', 'critic_opt'):
       assert cfg[k]['opt'] == 'adam' and not cfg[k]['warmup']
@@ -260,6 +260,8 @@ class Learner:
         'critic': head('critic', 'critic', 'critic', ['dist_out/out']),
         'critic_target': head('critic_target', 'critic_target', 'critic',
                               ['dist_out/out'])}
+    if not cfg['slow_target']:  # VFunction: target_net = net (reference agent.py:395-396)
+      self.heads['critic_target'] = self.heads['critic']
     if s.dec_mlp_keys:
       g = m
       n = cfg['decoder']['mlp_layers']
@@ -1016,15 +1018,13 @@ class Learner:
     feat = traj.view(M, F + A)[:, :F]
     (rew,) = self.head_fwd('reward', self.acts_im['reward'], feat)
     (cont,) = self.head_fwd('cont', self.acts_im['cont'], feat)
-    tname = 'critic_target' if cfg['slow_target'] else 'critic'
-    self.tname = tname
-    if cfg['slow_target']:
-      (val,) = self.head_fwd('critic_target', self.acts_im['critic_target'], feat)
-    else:
-      raise NotImplementedError('slow_target: False')
+    # target network: the slow copy, or the online critic itself with slow_target: False
+    # (agent.py:391-396: then heads['critic_target'] aliases the online parameters, _build_layers)
+    (val,) = self.head_fwd('critic_target', self.acts_im['critic_target'], feat)
     ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont_b'],
                          b['i_reward'], b['i_value'], b['i_cont'], b['i_weight'],
-                         b['i_ret'], H, N, cfg['discount'], cfg['return_lambda'])
+                         b['i_ret'], H, N, cfg['discount'], cfg['return_lambda'],
+                         cfg['critic_return'])
     # ---- critic update (reference agent.py:398-417)
     HN = H * N
     (cout,) = self.head_fwd('critic', self.acts_im['critic'], feat[:HN])
@@ -1041,6 +1041,7 @@ class Learner:
     """VFunction.update_slow (reference agent.py:444-454); host-side counter."""
     cfg = self.cfg
     if not cfg['slow_target']:
+      self.slow_copied = True  # the target IS the freshly updated critic: re-evaluate it
       return
     init = self.slow_updates == -1
     self.slow_copied = bool(init or self.slow_updates >= cfg['slow_target_update'])
@@ -1073,7 +1074,7 @@ class Learner:
     cont = self.acts_im['cont'][1][0].z
     ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont_b'],
                          b['i_reward'], b['i_value2'], None, None, b['i_ret2'],
-                         H, N, cfg['discount'], cfg['return_lambda'])
+                         H, N, cfg['discount'], cfg['return_lambda'], cfg['actor_return'])
     ops.sub(b['i_ret2'], b['i_value2'], b['i_diff'][:HN])
     kr = self.stat('ret2', b['i_ret2'][:HN])
     kd = self.stat('diff', b['i_diff'][:HN])

@@ -194,11 +194,13 @@ int dd_actent_stats(const float* os, long ldsd, int rows, int A, float lo, float
                     float ent_lo, float ent_div, double* out, double* ws,
                     size_t ws_bytes, void* stream);
 /* symexp / sigmoid of the head outputs, discount weights agent.py:256-259 and
- * the 'gve' lambda-return agent.py:434-440, one thread per trajectory. */
+ * VFunction.target: the 'gve' lambda-return agent.py:434-440 (gae = 0) or the same return
+ * summed as generalised advantages, 'gae' agent.py:428-433 (gae = 1); one thread per
+ * trajectory.  dd_imag_returns_bwd serves both (identical derivative). */
 int dd_imag_returns_fwd(const float* rew_raw, const float* val_raw, const float* cont_raw,
                         const float* first_cont, float* reward, float* value,
                         float* cont, float* weight, float* ret, int H, long N,
-                        float gamma, float lam, void* stream);
+                        float gamma, float lam, int gae, void* stream);
 int dd_imag_returns_bwd(const float* dret, const float* dbase, const float* rew_raw,
                         const float* val_raw, const float* cont_raw, const float* value,
                         const float* ret, float* d_rew_raw, float* d_val_raw,

@@ -682,12 +682,19 @@ class RefAgent:
     traj['policy_std'] = torch.stack([d[1] for d in dists], 0)
     return traj
 
-  def critic_target(self, traj, reward, prefix):  # agent.py:422-442 'gve'
+  def critic_target(self, traj, reward, prefix, impl='gve'):  # agent.py:422-442
     cfg = self.cfg
-    assert cfg['critic_return'] == 'gve' and cfg['actor_return'] == 'gve'
     disc = traj['cont'][1:] * cfg['discount']
     value = symexp(self.head(prefix, feat_of(traj), 'critic'))
     lam = cfg['return_lambda']
+    if impl == 'gae':  # :428-433
+      advs = [torch.zeros_like(value[0])]
+      deltas = reward + disc * value[1:] - value[:-1]
+      for t in reversed(range(len(disc))):
+        advs.append(deltas[t] + disc[t] * lam * advs[-1])
+      adv = torch.stack(list(reversed(advs))[:-1])
+      return adv + value[:-1], value[:-1]
+    assert impl == 'gve', impl  # :434-440
     vals = [value[-1]]
     interm = reward + disc * value[1:] * (1 - lam)
     for t in reversed(range(len(disc))):
@@ -738,7 +745,7 @@ class RefAgent:
                                         'reward_head'))[1:]
     reward = rewfn(traj)
     tprefix = 'critic_target' if cfg['slow_target'] else 'critic'
-    target = self.critic_target(traj, reward, tprefix)[0].detach()
+    target = self.critic_target(traj, reward, tprefix, cfg['critic_return'])[0].detach()
     tr_in = {k: v[:-1].detach() for k, v in traj.items()
              if k in ('deter', 'stoch')}
     out = self.head('critic', feat_of(tr_in), 'critic')
@@ -759,7 +766,7 @@ class RefAgent:
         'extr_imag_return_std': target.std(unbiased=False)})
     self.update_slow()
     # ---- actor update, agent.py:326-349 (sees the post-update slow critic)
-    ret, baseline = self.critic_target(traj, rewfn(traj), tprefix)
+    ret, baseline = self.critic_target(traj, rewfn(traj), tprefix, cfg['actor_return'])
     ret = self.retnorm(ret)
     baseline = self.retnorm(baseline, update=False)
     score = self.scorenorm(ret - baseline)

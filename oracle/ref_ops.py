@@ -436,7 +436,7 @@ class RefOps:
     out[A:2 * A] = (e.double() ** 2).sum(0)
 
   def imag_returns_fwd(self, rew_raw, val_raw, cont_raw, first_cont, reward,
-                       value, cont, weight, ret, H, N, gamma, lam):
+                       value, cont, weight, ret, H, N, gamma, lam, impl='gve'):
     rr = rew_raw.reshape(H + 1, N)
     vr = val_raw.reshape(H + 1, N)
     cr = cont_raw.reshape(H + 1, N)
@@ -450,11 +450,17 @@ class RefOps:
     value.copy_(v.reshape(value.shape))
     reward.copy_(r.reshape(reward.shape))
     d = c[1:] * gamma
-    R = v[H]
     outs = []
-    for t in reversed(range(H)):
-      R = r[t] + d[t] * ((1 - lam) * v[t + 1] + lam * R)
-      outs.append(R)
+    if impl == 'gae':  # agent.py:428-433
+      adv = torch.zeros_like(v[0])
+      for t in reversed(range(H)):
+        adv = (r[t] + d[t] * v[t + 1] - v[t]) + d[t] * lam * adv
+        outs.append(adv + v[t])
+    else:
+      R = v[H]
+      for t in reversed(range(H)):
+        R = r[t] + d[t] * ((1 - lam) * v[t + 1] + lam * R)
+        outs.append(R)
     ret.copy_(torch.stack(list(reversed(outs)), 0).reshape(ret.shape))
 
   def imag_returns_bwd(self, dret, dbase, rew_raw, val_raw, cont_raw, value,

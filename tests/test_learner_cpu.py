@@ -237,3 +237,17 @@ def test_named_workload_plumbing(name):
   grads = L.export_grads()
   for n, g in ag.last['grads'].items():
     assert helpers.rel_err(grads[n], g.numpy()) < 1e-6, n
+
+
+@pytest.mark.parametrize('over', [
+    {'actor_return': 'gae', 'critic_return': 'gae'},
+    {'slow_target': False},
+    {'wmkl.impl': 'prop', 'actent.impl': 'fixed'},
+    {'wmkl.impl': 'fixed', 'actent.impl': 'prop', 'scorenorm.impl': 'std'}])
+def test_learner_option_variants(over):
+  """Options of the reference beyond the defaults: VFunction.target 'gae' (agent.py:428-433),
+  slow_target: False (target_net = net, agent.py:395-396), AutoAdapt 'prop' / 'fixed'
+  (tfutils.py:427-432, 475-480): two steps against the autograd oracle."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=3, replay_chunk=4, imag_horizon=3)
+  cfg = cfg.update(over)
+  run_pair(cfg, steps=2, image=64, vector=5, action=3, terminals=0.1)
