@@ -240,7 +240,7 @@ def main():
   # launch of one sequential eager step, on the launch streams.
   roof = None
   step_flops = None
-  if rank == 0:
+  if True:  # every rank runs the traced step (it contains the collectives); rank 0 reports
     from daydreamer_amd import graphs
     agent.flush()
     all_ops = list({id(o): o for o in (L.ops_a, L.ops2, L.ops_b) if o is not None}.values())

@@ -82,6 +82,35 @@ def test_gemm_bf16_input_mode(hip, ref):
   close(C, A.double() @ B.double(), rtol=5e-6, what='default mode restored')
 
 
+def test_gemm_special_values(hip):
+  """Edge values through the exact 3-way bf16 split (gemm_core.h split3): subnormal operands
+  (the bf16 matrix pipe may flush them: the result must still be within 1e-36 absolute of the
+  float64 product - nothing of normal magnitude is lost), huge-but-finite operands (no spurious
+  overflow from the split), and +-inf / NaN operands: the affected outputs must be NON-FINITE
+  (inf - inf inside the split turns an inf into NaN; the learner's numerics check treats both
+  alike, tfutils.py:207,249), everything else stays exact."""
+  M, N, K = 70, 66, 100
+  A, B = rnd(M, K, seed=1), rnd(K, N, seed=2)
+  A[3, 5], A[10, 7], B[9, 4] = 1e-40, -3e-39, 2e-41          # subnormals
+  A[20, 11], B[11, 30] = 3e18, 1e19                           # product 3e37 < FLT_MAX
+  C = torch.zeros(M, N).cuda()
+  hip.gemm(A.cuda(), B.cuda(), C)
+  want = A.double() @ B.double()
+  got = C.cpu().double()
+  assert torch.isfinite(got).all()
+  err = (got - want).abs()
+  assert float((err / (A.double().abs() @ B.double().abs() + 1e-30)).max()) < 2e-6
+  for bad in (float('inf'), float('-inf'), float('nan')):
+    A2 = A.clone()
+    A2[33, 17] = bad
+    hip.gemm(A2.cuda(), B.cuda(), C)
+    got = C.cpu()
+    assert not torch.isfinite(got[33]).any(), bad            # the whole output row is poisoned
+    rest = torch.cat([got[:33], got[34:]])
+    assert torch.isfinite(rest).all()
+    close(rest, torch.cat([want[:33], want[34:]]), rtol=5e-6, what='rows untouched by the special value')
+
+
 def test_gemm_views(hip, ref):
   """Column slices of wider buffers as operands and output (ld != cols)."""
   Abuf, Bbuf, Cbuf = rnd(100, 300, seed=1), rnd(80, 64, seed=2), rnd(100, 200, seed=3)
