@@ -364,10 +364,15 @@ class Agent:
       # second launch context (own scratch workspace) for the side stream
       self.ops2 = hipops.HipOps(self.device, ws_bytes=1024 << 20)
       self.ops_b = None
+      # side context of the behaviour phase (heads of finished time chunks next to the
+      # imagination rollout, learner.phase_imagine)
+      self.ops_b2 = (hipops.HipOps(self.device, ws_bytes=1024 << 20)
+                     if self.cfg.get('hip', {}).get('overlap_heads', True) else None)
     else:
       self.ops = _ops
       self.ops2 = None
       self.ops_b = None
+      self.ops_b2 = None
       self.device = torch.device(_device or 'cpu')
     self._dtype = _dtype
     hip = self.cfg.get('hip', {})
@@ -416,7 +421,7 @@ class Agent:
         self.spec, self.ops, self.device, batch // self.world, length,
         rank=self.rank, world=self.world, comm=self.comm,
         noise_seed=self._noise_seed, dtype=self._dtype, groups=self.groups,
-        ops2=self.ops2, ops_b=self.ops_b, comm_b=self.comm_b)
+        ops2=self.ops2, ops_b=self.ops_b, comm_b=self.comm_b, ops_b2=self.ops_b2)
     if self._pending_load is not None:
       self._apply_load(self._pending_load)
       self._pending_load = None

@@ -31,9 +31,7 @@ extern "C" int dd_splitk_finish(const float* slabs, int n_slabs, float* C, long 
                                 float beta, const float* bias, void* stream) {
   if (n_slabs <= 0 || M <= 0 || N <= 0) return 0;
   const long MN = (long)M * N;
-  int blocks = (int)((MN + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  k_splitk_reduce<<<blocks, 256, 0, (hipStream_t)stream>>>(slabs, n_slabs, MN, N, C, ldc, bias, 1.f, beta);
+  launch_splitk_reduce(slabs, n_slabs, MN, N, C, ldc, bias, 1.f, beta, (hipStream_t)stream);
   DD_CHECK_LAUNCH("dd_splitk_finish");
   return 0;
 }

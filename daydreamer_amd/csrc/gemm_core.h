@@ -368,6 +368,39 @@ struct EpiConvUp4 {  // column n = (py, px, cb)
 };
 
 // ---------------------------------------------------------------------------
+// Tile <-> workgroup mapping.
+// ---------------------------------------------------------------------------
+
+// XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch placement, used for speed only)
+// and every XCD has its own 4 MiB L2.  Each XCD gets a CONTIGUOUS range of the linear tile
+// order, in which the column tiles of one row tile are adjacent: the (large, streamed)
+// row-operand tile is fetched from HBM once and re-read by the following column tiles from
+// that XCD's L2, instead of once per column tile from eight different L2s (PMC, round 1:
+// 3.0x the algorithmic bytes per launch).  tiles_m < 0 selects the plain column-major order
+// (DD_XCD_SWIZZLE=0, for A/B measurements).
+__device__ __forceinline__ void tile_coords(int tiles_m_signed, int& tm_idx, int& tn_idx) {
+  const int T = (int)gridDim.x;
+  const int tiles_m = tiles_m_signed < 0 ? -tiles_m_signed : tiles_m_signed;
+  int tile = (int)blockIdx.x;
+  if (tiles_m_signed > 0 && T >= 16) {
+    const int per = T >> 3, rem = T & 7;
+    const int x = tile & 7, slot = tile >> 3;
+    tile = x * per + (x < rem ? x : rem) + slot;
+    const int tiles_n = T / tiles_m;
+    tm_idx = tile / tiles_n;
+    tn_idx = tile - tm_idx * tiles_n;
+  } else {
+    tm_idx = tile % tiles_m;
+    tn_idx = tile / tiles_m;
+  }
+}
+
+inline int xcd_swizzle() {
+  static const int on = getenv("DD_XCD_SWIZZLE") ? atoi(getenv("DD_XCD_SWIZZLE")) : 1;
+  return on;
+}
+
+// ---------------------------------------------------------------------------
 // Main loop.
 // ---------------------------------------------------------------------------
 
@@ -385,8 +418,9 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   __shared__ __attribute__((aligned(16))) float As[2][BK * PA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
-  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+  int tmi, tni;
+  tile_coords(tiles_m, tmi, tni);
+  const int m0 = tmi * BM, n0 = tni * BN;
   const int kb = blockIdx.z * kps;
   const int ke = min(K, kb + kps);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -612,8 +646,9 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   __shared__ __attribute__((aligned(16))) unsigned char As[2][NPL * LA::BYTES];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NPL * LB::BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
-  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+  int tmi, tni;
+  tile_coords(tiles_m, tmi, tni);
+  const int m0 = tmi * BM, n0 = tni * BN;
   const int kb = blockIdx.z * kps;
   const int ke = min(K, kb + kps);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -776,6 +811,7 @@ inline int gemm_mode() {
 // workgroup per CU): distance 4 (BK 16) beats BK 32 x distance 2 and the fp32 loop.
 template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP>
 void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps, int tm) {
+  if (!xcd_swizzle()) tm = -tm;
   if (gemm_mode() == 0) {
     k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
     return;
@@ -805,6 +841,55 @@ __global__ void k_splitk_reduce(const float* __restrict__ slab, int S, long MN, 
     long o = m * ldc + n;
     if (beta != 0.f) r += beta * C[o];
     C[o] = r;
+  }
+}
+
+// the same sum (slabs ascending, then alpha, bias, beta * old: bit-identical) four columns
+// per thread with 16-byte accesses and the loads of four slabs in flight together;
+// N % 4 == 0, ldc % 4 == 0, 16-byte aligned C / bias / slabs, MN < 2^33
+__global__ void __launch_bounds__(256)
+k_splitk_reduce4(const float* __restrict__ slab, int S, long MN, int N4,
+                 float* C, long ldc, const float* bias, float alpha, float beta) {
+  const unsigned quads = (unsigned)(MN >> 2);
+  for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+    const float* p = slab + 4l * q;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 4 <= S; z += 4) {
+      const float4 t0 = *reinterpret_cast<const float4*>(p + (z + 0) * MN);
+      const float4 t1 = *reinterpret_cast<const float4*>(p + (z + 1) * MN);
+      const float4 t2 = *reinterpret_cast<const float4*>(p + (z + 2) * MN);
+      const float4 t3 = *reinterpret_cast<const float4*>(p + (z + 3) * MN);
+      f4_acc(s, t0); f4_acc(s, t1); f4_acc(s, t2); f4_acc(s, t3);
+    }
+    for (; z < S; ++z) f4_acc(s, *reinterpret_cast<const float4*>(p + z * MN));
+    const unsigned m = q / (unsigned)N4, n = (q - m * (unsigned)N4) * 4u;
+    float4 r = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + n);
+      r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w;
+    }
+    float4* o = reinterpret_cast<float4*>(C + (long)m * ldc + n);
+    if (beta != 0.f) {
+      const float4 c = *o;
+      r.x += beta * c.x; r.y += beta * c.y; r.z += beta * c.z; r.w += beta * c.w;
+    }
+    *o = r;
+  }
+}
+
+inline void launch_splitk_reduce(const float* slab, int S, long MN, int N, float* C, long ldc,
+                                 const float* bias, float alpha, float beta, hipStream_t st) {
+  const bool v4 = N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)slab & 15) == 0 &&
+                  ((uintptr_t)bias & 15) == 0 && MN < (1l << 33);
+  if (v4) {
+    long blocks = (MN / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    k_splitk_reduce4<<<(int)blocks, 256, 0, st>>>(slab, S, MN, N / 4, C, ldc, bias, alpha, beta);
+  } else {
+    int blocks = (int)((MN + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    k_splitk_reduce<<<blocks, 256, 0, st>>>(slab, S, MN, N, C, ldc, bias, alpha, beta);
   }
 }
 
@@ -870,9 +955,7 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
     return 0;
   }
   if (S > 1) {
-    int blocks = (int)((MN + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    k_splitk_reduce<<<blocks, 256, 0, st>>>(ws, S, MN, N, C, ldc, bias, alpha, beta);
+    launch_splitk_reduce(ws, S, MN, N, C, ldc, bias, alpha, beta, st);
     DD_CHECK_LAUNCH("dd_gemm_f32(split-k reduce)");
   }
   return 0;

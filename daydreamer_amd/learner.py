@@ -119,7 +119,7 @@ class Learner:
 
   def __init__(self, spec, ops, device, batch, length, params=None, seed=0,
                rank=0, world=1, comm=None, noise_seed=0, dtype=F32,
-               groups=None, ops2=None, ops_b=None, comm_b=None):
+               groups=None, ops2=None, ops_b=None, comm_b=None, ops_b2=None):
     self.spec, self.ops, self.device = spec, ops, torch.device(device)
     # ops_b: launch context (own scratch workspace) of the behaviour phase, so that it
     # can run on its own stream next to the next step's world-model phase (pipeline)
@@ -136,6 +136,11 @@ class Learner:
     self.ops2 = ops2
     self.side_stream = (torch.cuda.Stream(self.device)
                         if ops2 is not None and self.device.type == 'cuda' else None)
+    # ops_b2: the behaviour phase's own side context: the reward / cont / slow-critic heads of
+    # finished time chunks run next to the rest of the (latency-bound) imagination rollout
+    self.ops_b2 = ops_b2
+    self.side_stream_b = (torch.cuda.Stream(self.device)
+                          if ops_b2 is not None and self.device.type == 'cuda' else None)
     self.dtype = dtype  # float32 in the product; tests may use float64
     self.cfg = cfg = spec.cfg
     self.B, self.T = batch, length
@@ -415,17 +420,19 @@ class Learner:
     self.ops.reduce_stats(x, self.stat_sums[k], self.stat_maxs[k])
     return k
 
-  def fork(self):
+  def fork(self, stream=None):
     """Context: the body runs on the side stream, ordered after everything issued
     so far on the main stream (capturable: becomes a parallel graph branch)."""
-    if self.side_stream is None:
+    stream = stream or self.side_stream
+    if stream is None:
       return contextlib.nullcontext()
-    self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
-    return torch.cuda.stream(self.side_stream)
+    stream.wait_stream(torch.cuda.current_stream(self.device))
+    return torch.cuda.stream(stream)
 
-  def join(self):
-    if self.side_stream is not None:
-      torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+  def join(self, stream=None):
+    stream = stream or self.side_stream
+    if stream is not None:
+      torch.cuda.current_stream(self.device).wait_stream(stream)
 
   def allreduce(self, t):
     """Sum over data-parallel ranks (RCCL); a graph cut point."""
@@ -984,14 +991,17 @@ class Learner:
     ops.copy2d(b['post'], b['traj'][0][:, :self.F])
     ops.copy2d(b['cont'].view(1, -1), b['cont_b'].view(1, -1))
 
-  def imagine_rollout(self):
+  def imagine_rollout(self, on_state=None):
     """WorldModel.imagine (reference agent.py:234-254): H img_steps from the start states in
-    traj[0][:, :F] with the actor's sampled actions; fills traj [H+1, N, deter|stoch|action]."""
+    traj[0][:, :F] with the actor's sampled actions; fills traj [H+1, N, deter|stoch|action].
+    on_state(t): called once the latent state of time row t is complete (t = 0..H)."""
     ops, b, cfg = self.ops, self.b, self.cfg
     N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
     traj = b['traj']
     ca = cfg['actor']
     lo, hi = ca['minstd'], ca['maxstd']
+    if on_state:
+      on_state(0)
     for t in range(H + 1):
       st = lambda buf, t_=t: buf.view(H + 1, N, -1)[t_]
       if self.discrete:
@@ -1009,18 +1019,53 @@ class Learner:
                             self.ai_img_stats, si)
         ops.stats_fwd(xs, b['u_img'][t], b['ilogit'], traj[t + 1][:, D:F],
                       self.G, self.C, self.unimix, 0)
+        if on_state:
+          on_state(t + 1)
+
+  HEAD_CHUNK = 4  # time rows per chunk of the overlapped head evaluation
 
   def phase_imagine(self):
     ops, b, cfg = self.ops, self.b, self.cfg
     N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
     traj = b['traj']  # traj[0][:, :F] = start states, set by phase_wm_opt
-    self.imagine_rollout()
     feat = traj.view(M, F + A)[:, :F]
-    (rew,) = self.head_fwd('reward', self.acts_im['reward'], feat)
-    (cont,) = self.head_fwd('cont', self.acts_im['cont'], feat)
-    # target network: the slow copy, or the online critic itself with slow_target: False
-    # (agent.py:391-396: then heads['critic_target'] aliases the online parameters, _build_layers)
-    (val,) = self.head_fwd('critic_target', self.acts_im['critic_target'], feat)
+    # reward / cont / target-critic heads over the trajectory (rewfn, cont head, target net:
+    # agent.py:255-257, 400-403, 426).  They only read finished latent states, so each chunk
+    # of time rows is evaluated on the side stream while the rollout - a chain of mid-size
+    # dependent launches that leaves most of the chip idle - continues on the main stream.
+    def heads(r0, r1):
+      sel = lambda buf: buf[r0:r1]
+      x = feat[r0:r1]
+      self.head_fwd('reward', self.acts_im['reward'], x, sel)
+      self.head_fwd('cont', self.acts_im['cont'], x, sel)
+      # target network: the slow copy, or the online critic itself with slow_target: False
+      # (agent.py:391-396: then heads['critic_target'] aliases the online parameters)
+      self.head_fwd('critic_target', self.acts_im['critic_target'], x, sel)
+    side = self.side_stream_b   # (None on CPU: the chunks then run inline, same arithmetic)
+    if self.ops_b2 is None or not self._in_b:
+      self.imagine_rollout()
+      heads(0, M)
+    else:
+      done = [0]
+      def on_state(t):
+        if (t + 1) % self.HEAD_CHUNK == 0 or t == H:
+          r0, r1 = done[0] * N, (t + 1) * N
+          done[0] = t + 1
+          if t == H:   # last chunk: nothing left to overlap with, stay on the main stream
+            if side is not None:
+              self.join(side)
+            heads(r0, r1)
+            return
+          with (self.fork(side) if side is not None else contextlib.nullcontext()):
+            keep, self.ops = self.ops, self.ops_b2
+            try:
+              heads(r0, r1)
+            finally:
+              self.ops = keep
+      self.imagine_rollout(on_state)
+    rew = self.acts_im['reward'][1][0].z
+    cont = self.acts_im['cont'][1][0].z
+    val = self.acts_im['critic_target'][1][0].z
     ops.imag_returns_fwd(rew.view(-1), val.view(-1), cont.view(-1), b['cont_b'],
                          b['i_reward'], b['i_value'], b['i_cont'], b['i_weight'],
                          b['i_ret'], H, N, cfg['discount'], cfg['return_lambda'],

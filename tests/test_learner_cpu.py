@@ -251,3 +251,23 @@ def test_learner_option_variants(over):
   cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=3, replay_chunk=4, imag_horizon=3)
   cfg = cfg.update(over)
   run_pair(cfg, steps=2, image=64, vector=5, action=3, terminals=0.1)
+
+
+def test_chunked_heads_equal_bulk():
+  """phase_imagine with a side context evaluates the reward / cont / target-critic heads per
+  chunk of finished time rows (overlapping the rollout on the GPU): same results as one bulk
+  evaluation after the rollout."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=3, replay_chunk=4, imag_horizon=6)
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, image=64, vector=5, action=3)
+  outs = []
+  for side in (None, ref_ops.RefOps('cpu')):
+    L = learner_mod.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params, noise_seed=7,
+                            dtype=torch.float64, ops_b2=side)
+    for i in range(2):
+      L.upload(data)
+      L.train_step_device(use_carry=(i > 0))
+    outs.append((L.export_params(), L.read_metrics()))
+  for k, v in outs[0][0].items():
+    assert np.array_equal(v, outs[1][0][k]), k
+  for k, v in outs[0][1].items():
+    assert np.array_equal(v, outs[1][1][k], equal_nan=True), k
