@@ -248,6 +248,9 @@ def main():
     for o in all_ops:
       o.trace = trace
     keep, L.plan = L.plan, graphs.EagerPlan()
+    # strictly one launch at a time: no side-stream branches while the launches are timed
+    side = (L.ops2, L.ops_b2)
+    L.ops2 = L.ops_b2 = None
     torch.cuda.synchronize()
     L.upload(agent._shard(data))
     L.train_step_device(True)
@@ -255,6 +258,7 @@ def main():
     for o in all_ops:
       o.trace = None
     L.plan = keep
+    L.ops2, L.ops_b2 = side
     tot_f = sum(f for _, f, _, _ in trace)
     tot_t = sum(e0.elapsed_time(e1) for _, _, e0, e1 in trace) * 1e-3
     by = {}

@@ -366,8 +366,9 @@ class Agent:
       self.ops_b = None
       # side context of the behaviour phase (heads of finished time chunks next to the
       # imagination rollout, learner.phase_imagine)
+      hipc = self.cfg.get('hip', {})
       self.ops_b2 = (hipops.HipOps(self.device, ws_bytes=1024 << 20)
-                     if self.cfg.get('hip', {}).get('overlap_heads', True) else None)
+                     if hipc.get('overlap_heads', True) and not hipc.get('pipeline', False) else None)
     else:
       self.ops = _ops
       self.ops2 = None

@@ -1210,13 +1210,20 @@ class Learner:
                          self.acts_im['cont'][1][0].dout.view(-1), H, N,
                          cfg['discount'], cfg['return_lambda'])
     ops.fill(dtraj, 0.0)
-    self.head_bwd('reward', self.acts_im['reward'], feat, None, dfeat, 0.0, params=False)
-    self.head_bwd('cont', self.acts_im['cont'], feat, None, dfeat, 1.0, params=False)
-    self.head_bwd('critic_target', self.acts_im['critic_target'], feat, None,
-                  dfeat, 1.0, params=False)
-    # reverse scan through the imagined world model (data gradients only)
+    # Gradient of the score w.r.t. every imagined latent state through the reward / cont /
+    # target-critic heads (data gradients only), then the reverse scan through the imagined
+    # world model.  Scan step t adds into row t-1, so the heads of row t-1 must be done before
+    # it; apart from that the heads of a time chunk are independent of the scan: with a side
+    # context the heads of chunk c-1 run next to the (latency-bound) scan over chunk c.
+    def heads_bwd(t0, t1):
+      r0, r1 = t0 * N, t1 * N
+      sel = lambda buf: buf[r0:r1]
+      x, dx = feat[r0:r1], dfeat[r0:r1]
+      self.head_bwd('reward', self.acts_im['reward'], x, sel, dx, 0.0, params=False)
+      self.head_bwd('cont', self.acts_im['cont'], x, sel, dx, 1.0, params=False)
+      self.head_bwd('critic_target', self.acts_im['critic_target'], x, sel, dx, 1.0, params=False)
     zr = self.zero_rows[:N]
-    for t in reversed(range(1, H + 1)):
+    def scan_step(t):
       si = lambda buf, t_=t - 1: buf.view(H, N, -1)[t_]
       ops.stats_bwd(si(self.ai_img_stats.z), None, dtraj[t][:, D:F],
                     si(self.ai_img_stats.dout), self.G, self.C, self.unimix)
@@ -1226,6 +1233,29 @@ class Learner:
                     b['iz3'], b['igstats'], si, b['idz3'], b['idy3'], b['idh'],
                     dtraj[t - 1][:, D:], 1.0, self.P['img_in'])
       ops.reset_mask_bwd(b['idh'], zr, dtraj[t - 1][:, :D])
+    side = self.side_stream_b
+    if self.ops_b2 is None or not self._in_b:
+      heads_bwd(0, H + 1)
+      for t in reversed(range(1, H + 1)):
+        scan_step(t)
+    else:
+      CH = self.HEAD_CHUNK
+      bounds = list(range(0, H + 1, CH)) + [H + 1]
+      chunks = list(zip(bounds[:-1], bounds[1:]))        # [(t0, t1)], ascending
+      heads_bwd(*chunks[-1])
+      for c in reversed(range(len(chunks))):
+        t0, t1 = chunks[c]
+        if c > 0:
+          with (self.fork(side) if side is not None else contextlib.nullcontext()):
+            keep, self.ops = self.ops, self.ops_b2
+            try:
+              heads_bwd(*chunks[c - 1])
+            finally:
+              self.ops = keep
+        for t in reversed(range(max(t0, 1), t1)):
+          if t == t0 and c > 0 and side is not None:
+            self.join(side)        # row t0-1 belongs to the chunk evaluated on the side stream
+          scan_step(t)
     # policy head + entropy bonus, then the actor network (bulk)
     dact = dtraj.view(M, F + A)[:, F:]
     oa = self.acts_im['actor'][1]

@@ -26,7 +26,10 @@ sp = spec_mod.build_spec(plain, shapes, A, bool(getattr(act['action'], 'discrete
 B, T = plain['batch_size'], plain['replay_chunk']
 data = synthetic.make_batch(obs, act, B, T, seed=0)
 ops = hipops.HipOps('cuda:0')
-L = LM.Learner(sp, ops, 'cuda:0', B, T, params=spec_mod.init_params(sp, 0))
+# side launch contexts as the Agent creates them in its default (sequential) mode
+L = LM.Learner(sp, ops, 'cuda:0', B, T, params=spec_mod.init_params(sp, 0),
+               ops2=hipops.HipOps('cuda:0', ws_bytes=1024 << 20),
+               ops_b2=hipops.HipOps('cuda:0', ws_bytes=1024 << 20))
 L.upload(data)
 for i in range(2):
   L.train_step_device(use_carry=i > 0)
