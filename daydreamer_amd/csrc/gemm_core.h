@@ -873,6 +873,9 @@ void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps,
       k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 1, 16, 2, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
     return;
   }
+  // (64x64 tiles, about one workgroup per CU: prefetch distance 8 measured equal to 4 on every
+  // 2500-row and 50-row shape of the step - round 2, profiles/r02_gemm_prefetch_distance.txt -
+  // so that loop is not bound by the global-load latency; distance 4 keeps the registers)
   if constexpr (BM == 64 && BN == 64)
     k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   else
