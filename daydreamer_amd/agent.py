@@ -234,9 +234,15 @@ class Pipeline:
       s1.wait_event(self.ev_a)             # (the previous step may have used other streams)
     self.pa1.replay_on(s1)
     self.ev_in.record(s1)
+    # A2 = [data-parallel all-reduce of the world-model gradients] + [grad norm, Adam, hand-over].
+    # Only the second part must wait for B(k-1), which still reads the world-model weights:
+    # the collective (it touches nothing but the model gradient arena) runs next to B(k-1).
+    items = self.pa2.items
+    last = max(i for i, (kind, _) in enumerate(items) if kind == 'graph')
+    self.pa2.replay_on(s1, stop=last)
     if self.pending is not None:
-      s1.wait_event(self.ev_b[par ^ 1])    # B(k-1) still reads the world-model weights
-    self.pa2.replay_on(s1)
+      s1.wait_event(self.ev_b[par ^ 1])
+    self.pa2.replay_on(s1, start=last)
     self._publish(self.pub_a[par], s1)
     self.ev_a.record(s1)
     s2.wait_event(self.ev_a)

@@ -19,6 +19,10 @@ namespace {
 #ifndef BKBIG
 #define BKBIG 16
 #endif
+// two accumulator chains in the 64x64 tile's loop (k_mfma_gemm_s3 A2)
+#ifndef DD_A2_64
+#define DD_A2_64 false
+#endif
 
 // ---------------------------------------------------------------------------
 // Operand loaders.  load4(r, k, kend, v) returns four consecutive elements
@@ -598,6 +602,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
 
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef DD_ABL_NOSPLIT   // ablation (tools/abl_gemm.sh): no split arithmetic (wrong results, timing only)
+  h = m = l = __float_as_uint(x);
+  return;
+#endif
   h = __float_as_uint(x) & 0xFFFF0000u;
   const float r1 = x - __uint_as_float(h);          // exact
   m = __float_as_uint(r1) & 0xFFFF0000u;
@@ -619,20 +627,22 @@ struct PlaneS3 {
   // bytes per k-octet (KC) / per k (RC); the pad staggers bank quarters
   static constexpr int STR = KC ? BX * 16 + (BK == 16 ? 64 : 32) : BX * 2 + 64;
   static constexpr int BYTES = KC ? (BK / 8) * STR : BK * STR;
-  // float4 units staged per thread: KC chunks (row, 4 k); RC patches (4 rows, 2 k) = 2 units
+  // float4 units staged per tile: KC chunks (row, 4 k), RC chunks (4 rows, k); UNITS / 256 per
+  // thread, every thread active (a partially active workgroup puts the loads behind a
+  // divergent branch, and the compiler then waits for ALL outstanding loads - vmcnt 3 instead
+  // of 9 - before staging: the register prefetch distance collapsed to one k-tile and the
+  // 64x64 loop ran at one memory latency per k-tile, with or without the MFMAs)
   static constexpr int UNITS = BX * BK / 4;            // float4s per tile
-  static constexpr int WORK = KC ? UNITS : UNITS / 2;  // chunks / patches per tile
-  static constexpr int N = (WORK >= 256 ? WORK / 256 : 1) * (KC ? 1 : 2);
-  static constexpr int ACTIVE = WORK >= 256 ? 256 : WORK;  // threads that stage
+  static_assert(UNITS % 256 == 0, "tile too small for 256 staging threads");
+  static constexpr int N = UNITS / 256;
+  static constexpr int ACTIVE = 256;
   // unit u of thread tid -> (row, k) of its first element
   static __device__ __forceinline__ void coord(int tid, int u, int& r, int& k) {
+    const int id = tid + u * 256;
     if constexpr (KC) {
-      const int id = tid + u * 256;
       r = id / (BK / 4); k = (id % (BK / 4)) * 4;
-    } else {  // patch = units (2p, 2p+1): same rows, k and k+1
-      const int pp = tid + (u >> 1) * 256;
-      const int kp = pp / (BX / 4);
-      r = (pp % (BX / 4)) * 4; k = 2 * kp + (u & 1);
+    } else {
+      k = id / (BX / 4); r = (id % (BX / 4)) * 4;
     }
   }
   // staged float4 -> one 8-byte store per plane
@@ -671,8 +681,12 @@ struct PlaneS3 {
   }
 };
 
+// A2: a second accumulator per output block for the three small-term products.  A wave of a
+// 64x64 tile owns ONE 32x32 block, so its six products per k-step form one dependent MFMA
+// chain (each waits for the previous result); two chains of three halve that latency.  The
+// partial sums are added once, after the K loop (small terms + large terms).
 template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int NP = 6, int BK = 16,
-          int ST = 1, bool IL = false>
+          int ST = 1, bool IL = false, bool A2 = false>
 __global__ void __launch_bounds__(256, 2)
 k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   constexpr int NPL = NP == 1 ? 1 : (NP == 3 ? 2 : 3);     // planes kept
@@ -692,13 +706,16 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   const bool a_on = LA::ACTIVE >= 256 || tid < LA::ACTIVE;
   const bool b_on = LB::ACTIVE >= 256 || tid < LB::ACTIVE;
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[TM][TN], acs[A2 ? TM : 1][A2 ? TN : 1];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[a][b][r] = 0.f;
+        if (A2) acs[a][b][r] = 0.f;
+      }
 
   float ra_[ST][NA][4], rb_[ST][NB][4];
 
@@ -754,13 +771,29 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       // product (pa, pb) of the bit-planes, smallest terms first; consecutive MFMAs go
       // to different accumulators
       constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
+      // (A2: q = 0..2 go to the small-term accumulator, q = 3..5 to the main one; the order
+      // 0,3,1,4,2,5 alternates the two chains)
+      constexpr int ORD_[6] = {0, 3, 1, 4, 2, 5};
 #pragma unroll
-      for (int q = (NP == 6 ? 0 : (NP == 3 ? 3 : 5)); q < 6; ++q)
+      for (int qi = (NP == 6 ? 0 : (NP == 3 ? 3 : 5)); qi < 6; ++qi)
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TN; ++b) {
+            const int q = (A2 && NP == 6) ? ORD_[qi] : qi;
+#ifdef DD_ABL_NOMFMA    // ablation: fragment reads kept alive, no matrix instruction
+            acc[a][b][q] += (float)af[a][PA_[q]][0] + (float)bf[b][PB_[q]][0];
+#elif defined(DD_ABL_ONEMFMA)  // ablation: one product instead of six (dependent-chain length)
+            if (q == 5) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+            else acc[a][b][q] += (float)af[a][PA_[q]][0] + (float)bf[b][PB_[q]][0];
+#else
+            if (A2 && q < 3)
+              acs[A2 ? a : 0][A2 ? b : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  af[a][PA_[q]], bf[b][PB_[q]], acs[A2 ? a : 0][A2 ? b : 0], 0, 0, 0);
+            else
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+#endif
+          }
     }
   };
 
@@ -814,6 +847,14 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
     }
   }
 
+  if (A2) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] += acs[A2 ? a : 0][A2 ? b : 0][r];
+  }
   const int lk = lane >> 5, lr = lane & 31;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -876,10 +917,17 @@ void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps,
   // (64x64 tiles, about one workgroup per CU: prefetch distance 8 measured equal to 4 on every
   // 2500-row and 50-row shape of the step - round 2, profiles/r02_gemm_prefetch_distance.txt -
   // so that loop is not bound by the global-load latency; distance 4 keeps the registers)
-  if constexpr (BM == 64 && BN == 64)
-    k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-  else
+  if constexpr (BM == 64 && BN == 64) {
+#ifdef DD_EXP64   // experiment build (tools/exp64.sh): loop variants of the 64x64 tile by DD_V64
+    static const int v64 = getenv("DD_V64") ? atoi(getenv("DD_V64")) : 0;
+    if (v64 == 4) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 8, false, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
+    if (v64 == 5) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 8, false, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
+    if (v64 == 6) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 8, true, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
+#endif
+    k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false, DD_A2_64><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  } else {
     k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 2, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+  }
 }
 
 __global__ void k_splitk_reduce(const float* __restrict__ slab, int S, long MN, int N,

@@ -90,8 +90,8 @@ class GraphPlan:
     self.items.append(('cond', (pred, g)))
     self._begin()
 
-  def _run(self):
-    for kind, item in self.items:
+  def _run(self, start=0, stop=None):
+    for kind, item in self.items[start:stop]:
       if kind == 'graph':
         item.replay()
       elif kind == 'cond':
@@ -107,11 +107,12 @@ class GraphPlan:
       self._run()
     cur.wait_stream(self.stream)
 
-  def replay_on(self, stream):
-    """Enqueue the plan on `stream` and return without joining any other stream (the
-    caller orders streams with events: agent.Agent's two-stream pipeline)."""
+  def replay_on(self, stream, start=0, stop=None):
+    """Enqueue the plan (or its items [start:stop]) on `stream` and return without joining
+    any other stream (the caller orders streams with events: agent.Agent's two-stream
+    pipeline)."""
     with torch.cuda.stream(stream):
-      self._run()
+      self._run(start, stop)
 
   @property
   def n_graphs(self):
