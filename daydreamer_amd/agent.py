@@ -519,7 +519,8 @@ class Agent:
              'kl_loss': L.b['kl']}.get(name)
       if src is None:
         raise NotImplementedError(f'priority: {name}')
-      outs = {'key': data['key'],
+      key = data['key']
+      outs = {'key': key.cpu().numpy() if isinstance(key, torch.Tensor) else key,
               'priority': src.view(L.B, L.T).cpu().numpy().copy()}
     return outs, TrainState(L), metrics
 

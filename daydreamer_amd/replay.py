@@ -167,7 +167,8 @@ class DeviceReplay:
       yield chunk
 
   def prioritize(self, keys, priorities):
-    pass
+    """Uniform replay keeps no priorities (reference FixedLength has none either); the
+    prioritised variant is DevicePrioritized below."""
 
   def save(self, directory=None):
     """Write every not-yet-written episode as `<time>-<id>-len<L>-rew<R>.npz`
@@ -252,6 +253,10 @@ class DeviceReplay:
       if pick is None:
         raise RuntimeError('DeviceReplay.sample_batch: no episodes stored')
       picks.append(pick[1])
+    return self._gather(picks, batch)
+
+  def _gather(self, picks, batch):
+    """Assemble the chunks starting at ring rows `picks` on the device (dd_replay_gather)."""
     starts = torch.tensor(picks, dtype=torch.int64).to(self.device, non_blocking=True)
     out = self._out.get(batch)
     if out is None:
@@ -272,3 +277,210 @@ class DeviceReplay:
         timelib.sleep(1)
         continue
       yield self.sample_batch(batch)
+
+
+class PriorityTable:
+  """Two-level sampling distribution over (episode, chunk start) with per-step priorities:
+  the behaviour of the reference's `Priorities` (embodied/replay/prios.py:8-152), restated.
+
+  Every episode holds one priority per step.  `aggregate(steps)` maps them to one
+  non-negative weight per chunk start (Prioritized builds it as a windowed sum,
+  prioritized.py:25-31).  Within an episode, starts are drawn from
+  `fraction * weights/sum + (1 - fraction) * uniform`, where `uniform` up-weights the first /
+  last start by `(len(steps) - n_starts) * prio_starts / prio_ends` (prios.py:126-131);
+  episodes are drawn from `fraction * totals/sum + (1 - fraction) * n_starts/sum`
+  (prios.py:134-148).  Infinite weights (fresh, never-trained chunks) win outright: only they
+  keep probability mass in the weighted part (prios.py:122-124, 139-141).  Draws use an own
+  `RandomState(0)` with the reference's call sequence (prios.py:52-64)."""
+
+  def __init__(self, aggregate, fraction, prio_starts, prio_ends):
+    self.aggregate, self.fraction = aggregate, fraction
+    self.prio_starts, self.prio_ends = prio_starts, prio_ends
+    self.random = np.random.RandomState(seed=0)
+    self.steps, self.start_probs, self.totals = {}, {}, {}   # per episode id
+    self._episode_probs = None
+    self.samples = collections.defaultdict(int)
+    self.update_min, self.update_max = np.inf, -np.inf
+
+  def __len__(self):
+    return len(self.steps)
+
+  def _refresh(self, key):
+    weights = self.aggregate(self.steps[key])
+    assert (weights >= 0).all(), weights
+    self.totals[key] = weights.sum()          # before infinities are replaced
+    fresh = np.isposinf(weights)
+    if fresh.any():
+      weights = fresh.astype(np.float64)
+    n = len(weights)
+    uniform = np.full(n, 1.0 / n)
+    if self.prio_starts or self.prio_ends:
+      extra = len(self.steps[key]) - n
+      uniform[0] *= extra * self.prio_starts
+      uniform[-1] *= extra * self.prio_ends
+      uniform /= uniform.sum()
+    mass = weights.sum()
+    weighted = uniform if mass == 0 else weights / mass
+    self.start_probs[key] = self.fraction * weighted + (1 - self.fraction) * uniform
+    self._episode_probs = None
+
+  def add(self, key, prios):
+    self.steps[key] = np.asarray(prios, np.float64).copy()
+    self._refresh(key)
+
+  def update(self, key, index, prios):
+    prios = np.asarray(prios, np.float64)
+    self.update_min = min(self.update_min, prios.min())
+    self.update_max = max(self.update_max, prios.max())
+    if key not in self.steps or not 0 <= index <= len(self.steps[key]):
+      raise KeyError(key)
+    try:
+      self.steps[key][index:index + len(prios)] = prios
+    except ValueError:
+      raise KeyError(key)
+    self._refresh(key)
+
+  def remove(self, key):
+    for table in (self.steps, self.start_probs, self.totals, self.samples):
+      table.pop(key, None)
+    self._episode_probs = None
+
+  def _episodes(self):
+    if self._episode_probs is None:
+      keys = tuple(self.steps)
+      counts = np.array([len(self.start_probs[k]) for k in keys], np.float64)
+      totals = np.array([self.totals[k] for k in keys], np.float64)
+      fresh = np.isposinf(totals)
+      if fresh.any():
+        totals = fresh.astype(np.float64)
+      mass = totals.sum()
+      weighted = np.full(len(keys), 1.0 / len(keys)) if mass == 0 else totals / mass
+      self._episode_probs = (keys, self.fraction * weighted + (1 - self.fraction) * counts / counts.sum())
+    return self._episode_probs
+
+  def sample(self):
+    """(episode id, chunk start, probability of that draw)."""
+    keys, probs = self._episodes()
+    if len(keys) == 1:
+      key, prob = keys[0], 1.0
+    else:
+      pos = self.random.choice(len(probs), p=probs)
+      key, prob = keys[pos], probs[pos]
+    inner = self.start_probs[key]
+    index = self.random.choice(len(inner), p=inner)
+    self.samples[key] += 1
+    return key, index, prob * inner[index]
+
+  @property
+  def stats(self):
+    if len(self) <= 1:
+      return {}
+    _, probs = self._episodes()
+    counts = list(self.samples.values()) or [0]
+    return {
+        'randomness': float(-(probs @ np.log(probs)) / np.log(len(probs))),
+        'seen_frac': len(self.samples) / len(self.steps), 'seen_max': max(counts),
+        'sample_frac': sum(counts) / len(self.steps),
+        'update_min': self.update_min, 'update_max': self.update_max}
+
+
+class DevicePrioritized(DeviceReplay):
+  """`embodied.replay.Prioritized` (reference replay/prioritized.py:12-135) over the HBM episode
+  ring.  Every sampled chunk carries `key` int64[T,3] (episode uuid + chunk start of the
+  priority draw, prioritized.py:114-124) and `prob` float64[T]; `Agent.train` hands them back
+  with the per-step priorities (`outs['key'], outs['priority']`, agent.py:89-93) and the run
+  loop calls `prioritize` (run/learning.py:57-58).  A drawn chunk cools down to priority 0
+  (-inf with softmax) until it is re-prioritised (prioritized.py:33-36, 97).
+
+  Faithful to the reference AS WRITTEN: the steps that are returned are chosen by the same
+  uniform rule as FixedLength (prioritized.py:100-110 draw the episode and start again from
+  `self.random`, independently of the priority draw) - the priority draw only determines the
+  `key` / `prob` bookkeeping; and episodes evicted from the ring are dropped from the table
+  (the reference leaves them behind, its TODO at prioritized.py:17-18, and ignores late
+  priorities for them - as does `prioritize` here)."""
+
+  def __init__(self, chunk=64, capacity=None, prio_starts=0.0, prio_ends=1.0, fraction=0.1,
+               softmax=False, temp=1.0, constant=0.0, exponent=0.5, **kw):
+    super().__init__(chunk=chunk, capacity=capacity, prio_starts=prio_starts,
+                     prio_ends=prio_ends, **kw)
+    def aggregate(prios):  # prioritized.py:25-31
+      if softmax:
+        prios = np.maximum(np.exp(prios / temp) + constant, 0)
+      else:
+        prios = np.abs(prios) ** exponent
+      return np.convolve(prios, np.ones(self.chunk), 'valid')
+    self.prios = PriorityTable(aggregate, fraction, prio_starts, prio_ends)
+    self.cooldown = np.full(self.chunk, -np.inf if softmax else 0.0, np.float64)
+    self.handed_out = set()
+
+  @property
+  def stats(self):
+    return {**super().stats, **self.prios.stats}
+
+  def add_traj(self, traj, key=None, stamp=None):
+    key = super().add_traj(traj, key, stamp)
+    if key is not None:
+      self.prios.add(key, np.full(self.table[key][1], np.inf, np.float64))
+    return key
+
+  def _drop(self, key):
+    super()._drop(key)
+    self.prios.remove(key)
+
+  @staticmethod
+  def encode(key, index):
+    return np.frombuffer(uuid.UUID(key).bytes + int(index).to_bytes(8, 'big'), np.int64)
+
+  @staticmethod
+  def decode(code):
+    raw = np.asarray(code, np.int64).tobytes()
+    return uuid.UUID(bytes=raw[:16]).hex, int.from_bytes(raw[16:], 'big')
+
+  def prioritize(self, keys, priorities):
+    keys = np.asarray(keys, np.int64)[:, 0]     # replicated along the time axis
+    priorities = np.asarray(priorities, np.float64)
+    assert priorities.shape == (len(keys), self.chunk), priorities.shape
+    for code, prio in zip(keys, priorities):
+      assert tuple(code.tolist()) in self.handed_out, code
+      key, index = self.decode(code)
+      try:
+        self.prios.update(key, index, prio)
+      except KeyError:
+        print('Received priorities for an episode that was already removed.')
+
+  def _pick_prio(self):
+    """One chunk: (ring row of its first step, key code int64[3], prob); None when empty."""
+    if not self.table:
+      return None
+    key, index, prob = self.prios.sample()
+    self.prios.update(key, index, self.cooldown)
+    code = self.encode(key, index)
+    self.handed_out.add(tuple(code.tolist()))
+    return self._pick()[1], code, prob
+
+  def dataset(self):
+    while True:
+      pick = self._pick_prio()
+      if pick is None:
+        print('Waiting for episodes.')
+        timelib.sleep(1)
+        continue
+      start, code, prob = pick
+      chunk = {k: r[start:start + self.chunk].cpu().numpy() for k, r in self.rings.items()}
+      chunk['is_first'] = np.zeros(self.chunk, bool)
+      chunk['is_first'][0] = True
+      chunk['key'] = np.repeat(code[None], self.chunk, axis=0)
+      chunk['prob'] = np.repeat(np.float64(prob), self.chunk)
+      yield chunk
+
+  def sample_batch(self, batch):
+    picks = [self._pick_prio() for _ in range(batch)]
+    if any(p is None for p in picks):
+      raise RuntimeError('DevicePrioritized.sample_batch: no episodes stored')
+    out = self._gather([p[0] for p in picks], batch)
+    out = dict(out)
+    codes = np.stack([p[1] for p in picks])                       # [B, 3]
+    out['key'] = torch.from_numpy(np.repeat(codes[:, None], self.chunk, 1).copy()).to(self.device)
+    out['prob'] = torch.from_numpy(np.repeat(np.array([p[2] for p in picks], np.float64)[:, None],
+                                             self.chunk, 1).copy()).to(self.device)
+    return out

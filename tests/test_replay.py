@@ -199,3 +199,59 @@ def test_edge_cases(tmp_path):
   dst.load()
   assert sorted(n for _, n in dst.table.values()) == [12, 13]
   assert len(dst) == 25
+
+
+# ---- prioritized replay -------------------------------------------------------------------
+
+def _prio_trace(replay, lengths, n_picks):
+  sys.path.insert(0, str(ROOT / 'tools'))
+  import importlib
+  sys.modules.setdefault('gym', types.ModuleType('gym'))
+  spec = importlib.util.spec_from_file_location('mpg', ROOT / 'tools' / 'make_prio_golden.py')
+  src = (ROOT / 'tools' / 'make_prio_golden.py').read_text()
+  # only the `trace` driver is needed (the module imports the reference at top level)
+  ns = {'np': np, 'itertools': __import__('itertools'), 'uuid': __import__('uuid'),
+        'episodes': episodes}
+  start = src.index('def trace(')
+  end = src.index("if __name__ == '__main__':")
+  exec(src[start:end], ns)
+  return ns['trace'](replay, lengths, n_picks, replay.chunk)
+
+
+@pytest.mark.parametrize('name,kw', [
+    ('power', dict(fraction=0.5, exponent=0.5)),
+    ('softmax', dict(fraction=0.3, softmax=True, temp=2.0, constant=0.1))])
+def test_prioritized_matches_reference_golden(name, kw):
+  """DevicePrioritized against a committed trace of the reference's Prioritized replay
+  (tools/make_prio_golden.py): the same chunks, the same priority-draw keys and the same
+  draw probabilities, with priorities fed back through prioritize() every four draws."""
+  g = np.load(ROOT / 'tests' / 'golden' / 'replay_prio.npz')
+  rep = replay_mod.DevicePrioritized(chunk=int(g['chunk']), capacity=100000, device='cpu',
+                                     ops=ref_ops.RefOps('cpu'), **kw)
+  tags, keys, probs = _prio_trace(rep, g['lengths'], len(g[f'{name}_tags']))
+  np.testing.assert_array_equal(tags, g[f'{name}_tags'])
+  np.testing.assert_array_equal(keys, g[f'{name}_keys'])
+  np.testing.assert_allclose(probs, g[f'{name}_probs'], rtol=1e-12)
+  st = rep.stats
+  assert st['replay_trajs'] == len(g['lengths']) and 0 < st['randomness'] <= 1
+  assert st['update_max'] > 0
+
+
+def test_prioritized_batches_and_eviction():
+  rep = replay_mod.DevicePrioritized(chunk=8, capacity=120, device='cpu', ops=ref_ops.RefOps('cpu'))
+  for traj in episodes([30, 40, 50, 35]):
+    rep.add_traj(traj)
+  assert len(rep.prios) == len(rep.table) < 4            # evicted episodes leave the table too
+  batch = rep.sample_batch(5)
+  assert batch['key'].shape == (5, 8, 3) and batch['key'].dtype == torch.int64
+  assert batch['prob'].shape == (5, 8) and batch['prob'].dtype == torch.float64
+  assert bool((batch['key'][:, 0] == batch['key'][:, -1]).all())
+  rep.prioritize(batch['key'].numpy(), np.abs(np.random.RandomState(0).randn(5, 8)))
+  key, index = rep.decode(batch['key'][0, 0].numpy())
+  assert key in rep.table and rep.prios.steps[key][index] > 0
+  # priorities for an episode that has been evicted meanwhile are ignored, not an error
+  for traj in episodes([60, 60], seed=5):
+    rep.add_traj(traj)
+  rep.prioritize(batch['key'].numpy(), np.ones((5, 8)))
+  chunk = next(rep.dataset())
+  assert chunk['key'].shape == (8, 3) and chunk['prob'].shape == (8,) and chunk['is_first'][0]
