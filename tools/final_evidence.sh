@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round evidence on the MI355X box: GPU test log, smoke, bench lines, rocprofv3 kernel stats of the
+# bench command (pipelined default and sequential), PMC HBM traffic.  Writes gpurun_out/<tag>_*.
+tag=${1:-r02}
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+(timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rA 2>&1 | tail -170 > gpurun_out/${tag}_pytest_gpu.log)
+(timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1)
+(timeout 400 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err)
+(timeout 250 python bench.py --gpus 2 --steps 3 --warmup 3 --no-cpu-baseline 2>/dev/null | grep -a -o '{"metric.*' > gpurun_out/${tag}_bench_2ranks_shared_gpu.json)
+cd /tmp && export TMPDIR=/tmp
+for mode in 1 0; do
+  rm -rf /tmp/prof$mode
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof$mode -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --pipeline $mode > /tmp/prof$mode.log 2>&1
+  DB=$(ls /tmp/prof$mode/*/*.db /tmp/prof$mode/*.db 2>/dev/null | head -1)
+  python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $DB 1 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_rocprof_kernel_stats_pipeline$mode.csv 2>> /tmp/prof$mode.log
+  grep -a -o '{"metric.*' /tmp/prof$mode.log | head -c 300 >> $GRAFT_REPO_ROOT/gpurun_out/${tag}_rocprof_kernel_stats_pipeline$mode.csv
+done
+bash $GRAFT_REPO_ROOT/tools/pmc_bench.sh > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_hbm_traffic.csv 2>&1
+cd $GRAFT_REPO_ROOT
+tail -4 gpurun_out/${tag}_pytest_gpu.log; cat gpurun_out/${tag}_smoke.log | tail -2; head -c 500 gpurun_out/${tag}_bench.json; echo; head -c 300 gpurun_out/${tag}_bench_2ranks_shared_gpu.json; echo; tail -12 gpurun_out/${tag}_pmc_hbm_traffic.csv
