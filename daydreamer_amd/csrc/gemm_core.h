@@ -923,6 +923,9 @@ void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps,
     if (v64 == 4) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 8, false, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
     if (v64 == 5) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 8, false, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
     if (v64 == 6) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 8, true, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
+    if (v64 == 7) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 32, 2, false, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
+    if (v64 == 8) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 32, 4, false, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
+    if (v64 == 9) { k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 32, 2, false, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm); return; }
 #endif
     k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false, DD_A2_64><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   } else {
