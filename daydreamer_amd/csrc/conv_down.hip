@@ -23,7 +23,13 @@ extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w,
     ConvDownA<float, true> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
     return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
   }
-  ConvDownA<float, false> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+  // few-channel float image (decoder output layer backward): patch rows of kw*Cb floats at
+  // 4-byte alignment -> the unaligned-row loader (mode 2) when a row holds at least four
+  // floats; the filter operand keeps its own fast path
+  const int mode = kwc >= 4 ? 2 : vec;
+  ConvDownA<float, false> al{(const float*)big, M, hs, ws_, hb, wb, Cb, kwc, 1.f, mode, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+  if (vb)
+    return run_mat<true, false>(al, MatRC<true>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
   return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
 }
 

@@ -23,7 +23,11 @@ extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* s
     ConvWgradA<float, true> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
     return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
   }
-  ConvWgradA<float, false> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, vec, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+  // few-channel float image: unaligned-row loader (mode 2), see dd_conv2d_s2_down
+  const int mode = kwc >= 4 ? 2 : vec;
+  ConvWgradA<float, false> al{(const float*)big, hs, ws_, hb, wb, Cb, kwc, M, 1.f, mode, FastDiv(hs * ws_), FastDiv(ws_), FastDiv(kwc)};
+  if (vb)
+    return run_mat<false, false>(al, MatRC<true>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
   return run_mat<false, false>(al, MatRC<false>{small, Cs, Cs, vb}, M, N, K, dw, Cs, nullptr, 1.f, beta, wsp, ws_bytes, st, "dd_conv2d_s2_wgrad");
 }
 

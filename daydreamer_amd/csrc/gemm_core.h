@@ -121,6 +121,14 @@ __device__ __forceinline__ void load4_elems(const unsigned char* p, float s, flo
   v[2] = (float)((w >> 16) & 255u) * s; v[3] = (float)(w >> 24) * s;
 }
 
+// 16 bytes at 4-byte alignment (a patch row of a 3-channel float image starts on any float)
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void load4_unaligned(const float* p, float v[4]) {
+  const f32x4_u t = *reinterpret_cast<const f32x4_u*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4_unaligned(const unsigned char*, float v[4]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+
 __device__ __forceinline__ float cvt(float x, float) { return x; }
 __device__ __forceinline__ float cvt(unsigned char x, float s) { return (float)x * s; }
 
@@ -139,6 +147,34 @@ struct ConvDownA {
       d_kwc.divmod(kk, ky, o);
       load4_elems(big + (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o, scale, v);
       if (!(FULL || k < kend)) v[0] = v[1] = v[2] = v[3] = 0.f;
+      return;
+    }
+    if (vec == 2) {
+      // float image whose patch row (kw*Cb floats) is not a multiple of four (3 channels, k 6):
+      // the four k of a chunk are contiguous inside one patch row or straddle two rows - two
+      // 16-byte loads at 4-byte alignment (this row at o, the next row at o - kwc) and a
+      // per-element select, instead of four scalar loads with their own index arithmetic
+      const int rr = min(r, npix - 1), kk = min(k, kend - 1);
+      int n, rem, sy, sx, ky, o;
+      d_hw.divmod(rr, n, rem);
+      d_w.divmod(rem, sy, sx);
+      d_kwc.divmod(kk, ky, o);
+      const T* row0 = big + (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb;
+      const int ky1 = min(ky + 1, (kend - 1) / kwc);       // stays inside the kernel window
+      const T* row1 = big + (((long)n * hb + 2 * sy + ky1) * wb + 2 * sx) * Cb;
+      // both loads stay inside their patch rows (no read past the tensor's last pixel)
+      float a[4], b[4];
+      const int oa = min(o, kwc - 4);
+      load4_unaligned(row0 + oa, a);
+      load4_unaligned(row1, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ia = o + j - oa, ib = o + j - kwc;
+        const float xa = ia == 0 ? a[0] : (ia == 1 ? a[1] : (ia == 2 ? a[2] : a[3]));
+        const float xb = ib <= 0 ? b[0] : (ib == 1 ? b[1] : (ib == 2 ? b[2] : b[3]));
+        const float x = (o + j < kwc) ? xa : xb;
+        v[j] = (r < npix && k + j < kend) ? x * scale : 0.f;
+      }
       return;
     }
     if (r >= npix) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
@@ -294,6 +330,29 @@ struct ConvWgradA {
       d_kwc.divmod(rr, ky, o);
       load4_elems(big + (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb + o, scale, v);
       if (!(FULL || k < kend)) v[0] = v[1] = v[2] = v[3] = 0.f;
+      return;
+    }
+    if (vec == 2) {  // float image, patch row not a multiple of four floats: see ConvDownA
+      const int kk = min(k, kend - 1), rr = min(r, R - 1);
+      int n, rem, sy, sx, ky, o;
+      d_hw.divmod(kk, n, rem);
+      d_w.divmod(rem, sy, sx);
+      d_kwc.divmod(rr, ky, o);
+      const T* row0 = big + (((long)n * hb + 2 * sy + ky) * wb + 2 * sx) * Cb;
+      const int ky1 = min(ky + 1, (R - 1) / kwc);
+      const T* row1 = big + (((long)n * hb + 2 * sy + ky1) * wb + 2 * sx) * Cb;
+      float a[4], b[4];
+      const int oa = min(o, kwc - 4);
+      load4_unaligned(row0 + oa, a);
+      load4_unaligned(row1, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ia = o + j - oa, ib = o + j - kwc;
+        const float xa = ia == 0 ? a[0] : (ia == 1 ? a[1] : (ia == 2 ? a[2] : a[3]));
+        const float xb = ib <= 0 ? b[0] : (ib == 1 ? b[1] : (ib == 2 ? b[2] : b[3]));
+        const float x = (o + j < kwc) ? xa : xb;
+        v[j] = (k < kend && r + j < R) ? x * scale : 0.f;
+      }
       return;
     }
     if (k >= kend) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }

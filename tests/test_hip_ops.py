@@ -130,7 +130,8 @@ CONVS = [  # n, hb, Cb, hs, Cs, k, u8
     (3, 64, 3, 31, 16, 4, True), (3, 31, 16, 14, 32, 4, False),
     (2, 14, 32, 6, 64, 4, False), (5, 6, 64, 2, 128, 4, False),
     (4, 5, 64, 1, 320, 5, False), (3, 13, 32, 5, 64, 5, False),
-    (2, 30, 16, 13, 32, 6, False), (2, 64, 3, 30, 16, 6, False)]
+    (2, 30, 16, 13, 32, 6, False), (2, 64, 3, 30, 16, 6, False),
+    (2, 128, 6, 64, 32, 2, False), (1, 64, 3, 31, 16, 4, False), (2, 20, 5, 8, 12, 5, False)]
 
 
 @pytest.mark.parametrize('n,hb,Cb,hs,Cs,k,u8', CONVS)
