@@ -9,26 +9,12 @@
 // (LW = next power of two >= C); all reductions are butterfly shuffles inside
 // the sub-wave.  The draw is inverse-CDF: idx = #{c < C-1 : cdf_c <= u*cdf_{C-1}}
 // with a Kogge-Stone inclusive scan over the (unimixed) probabilities.
-#include "dd_common.h"
-#include "sampler_core.h"
+#include "latent_core.h"
 #include <math.h>
 #include <type_traits>
 #include "../../include/daydreamer_hip.h"
 
 namespace {
-
-template <int LW>
-__device__ __forceinline__ float sub_sum(float v) {
-#pragma unroll
-  for (int o = LW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-template <int LW>
-__device__ __forceinline__ float sub_max(float v) {
-#pragma unroll
-  for (int o = LW / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 
 // mode: 0 sample with u, 1 argmax (OneHotCategorical.mode()).
 template <int LW>
@@ -57,32 +43,10 @@ k_stats_fwd(float* __restrict__ x, long ldx, const float* __restrict__ u, long l
         xv = *xp;
       }
     }
-    // (the arithmetic below is sampler_core.h, shared with dd_onehot_sample_host)
-    float m = sub_max<LW>(xv);
-    float e = ok ? dd_exp_det(xv - m) : 0.f;
-    float s = sub_sum<LW>(e);
-    float pm = ok ? dd_unimix_prob(e, s, unimix, C) : 0.f;
-    float lg = unimix > 0.f ? logf(pm) : (xv - m) - logf(s);
+    float lg;
     int idx;
-    if (mode == 1) {
-      float best = sub_max<LW>(ok ? pm : -1.f);
-      unsigned long long b = __ballot(ok && pm == best);
-      if constexpr (LW < 64) b = (b >> (sub * LW)) & ((1ull << LW) - 1ull);
-      idx = __ffsll((long long)b) - 1;
-    } else {
-      // inclusive Kogge-Stone scan inside the sub-wave
-      float cdf = pm;
-#pragma unroll
-      for (int o = 1; o < LW; o <<= 1) {
-        float t = __shfl_up(cdf, o, LW);
-        if (c >= o) cdf += t;
-      }
-      float tot = __shfl(cdf, C - 1, LW);
-      float uu = live ? u[row * ldu + g] : 0.f;
-      float thr = dd_draw_threshold(uu, tot);
-      float flag = (ok && c < C - 1 && cdf <= thr) ? 1.f : 0.f;
-      idx = (int)sub_sum<LW>(flag);
-    }
+    const float uu = (mode != 1 && live) ? u[row * ldu + g] : 0.f;
+    stats_item<LW>(xv, ok, c, sub, C, unimix, mode, uu, lg, idx);
     if (ok) {
       logit[row * ldl + (long)g * C + c] = lg;
       stoch[row * lds + (long)g * C + c] = (c == idx) ? 1.f : 0.f;

@@ -40,6 +40,9 @@ _SIGS = {
     'dd_col_sum': [c_p, c_l, c_p, c_f, c_l, c_i, c_p, c_z, c_p],
     'dd_gru_cell_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_i, c_f, c_p],
     'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    'dd_observe_scan_supported': [c_i] * 6,
+    'dd_scan_wprep': [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
+    'dd_observe_scan_fwd': [c_i] * 8 + [c_f] + [c_p] * 30,
     'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_f, c_p, c_p],
     'dd_onehot_sample_host': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i],
     'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
@@ -324,6 +327,30 @@ class HipOps:
         hp, ldh, dzp, lddz, dhp, lddh, dyp, lddy, zxp, ldzx, U, rows, D,
         self.stream),
         'dd_gru_cell_bwd')
+
+  # ---- fused observe scan ----------------------------------------------------------
+
+  def observe_scan_supported(self, B, D, U, G, C, A):
+    return bool(self.lib.dd_observe_scan_supported(B, D, U, G, C, A))
+
+  def scan_wprep(self, W, planes, Kp):
+    """Weight cache of the fused scan: W [K, N] fp32 -> bf16 planes [3, N, Kp]."""
+    K, N = W.shape
+    assert W.stride(1) == 1 and planes.dtype == torch.int16 and planes.numel() == 3 * N * Kp
+    self._check(self.lib.dd_scan_wprep(W.data_ptr(), W.stride(0), K, N, Kp, planes.data_ptr(),
+                                       self.stream), 'dd_scan_wprep')
+
+  def observe_scan_fwd(self, B, T, D, U, G, C, A, use_carry, unimix, first, carry, init_deter,
+                       init_stoch, u_post, wts, vecs, bufs, sync2):
+    """wts: 4 plane caches; vecs: g1, b1, gg, bg, g3, b3, bias4; bufs: xin, z1, st1, gin, z3, gst,
+    post, zo, xo, st3, xq, post_logit (all contiguous, rows b*T + t)."""
+    for t in bufs:
+      assert t.is_contiguous()
+    self._check(self.lib.dd_observe_scan_fwd(
+        B, T, D, U, G, C, A, int(use_carry), unimix, first.data_ptr(), _ptr(carry),
+        init_deter.data_ptr(), init_stoch.data_ptr(), u_post.data_ptr(),
+        *[w.data_ptr() for w in wts], *[v.data_ptr() for v in vecs],
+        *[t.data_ptr() for t in bufs], sync2.data_ptr(), self.stream), 'dd_observe_scan_fwd')
 
   # ---- categorical latent -----------------------------------------------------
 

@@ -360,6 +360,18 @@ class Learner:
     self.a_init_stats = Act(self, 1, S, False, grads=False)
     # carry state between train calls
     b['carry'] = z(B, F)
+    # fused observe scan (csrc/scan.hip): transposed bf16 weight planes + barrier words
+    self.fused_scan = (bool(self.cfg.get('hip', {}).get('fused_scan', True)) and
+                       self.dtype == torch.float32 and hasattr(self.ops, 'observe_scan_fwd') and
+                       self.ops.observe_scan_supported(B, D, U, G, self.C, A))
+    if self.fused_scan:
+      xkp = (S + A + 31) // 32 * 32
+      i16 = lambda n: torch.zeros(n, dtype=torch.int16, device=self.device)
+      self.scan_w = [(self.P['img_in'].W, i16(3 * U * xkp), xkp),
+                     (self.P['gru'].W, i16(3 * 3 * D * (D + U)), D + U),
+                     (self.P['obs_out_h'].W, i16(3 * U * D), D),
+                     (self.P['obs_stats'].W, i16(3 * S * U), U)]
+      self.scan_sync = torch.zeros(2, dtype=torch.int32, device=self.device)
     # ---- heads on the posterior
     self.acts_wm = {k: self._head_acts(k, N) for k in ('reward', 'cont')}
     if s.dec_mlp_keys:
@@ -743,9 +755,32 @@ class Learner:
     self.ops.copy2d(b['init_deter'].expand(self.B, D), b['carry'][:, :D])
     self.ops.copy2d(b['init_stoch'].expand(self.B, self.S), b['carry'][:, D:])
 
+  def observe_scan_fused(self, use_carry):
+    """The T obs_steps as one persistent launch (dd_observe_scan_fwd): same buffers, same
+    values up to the summation order of the small contractions."""
+    ops, b, P = self.ops, self.b, self.P
+    for W, planes, kp in self.scan_w:   # the weights changed in the last optimizer step
+      ops.scan_wprep(W, planes, kp)
+    g = P['gru_h']
+    ops.observe_scan_fwd(
+        self.B, self.T, self.D, self.U, self.G, self.C, self.A, use_carry, self.unimix,
+        b['first'], b['carry'] if use_carry else None, b['init_deter'], b['init_stoch'],
+        b['u_post'], [w[1] for w in self.scan_w],
+        [P['img_in'].gamma, P['img_in'].beta, g.gamma, g.beta, P['obs_out_h'].gamma,
+         P['obs_out_h'].beta, P['obs_stats'].bias],
+        [b['xin'], self.a_img_in.z, self.a_img_in.stats, b['gin'], b['z3'], b['gstats'], b['post'],
+         self.a_obs_out.z, self.a_obs_out.out, self.a_obs_out.stats, self.a_obs_stats.z,
+         b['post_logit']], self.scan_sync)
+
   def observe_fwd(self, use_carry=True):
     ops, b = self.ops, self.b
     B, T, D, S, F = self.B, self.T, self.D, self.S, self.F
+    if self.fused_scan:
+      self.observe_scan_fused(use_carry)
+      xs = self.prior_fwd(b['post'][:, :D], self.a_img_out, self.a_img_stats)
+      ops.stats_fwd(xs, b['u_prior'].view(self.N, self.G), b['prior_logit'],
+                    b['prior_stoch'], self.G, self.C, self.unimix, 0)
+      return
     bt = lambda t_: (lambda buf: buf.view(B, T, -1)[:, t_])
     first = b['first'].view(B, T)
     post = b['post'].view(B, T, F)

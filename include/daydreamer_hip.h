@@ -125,6 +125,33 @@ int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
                     float* dh, long lddh, float* dy3, long lddy,
                     float* zx, long ldzx, int U, int rows, int D, void* stream);
 
+/* ---- fused observe scan ------------------------------------------------------- */
+
+/* RSSM.observe forward (nets.py:66-76, obs_step :99-117, _gru :149-160) for all T steps in ONE
+ * persistent launch (csrc/scan.hip): per step four phases separated by grid barriers -
+ * img_in, GRU, obs_out (+ the hoisted embed part already in zo), obs_stats + the latent draw -
+ * each a small-M MFMA contraction whose operand is built from the RAW output rows of the
+ * previous phase (the consumer applies LayerNorm / ELU / GRU gates).  Writes every buffer the
+ * unfused launch sequence writes (same layouts, rows b*T + t): xin[:, :S] (masked stoch),
+ * z1 / st1 / gin (= [hprev | x1]), z3 / gst, post (= [deter | stoch]), zo / xo / st3, xq,
+ * post_logit.  The draw is the shared sampler (latent_core.h): same indices as
+ * dd_stats_sample_fwd / dd_onehot_sample_host given the same statistics.
+ * wt1..wt4: weight caches from dd_scan_wprep for img_in [U][pad32(S+A)], gru_out [3D][D+U],
+ * obs_out[:D] [U][D], obs_stats [S][U].  sync2: two zero-initialisable device words (barrier
+ * counter, error word - non-zero after the launch if a bounded spin timed out).
+ * dd_observe_scan_supported: B <= 64, D and U multiples of 32, classes in {16, 32, 64}. */
+int dd_observe_scan_supported(int B, int D, int U, int G, int C, int A);
+int dd_scan_wprep(const float* W, long ld, int K, int N, int Kp, void* planes, void* stream);
+int dd_observe_scan_fwd(
+    int B, int T, int D, int U, int G, int C, int A, int use_carry, float unimix,
+    const float* first, const float* carry, const float* init_deter, const float* init_stoch,
+    const float* u_post,
+    const void* wt1, const void* wt2, const void* wt3, const void* wt4,
+    const float* g1, const float* b1, const float* gg, const float* bg, const float* g3,
+    const float* b3, const float* bias4,
+    float* xin, float* z1, float* st1, float* gin, float* z3, float* gst, float* post, float* zo,
+    float* xo, float* st3, float* xq, float* post_logit, unsigned* sync2, void* stream);
+
 /* ---- categorical latent ------------------------------------------------------ */
 
 /* logit = log((1-unimix)*softmax(x)+unimix/C); stoch = one_hot(draw).

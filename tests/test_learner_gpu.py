@@ -130,6 +130,65 @@ def test_e2e_multicam_128(hip):
   run(hip, cfg, 1, image=128, cameras=2, vector=5, action=3, terminals=0.1)
 
 
+def test_fused_observe_scan_equals_launch_sequence(hip):
+  """csrc/scan.hip: RSSM.observe forward as ONE persistent launch (grid barriers between the
+  four layers of a step) against the per-layer launch sequence on the same inputs, at the full
+  configs[1] size and on a ragged batch (B = 21: partly filled row block): every buffer the
+  backward pass reads must agree to float reassociation, the drawn latents exactly - except in
+  sequences where a draw sat on a CDF edge and flipped (the two paths sum the small contractions
+  in different orders); those are counted and must be rare.  The barrier's error word stays 0."""
+  for (B, T, first_mid) in ((50, 50, False), (21, 7, True)):
+    cfg = helpers.make_config(('a1_vision',), batch_size=B, replay_chunk=T)
+    plain, sp, shapes, params, data, _, _ = helpers.make_problem(
+        cfg, image=64, vector=16, action=16, terminals=0.02, smooth=True)
+    if first_mid:
+      data['is_first'][3, 4] = True
+      data['is_first'][20, 2] = True
+    Ls = []
+    for fused in (True, False):
+      plain2 = dict(plain, hip=dict(plain.get('hip', {}), fused_scan=fused))
+      sp2 = type(sp)(**{**sp.__dict__, 'cfg': plain2})
+      L = learner_mod.Learner(sp2, hip, 'cuda:0', B, T, params=params, noise_seed=5)
+      assert L.fused_scan == fused
+      L.upload(data)
+      L.reset_carry()
+      L.phase_prep()
+      L.encoder_fwd()
+      L.initial_fwd()
+      L.observe_fwd(True)
+      torch.cuda.synchronize()
+      Ls.append(L)
+    A, Bq = Ls
+    assert int(A.scan_sync[1]) == 0, 'a grid-barrier spin timed out'
+    G, C, D = A.G, A.C, A.D
+    ia = A.b['post'][:, D:].view(B, T, G, C).argmax(-1)
+    ib = Bq.b['post'][:, D:].view(B, T, G, C).argmax(-1)
+    assert torch.equal(A.b['post'][:, D:].sum(-1), torch.full((B * T,), float(G), device='cuda'))
+    same = (ia == ib).all(-1).all(-1)          # sequences with identical draws throughout
+    print(f'fused scan B{B} T{T}: {int((~same).sum())} of {B} sequences contain a flipped draw')
+    assert int((~same).sum()) <= max(1, B // 25)
+    rows = same.repeat_interleave(T)
+    def cmp(x, y, what, tol=2e-5):
+      x, y = x[rows].double(), y[rows].double()
+      err = float((x - y).abs().max() / (y.abs().max() + 1e-30))
+      assert err < tol, (what, err)
+    cmp(A.b['post'], Bq.b['post'], 'post')
+    cmp(A.b['post_logit'], Bq.b['post_logit'], 'post_logit')
+    cmp(A.b['xin'], Bq.b['xin'], 'xin')
+    cmp(A.b['gin'], Bq.b['gin'], 'gin')
+    cmp(A.b['z3'], Bq.b['z3'], 'z3')
+    cmp(A.b['gstats'], Bq.b['gstats'], 'gstats')
+    cmp(A.a_img_in.z, Bq.a_img_in.z, 'z1')
+    cmp(A.a_img_in.stats, Bq.a_img_in.stats, 'st1')
+    cmp(A.a_obs_out.z, Bq.a_obs_out.z, 'zo')
+    cmp(A.a_obs_out.out, Bq.a_obs_out.out, 'xo')
+    cmp(A.a_obs_out.stats, Bq.a_obs_out.stats, 'st3')
+    cmp(A.a_obs_stats.z, Bq.a_obs_stats.z, 'xq')
+    cmp(A.b['prior_logit'], Bq.b['prior_logit'], 'prior_logit')
+    del Ls, A, Bq
+    torch.cuda.empty_cache()
+
+
 def test_full_size_properties(hip):
   """BASELINE configs[1] at full size (batch 50 x seq 50 x horizon 15): the oracle
   is too slow here, so check size-independent properties instead: finite losses,
