@@ -93,6 +93,12 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&pl)[3]) {
   pl[2] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]), pack_hi(l[4], l[5]), pack_hi(l[6], l[7])));
 }
 
+// eight consecutive floats (32-byte aligned address) as two 16-byte loads
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+}
+
 __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -179,7 +185,6 @@ k_observe_scan_fwd(ScanArgs a) {
   __shared__ float sh_stats[16][2];
   __shared__ long sh_row[16];      // buffer row b*T + t of the block's 16 rows (clamped)
   __shared__ long sh_prev[16];     // row of step t-1
-  __shared__ float sh_first[16];
   const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int mblk = wg & 3, nstr = wg >> 2, NSTR = NWG / 4;
   const int D = a.D, U = a.U, S = a.S, C = a.C, F = a.D + a.S, T = a.T;
@@ -188,46 +193,52 @@ k_observe_scan_fwd(ScanArgs a) {
   const bool olive = ob < a.B;
   const int ab = min(mblk * 16 + (lane & 15), a.B - 1);               // batch row of the A operand
   unsigned gen = 0;
+  if (a.use_carry & 2) {   // measurement aid: the barriers alone (4 per step), no work
+    for (int i = 0; i < 4 * T; ++i) grid_barrier(a.ctr, ++gen * NWG);
+    return;
+  }
   for (int t = 0; t < T; ++t) {
     if (tid < 16) {
       const int b = min(mblk * 16 + tid, a.B - 1);
       sh_row[tid] = (long)b * T + t;
       sh_prev[tid] = (long)b * T + t - 1;
-      sh_first[tid] = a.first[(long)b * T + t];
     }
     __syncthreads();
     const long arow = (long)ab * T + t, aprev = arow - 1;
     const float af = a.first[arow];
     const long oidx = (long)ob * T + t;
     // previous posterior of the A-operand row: carry at t = 0
-    const float* pprev = t > 0 ? a.post + aprev * F : (a.use_carry ? a.carry + (long)ab * F : nullptr);
+    const float* pprev = t > 0 ? a.post + aprev * F : ((a.use_carry & 1) ? a.carry + (long)ab * F : nullptr);
 
     // ---------------- P1: z1 = [mask(stoch) | masked action] @ W_img_in
     {
+      // (S is a multiple of 16: an octet lies entirely in the stoch or in the action part)
       auto afn = [&](int k, float (&v)[8]) {
+        if (k < S) {
+          float pv[8], iv[8];
+          ld8(a.init_stoch + k, iv);
+          if (pprev) ld8(pprev + D + k, pv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int kk = k + j;
-          float x = 0.f;
-          if (kk < S) {
-            const float pv = pprev ? pprev[D + kk] : 0.f;
-            x = pv * (1.f - af) + a.init_stoch[kk] * af;
-          } else if (kk < a.XK) {
-            x = a.xin[arow * a.XK + kk];
-          }
-          v[j] = x;
+          for (int j = 0; j < 8; ++j) v[j] = (pprev ? pv[j] : 0.f) * (1.f - af) + iv[j] * af;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (k + j < a.XK) ? a.xin[arow * a.XK + k + j] : 0.f;
         }
       };
-      if (nstr == 0) {   // side output: the masked stoch input (bulk weight gradient reads xin)
-        for (int e = tid; e < 16 * S; e += 256) {
-          const int r = e / S, kk = e - r * S;
-          const int b = mblk * 16 + r;
-          if (b < a.B) {
-            const long row = (long)b * T + t;
-            const float f = a.first[row];
-            const float* pp = t > 0 ? a.post + (row - 1) * F : (a.use_carry ? a.carry + (long)b * F : nullptr);
-            a.xin[row * a.XK + kk] = (pp ? pp[D + kk] : 0.f) * (1.f - f) + a.init_stoch[kk] * f;
-          }
+      // side output: the masked stoch input (the bulk weight gradient reads xin); the 16
+      // workgroups of a row block share it, four floats per thread and trip
+      for (int e4 = tid + 256 * nstr; e4 < 16 * S / 4; e4 += 256 * NSTR) {
+        const int r = e4 / (S / 4), kk = (e4 - r * (S / 4)) * 4;
+        const int b = mblk * 16 + r;
+        if (b < a.B) {
+          const long row = (long)b * T + t;
+          const float f = a.first[row];
+          const float* pp = t > 0 ? a.post + (row - 1) * F : ((a.use_carry & 1) ? a.carry + (long)b * F : nullptr);
+          const float4 iv = *reinterpret_cast<const float4*>(a.init_stoch + kk);
+          const float4 pv = pp ? *reinterpret_cast<const float4*>(pp + D + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(a.xin + row * a.XK + kk) =
+              make_float4(pv.x * (1.f - f) + iv.x * f, pv.y * (1.f - f) + iv.y * f,
+                          pv.z * (1.f - f) + iv.z * f, pv.w * (1.f - f) + iv.w * f);
         }
       }
       for (int nt = nstr; nt < U / 16; nt += NSTR) {
@@ -243,40 +254,41 @@ k_observe_scan_fwd(ScanArgs a) {
       __syncthreads();
       const float mean = sh_stats[lane & 15][0], rstd = sh_stats[lane & 15][1];
       auto afn = [&](int k, float (&v)[8]) {
+        if (k < D) {
+          float pv[8], iv[8];
+          ld8(a.init_deter + k, iv);
+          if (pprev) ld8(pprev + k, pv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int kk = k + j;
-          if (kk < D) {
-            const float pv = pprev ? pprev[kk] : 0.f;
-            v[j] = pv * (1.f - af) + a.init_deter[kk] * af;
-          } else {
-            const int c = kk - D;
-            v[j] = elu_((a.z1[arow * U + c] - mean) * rstd * a.g1[c] + a.b1[c]);
-          }
+          for (int j = 0; j < 8; ++j) v[j] = (pprev ? pv[j] : 0.f) * (1.f - af) + iv[j] * af;
+        } else {
+          const int c = k - D;
+          float zz[8], gm[8], bt[8];
+          ld8(a.z1 + arow * U + c, zz); ld8(a.g1 + c, gm); ld8(a.b1 + c, bt);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = elu_((zz[j] - mean) * rstd * gm[j] + bt[j]);
         }
       };
-      if (nstr == 0) {   // side outputs: hprev, x1, LayerNorm statistics
-        for (int e = tid; e < 16 * (D + U); e += 256) {
-          const int r = e / (D + U), kk = e - r * (D + U);
-          const int b = mblk * 16 + r;
-          if (b < a.B) {
-            const long row = (long)b * T + t;
-            float x;
-            if (kk < D) {
-              const float f = a.first[row];
-              const float* pp = t > 0 ? a.post + (row - 1) * F : (a.use_carry ? a.carry + (long)b * F : nullptr);
-              x = (pp ? pp[kk] : 0.f) * (1.f - f) + a.init_deter[kk] * f;
-            } else {
-              const int c = kk - D;
-              x = elu_((a.z1[row * U + c] - sh_stats[r][0]) * sh_stats[r][1] * a.g1[c] + a.b1[c]);
-            }
-            a.gin[row * (D + U) + kk] = x;
+      // side outputs: hprev, x1 (shared by the 16 workgroups of the row block), statistics
+      for (int e = tid + 256 * nstr; e < 16 * (D + U); e += 256 * NSTR) {
+        const int r = e / (D + U), kk = e - r * (D + U);
+        const int b = mblk * 16 + r;
+        if (b < a.B) {
+          const long row = (long)b * T + t;
+          float x;
+          if (kk < D) {
+            const float f = a.first[row];
+            const float* pp = t > 0 ? a.post + (row - 1) * F : ((a.use_carry & 1) ? a.carry + (long)b * F : nullptr);
+            x = (pp ? pp[kk] : 0.f) * (1.f - f) + a.init_deter[kk] * f;
+          } else {
+            const int c = kk - D;
+            x = elu_((a.z1[row * U + c] - sh_stats[r][0]) * sh_stats[r][1] * a.g1[c] + a.b1[c]);
           }
+          a.gin[row * (D + U) + kk] = x;
         }
-        if (tid < 16 && mblk * 16 + tid < a.B) {
-          a.st1[sh_row[tid] * 2] = sh_stats[tid][0];
-          a.st1[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
-        }
+      }
+      if (nstr == 0 && tid < 16 && mblk * 16 + tid < a.B) {
+        a.st1[sh_row[tid] * 2] = sh_stats[tid][0];
+        a.st1[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
       }
       for (int nt = nstr; nt < 3 * D / 16; nt += NSTR) {
         const float r = tile_gemm(afn, a.wt2, 3 * D, D + U, nt * 16, red);
@@ -289,29 +301,39 @@ k_observe_scan_fwd(ScanArgs a) {
     {
       block_stats(a.z3, 3 * D, 3 * D, sh_row, sh_stats);
       __syncthreads();
+      auto gate = [&](float zr_, float zc_, float zu_, float gr, float gc, float gu, float br,
+                      float bc, float bu, float hp, float mean, float rstd) {
+        const float yr = (zr_ - mean) * rstd * gr + br;
+        const float yc = (zc_ - mean) * rstd * gc + bc;
+        const float yu = (zu_ - mean) * rstd * gu + bu;
+        const float rr = sigmoidf_(yr), cand = tanhf(rr * yc), uu = sigmoidf_(yu - 1.f);
+        return uu * cand + (1.f - uu) * hp;
+      };
       auto gru = [&](long row, int j, float mean, float rstd) {
         const float* zr = a.z3 + row * 3 * D;
-        const float yr = (zr[j] - mean) * rstd * a.gg[j] + a.bg[j];
-        const float yc = (zr[D + j] - mean) * rstd * a.gg[D + j] + a.bg[D + j];
-        const float yu = (zr[2 * D + j] - mean) * rstd * a.gg[2 * D + j] + a.bg[2 * D + j];
-        const float rr = sigmoidf_(yr), cand = tanhf(rr * yc), uu = sigmoidf_(yu - 1.f);
-        const float hp = a.gin[row * (D + U) + j];
-        return uu * cand + (1.f - uu) * hp;
+        return gate(zr[j], zr[D + j], zr[2 * D + j], a.gg[j], a.gg[D + j], a.gg[2 * D + j], a.bg[j],
+                    a.bg[D + j], a.bg[2 * D + j], a.gin[row * (D + U) + j], mean, rstd);
       };
       const float mean = sh_stats[lane & 15][0], rstd = sh_stats[lane & 15][1];
       auto afn = [&](int k, float (&v)[8]) {
+        float z0[8], z1_[8], z2[8], g0[8], g1_[8], g2[8], b0[8], b1_[8], b2[8], hp[8];
+        const float* zr = a.z3 + arow * 3 * D;
+        ld8(zr + k, z0); ld8(zr + D + k, z1_); ld8(zr + 2 * D + k, z2);
+        ld8(a.gg + k, g0); ld8(a.gg + D + k, g1_); ld8(a.gg + 2 * D + k, g2);
+        ld8(a.bg + k, b0); ld8(a.bg + D + k, b1_); ld8(a.bg + 2 * D + k, b2);
+        ld8(a.gin + arow * (D + U) + k, hp);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gru(arow, k + j, mean, rstd);
+        for (int j = 0; j < 8; ++j)
+          v[j] = gate(z0[j], z1_[j], z2[j], g0[j], g1_[j], g2[j], b0[j], b1_[j], b2[j], hp[j], mean, rstd);
       };
-      if (nstr == 0) {   // side outputs: deter_t, GRU LayerNorm statistics
-        for (int e = tid; e < 16 * D; e += 256) {
-          const int r = e / D, j = e - r * D;
-          if (mblk * 16 + r < a.B) a.post[sh_row[r] * F + j] = gru(sh_row[r], j, sh_stats[r][0], sh_stats[r][1]);
-        }
-        if (tid < 16 && mblk * 16 + tid < a.B) {
-          a.gst[sh_row[tid] * 2] = sh_stats[tid][0];
-          a.gst[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
-        }
+      // side outputs: deter_t (shared by the row block's workgroups), GRU statistics
+      for (int e = tid + 256 * nstr; e < 16 * D; e += 256 * NSTR) {
+        const int r = e / D, j = e - r * D;
+        if (mblk * 16 + r < a.B) a.post[sh_row[r] * F + j] = gru(sh_row[r], j, sh_stats[r][0], sh_stats[r][1]);
+      }
+      if (nstr == 0 && tid < 16 && mblk * 16 + tid < a.B) {
+        a.gst[sh_row[tid] * 2] = sh_stats[tid][0];
+        a.gst[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
       }
       for (int nt = nstr; nt < U / 16; nt += NSTR) {
         const float r = tile_gemm(afn, a.wt3, U, D, nt * 16, red);
@@ -326,22 +348,20 @@ k_observe_scan_fwd(ScanArgs a) {
       __syncthreads();
       const float mean = sh_stats[lane & 15][0], rstd = sh_stats[lane & 15][1];
       auto afn = [&](int k, float (&v)[8]) {
+        float zz[8], gm[8], bt[8];
+        ld8(a.zo + arow * U + k, zz); ld8(a.g3 + k, gm); ld8(a.b3 + k, bt);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = k + j;
-          v[j] = elu_((a.zo[arow * U + c] - mean) * rstd * a.g3[c] + a.b3[c]);
-        }
+        for (int j = 0; j < 8; ++j) v[j] = elu_((zz[j] - mean) * rstd * gm[j] + bt[j]);
       };
-      if (nstr == 0) {   // side outputs: xo, LayerNorm statistics
-        for (int e = tid; e < 16 * U; e += 256) {
-          const int r = e / U, c = e - r * U;
-          if (mblk * 16 + r < a.B)
-            a.xo[sh_row[r] * U + c] = elu_((a.zo[sh_row[r] * U + c] - sh_stats[r][0]) * sh_stats[r][1] * a.g3[c] + a.b3[c]);
-        }
-        if (tid < 16 && mblk * 16 + tid < a.B) {
-          a.st3[sh_row[tid] * 2] = sh_stats[tid][0];
-          a.st3[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
-        }
+      // side outputs: xo (shared by the row block's workgroups), LayerNorm statistics
+      for (int e = tid + 256 * nstr; e < 16 * U; e += 256 * NSTR) {
+        const int r = e / U, c = e - r * U;
+        if (mblk * 16 + r < a.B)
+          a.xo[sh_row[r] * U + c] = elu_((a.zo[sh_row[r] * U + c] - sh_stats[r][0]) * sh_stats[r][1] * a.g3[c] + a.b3[c]);
+      }
+      if (nstr == 0 && tid < 16 && mblk * 16 + tid < a.B) {
+        a.st3[sh_row[tid] * 2] = sh_stats[tid][0];
+        a.st3[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
       }
       // units of whole latent groups (C / 16 column tiles each), so that the draw of a
       // (row, group) only reads statistics this workgroup wrote
@@ -428,7 +448,7 @@ extern "C" int dd_observe_scan_fwd(
   ScanArgs a;
   a.B = B; a.T = T; a.D = D; a.U = U; a.G = G; a.C = C; a.A = A; a.S = G * C;
   a.XK = a.S + A; a.XKp = (a.XK + 31) / 32 * 32;
-  a.use_carry = use_carry && carry != nullptr; a.unimix = unimix;
+  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 2); a.unimix = unimix;
   a.first = first; a.carry = carry; a.init_deter = init_deter; a.init_stoch = init_stoch;
   a.u_post = u_post;
   a.wt1 = (const unsigned short*)wt1; a.wt2 = (const unsigned short*)wt2;

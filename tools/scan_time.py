@@ -1,0 +1,59 @@
+"""Time the fused observe scan (dd_observe_scan_fwd) at BASELINE configs[1]: the full kernel, its
+grid barriers alone (dry mode: 4 barriers per step, no work), the weight-plane preparation,
+and the per-layer launch sequence it replaces.  python tools/scan_time.py"""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import torch
+import helpers
+from daydreamer_amd import learner as LM, hipops, synthetic, config as config_mod, spec as spec_mod
+
+cfg = helpers.make_config(('a1_vision',))
+plain = config_mod.to_plain(cfg)
+obs, act = synthetic.config_spaces('a1_vision')
+shapes = {k: v.shape for k, v in obs.items()}
+sp = spec_mod.build_spec(plain, shapes, 16, False)
+B, T = plain['batch_size'], plain['replay_chunk']
+data = synthetic.make_batch(obs, act, B, T, seed=0)
+ops = hipops.HipOps('cuda:0')
+L = LM.Learner(sp, ops, 'cuda:0', B, T, params=spec_mod.init_params(sp, 0))
+L.upload(data)
+L.train_step_device(False)
+torch.cuda.synchronize()
+
+
+def timed(label, fn, reps=10):
+  for _ in range(2):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  print(f'{label:44s} {e0.elapsed_time(e1) / reps:8.3f} ms', flush=True)
+
+
+def scan(flag):
+  b, P = L.b, L.P
+  g = P['gru_h']
+  ops.observe_scan_fwd(
+      L.B, L.T, L.D, L.U, L.G, L.C, L.A, flag, L.unimix, b['first'], b['carry'], b['init_deter'],
+      b['init_stoch'], b['u_post'], [w[1] for w in L.scan_w],
+      [P['img_in'].gamma, P['img_in'].beta, g.gamma, g.beta, P['obs_out_h'].gamma,
+       P['obs_out_h'].beta, P['obs_stats'].bias],
+      [b['xin'], L.a_img_in.z, L.a_img_in.stats, b['gin'], b['z3'], b['gstats'], b['post'],
+       L.a_obs_out.z, L.a_obs_out.out, L.a_obs_out.stats, L.a_obs_stats.z, b['post_logit']], L.scan_sync)
+
+
+timed('weight planes (4 x dd_scan_wprep)', lambda: [ops.scan_wprep(W, p, k) for W, p, k in L.scan_w])
+timed('fused scan, full (T = %d steps)' % T, lambda: scan(1))
+timed('fused scan, barriers only (4 per step)', lambda: scan(3))
+print('error word', int(L.scan_sync[1]))
+L.fused_scan = False
+from daydreamer_amd import graphs
+plan = graphs.GraphPlan('cuda:0')
+keep, L.plan = L.plan, plan
+plan.capture(lambda: L.observe_fwd(True))
+L.plan = keep
+timed('launch sequence (graph replay, incl. bulk prior)', plan.replay)
