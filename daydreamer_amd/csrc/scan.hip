@@ -32,12 +32,13 @@
 // out, never a hang).  NWG <= CU count, one workgroup per CU, so all workgroups are resident.
 #include "latent_core.h"
 #include <math.h>
+#include <stdlib.h>
 #include "../../include/daydreamer_hip.h"
 
 namespace {
 
 constexpr float LN_EPS = 1e-3f;
-constexpr int NWG = 64;            // resident workgroups (16 column strides x 4 row blocks)
+constexpr int NWG_DEFAULT = 128;   // resident workgroups (column strides x 4 row blocks), DD_SCAN_NWG
 constexpr int SPIN_LIMIT = 1 << 22;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -46,6 +47,7 @@ struct ScanArgs {
   int B, T, D, U, S, G, C, A;      // S = G * C
   int XK, XKp;                     // S + A and its multiple of 32
   int use_carry;
+  int nwg;                         // workgroups in the grid (multiple of 4, <= CU count)
   float unimix;
   // inputs
   const float* first;              // [B*T]  is_first as float
@@ -55,6 +57,7 @@ struct ScanArgs {
   const float* u_post;             // [T, B, G]
   // weights: bf16 plane caches [3][N][Kp] and fp32 vectors
   const unsigned short *wt1, *wt2, *wt3, *wt4;
+  const float* w_in;               // img_in kernel [S+A, U] fp32 (P1 gathers its rows)
   const float *g1, *b1, *gg, *bg, *g3, *b3, *bias4;
   // buffers (rows b*T + t)
   float* xin;        // [N, S+A]
@@ -69,6 +72,9 @@ struct ScanArgs {
   float* st3;        // [N, 2]
   float* xq;         // [N, S]
   float* post_logit; // [N, S]
+  int* idx;          // [N, G] drawn class per (row, group) (P1 of the next step gathers by it)
+  const int* idx_init;   // [G] classes of the initial stoch (one-hot)
+  const int* idx_carry;  // [B, G] classes of the carried stoch (step 0)
   unsigned* ctr;     // [2]: barrier counter, error word
 };
 
@@ -155,14 +161,26 @@ __device__ __forceinline__ float tile_gemm(AF afn, const unsigned short* wt, int
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const long plane = (long)Nn * Kp;
   const unsigned short* wrow = wt + (long)(n0 + (lane & 15)) * Kp + kq;
-  for (int k0 = wave * 32; k0 < Kp; k0 += 128) {
-    float v[8];
+  // software pipeline: the operands of k-step i+1 are loaded before the MFMAs of k-step i
+  float v[8], vn[8];
+  uint4 bq[3], bn[3];
+  int k0 = wave * 32;
+  if (k0 < Kp) {
     afn(k0 + kq, v);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bq[p] = *reinterpret_cast<const uint4*>(wrow + p * plane + k0);
+  }
+  for (; k0 < Kp; k0 += 128) {
+    const int k1 = k0 + 128;
+    if (k1 < Kp) {
+      afn(k1 + kq, vn);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bn[p] = *reinterpret_cast<const uint4*>(wrow + p * plane + k1);
+    }
     bf16x8 a[3], b[3];
     split8(v, a);
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      b[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + p * plane + k0));
+    for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bq[p]);
     // six cross products, smallest terms first (as k_mfma_gemm_s3)
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
@@ -170,6 +188,12 @@ __device__ __forceinline__ float tile_gemm(AF afn, const unsigned short* wt, int
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    if (k1 < Kp) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = vn[j];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[p] = bn[p];
+    }
   }
   __syncthreads();   // red[] free (previous tile's readers are done)
 #pragma unroll
@@ -186,6 +210,7 @@ k_observe_scan_fwd(ScanArgs a) {
   __shared__ long sh_row[16];      // buffer row b*T + t of the block's 16 rows (clamped)
   __shared__ long sh_prev[16];     // row of step t-1
   const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int NWG = a.nwg;
   const int mblk = wg & 3, nstr = wg >> 2, NSTR = NWG / 4;
   const int D = a.D, U = a.U, S = a.S, C = a.C, F = a.D + a.S, T = a.T;
   const int orow = ((lane >> 4) * 4) + (tid >> 6), ocol = tid & 15;   // element of a finished tile
@@ -211,21 +236,11 @@ k_observe_scan_fwd(ScanArgs a) {
     const float* pprev = t > 0 ? a.post + aprev * F : ((a.use_carry & 1) ? a.carry + (long)ab * F : nullptr);
 
     // ---------------- P1: z1 = [mask(stoch) | masked action] @ W_img_in
+    // The stoch part of the operand is one-hot per group: its product with W is the SUM of the
+    // G selected rows of W (1.0 * w is exact, the zero terms vanish) - a gather instead of a
+    // K = S contraction; the A action columns are a short dense product.  fp32 adds in group order.
     {
-      // (S is a multiple of 16: an octet lies entirely in the stoch or in the action part)
-      auto afn = [&](int k, float (&v)[8]) {
-        if (k < S) {
-          float pv[8], iv[8];
-          ld8(a.init_stoch + k, iv);
-          if (pprev) ld8(pprev + D + k, pv);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (pprev ? pv[j] : 0.f) * (1.f - af) + iv[j] * af;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (k + j < a.XK) ? a.xin[arow * a.XK + k + j] : 0.f;
-        }
-      };
-      // side output: the masked stoch input (the bulk weight gradient reads xin); the 16
+      // side output: the masked stoch input (the bulk weight gradient reads xin); the
       // workgroups of a row block share it, four floats per thread and trip
       for (int e4 = tid + 256 * nstr; e4 < 16 * S / 4; e4 += 256 * NSTR) {
         const int r = e4 / (S / 4), kk = (e4 - r * (S / 4)) * 4;
@@ -241,9 +256,23 @@ k_observe_scan_fwd(ScanArgs a) {
                           pv.z * (1.f - f) + iv.z * f, pv.w * (1.f - f) + iv.w * f);
         }
       }
+      // thread -> (row r = tid >> 4 of the block, column c = tid & 15 of the tile)
+      const int r = tid >> 4, c = tid & 15;
+      const int b = min(mblk * 16 + r, a.B - 1);
+      const long row = (long)b * T + t;
+      const float f = a.first[row];
+      // class of every group of this row's masked stoch: the previous draw, or the initial
+      // state's (is_first), or none (no carry at t = 0: zero vector)
+      const int* pidx = t > 0 ? a.idx + (row - 1) * a.G : ((a.use_carry & 1) ? a.idx_carry + (long)b * a.G : nullptr);
+      const int* sel = f != 0.f ? a.idx_init : pidx;
       for (int nt = nstr; nt < U / 16; nt += NSTR) {
-        const float r = tile_gemm(afn, a.wt1, U, a.XKp, nt * 16, red);
-        if (olive) a.z1[oidx * U + nt * 16 + ocol] = r;
+        const int n = nt * 16 + c;
+        float acc = 0.f;
+        if (sel) {
+          for (int g = 0; g < a.G; ++g) acc += a.w_in[(long)(g * C + sel[g]) * U + n];
+        }
+        for (int j = 0; j < a.A; ++j) acc += a.xin[row * a.XK + S + j] * a.w_in[(long)(S + j) * U + n];
+        if (mblk * 16 + r < a.B) a.z1[row * U + n] = acc;
       }
     }
     grid_barrier(a.ctr, ++gen * NWG);
@@ -393,12 +422,25 @@ k_observe_scan_fwd(ScanArgs a) {
           if (ok) {
             a.post_logit[row * S + g * C + c] = lg;
             a.post[row * F + D + g * C + c] = (c == idx) ? 1.f : 0.f;
+            if (c == 0) a.idx[row * a.G + g] = idx;
           }
         }
       }
     }
     grid_barrier(a.ctr, ++gen * NWG);
   }
+}
+
+// class index of every one-hot group: idx[r][g] = argmax_c x[r][g*C + c]
+__global__ void k_onehot_argmax(const float* __restrict__ x, long ldx, int* __restrict__ idx, int rows,
+                                int G, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * G) return;
+  const int r = i / G, g = i - r * G;
+  const float* p = x + (long)r * ldx + (long)g * C;
+  int best = 0;
+  for (int c = 1; c < C; ++c) best = p[c] > p[best] ? c : best;
+  idx[i] = best;
 }
 
 // Weight cache: W [K, N] fp32 (row stride ld) -> three bf16 planes [3][N][Kp], exact 3-way
@@ -442,7 +484,8 @@ extern "C" int dd_observe_scan_fwd(
     const float* g1, const float* b1, const float* gg, const float* bg, const float* g3,
     const float* b3, const float* bias4,
     float* xin, float* z1, float* st1, float* gin, float* z3, float* gst, float* post, float* zo,
-    float* xo, float* st3, float* xq, float* post_logit, unsigned* sync2, void* stream) {
+    float* xo, float* st3, float* xq, float* post_logit, const float* w_in, int* idx_ws,
+    unsigned* sync2, void* stream) {
   DD_REQUIRE(dd_observe_scan_supported(B, D, U, G, C, A), "dd_observe_scan_fwd: unsupported shape");
   hipStream_t st = (hipStream_t)stream;
   ScanArgs a;
@@ -456,9 +499,20 @@ extern "C" int dd_observe_scan_fwd(
   a.g1 = g1; a.b1 = b1; a.gg = gg; a.bg = bg; a.g3 = g3; a.b3 = b3; a.bias4 = bias4;
   a.xin = xin; a.z1 = z1; a.st1 = st1; a.gin = gin; a.z3 = z3; a.gst = gst; a.post = post;
   a.zo = zo; a.xo = xo; a.st3 = st3; a.xq = xq; a.post_logit = post_logit; a.ctr = sync2;
+  a.w_in = w_in;
+  const long N = (long)B * T;
+  a.idx = idx_ws; a.idx_carry = idx_ws + N * G; a.idx_init = idx_ws + (N + B) * G;
+  static const int nwg_env = getenv("DD_SCAN_NWG") ? atoi(getenv("DD_SCAN_NWG")) : NWG_DEFAULT;
+  a.nwg = nwg_env < 4 ? 4 : (nwg_env > 256 ? 256 : nwg_env / 4 * 4);
+  if (a.use_carry & 1) {
+    k_onehot_argmax<<<(B * G + 255) / 256, 256, 0, st>>>(carry + D, D + a.S, idx_ws + N * G, B, G, C);
+    DD_CHECK_LAUNCH("dd_observe_scan_fwd(argmax carry)");
+  }
+  k_onehot_argmax<<<(G + 255) / 256, 256, 0, st>>>(init_stoch, a.S, idx_ws + (N + B) * G, 1, G, C);
+  DD_CHECK_LAUNCH("dd_observe_scan_fwd(argmax init)");
   hipError_t e = hipMemsetAsync(sync2, 0, 2 * sizeof(unsigned), st);
   if (e != hipSuccess) { dd_set_error("dd_observe_scan_fwd(memset)", e); return (int)e; }
-  k_observe_scan_fwd<<<NWG, 256, 0, st>>>(a);
+  k_observe_scan_fwd<<<a.nwg, 256, 0, st>>>(a);
   DD_CHECK_LAUNCH("dd_observe_scan_fwd");
   return 0;
 }

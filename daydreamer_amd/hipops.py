@@ -42,7 +42,7 @@ _SIGS = {
     'dd_gru_cell_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     'dd_observe_scan_supported': [c_i] * 6,
     'dd_scan_wprep': [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
-    'dd_observe_scan_fwd': [c_i] * 8 + [c_f] + [c_p] * 30,
+    'dd_observe_scan_fwd': [c_i] * 8 + [c_f] + [c_p] * 32,
     'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_f, c_p, c_p],
     'dd_onehot_sample_host': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i],
     'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
@@ -341,7 +341,7 @@ class HipOps:
                                        self.stream), 'dd_scan_wprep')
 
   def observe_scan_fwd(self, B, T, D, U, G, C, A, use_carry, unimix, first, carry, init_deter,
-                       init_stoch, u_post, wts, vecs, bufs, sync2):
+                       init_stoch, u_post, wts, vecs, bufs, w_in, idx_ws, sync2):
     """wts: 4 plane caches; vecs: g1, b1, gg, bg, g3, b3, bias4; bufs: xin, z1, st1, gin, z3, gst,
     post, zo, xo, st3, xq, post_logit (all contiguous, rows b*T + t)."""
     for t in bufs:
@@ -350,7 +350,8 @@ class HipOps:
         B, T, D, U, G, C, A, int(use_carry), unimix, first.data_ptr(), _ptr(carry),
         init_deter.data_ptr(), init_stoch.data_ptr(), u_post.data_ptr(),
         *[w.data_ptr() for w in wts], *[v.data_ptr() for v in vecs],
-        *[t.data_ptr() for t in bufs], sync2.data_ptr(), self.stream), 'dd_observe_scan_fwd')
+        *[t.data_ptr() for t in bufs], w_in.data_ptr(), idx_ws.data_ptr(), sync2.data_ptr(),
+        self.stream), 'dd_observe_scan_fwd')
 
   # ---- categorical latent -----------------------------------------------------
 

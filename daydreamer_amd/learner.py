@@ -372,6 +372,7 @@ class Learner:
                      (self.P['obs_out_h'].W, i16(3 * U * D), D),
                      (self.P['obs_stats'].W, i16(3 * S * U), U)]
       self.scan_sync = torch.zeros(2, dtype=torch.int32, device=self.device)
+      self.scan_idx = torch.zeros((N + B + 1) * G, dtype=torch.int32, device=self.device)
     # ---- heads on the posterior
     self.acts_wm = {k: self._head_acts(k, N) for k in ('reward', 'cont')}
     if s.dec_mlp_keys:
@@ -770,7 +771,7 @@ class Learner:
          P['obs_out_h'].beta, P['obs_stats'].bias],
         [b['xin'], self.a_img_in.z, self.a_img_in.stats, b['gin'], b['z3'], b['gstats'], b['post'],
          self.a_obs_out.z, self.a_obs_out.out, self.a_obs_out.stats, self.a_obs_stats.z,
-         b['post_logit']], self.scan_sync)
+         b['post_logit']], P['img_in'].W, self.scan_idx, self.scan_sync)
 
   def observe_fwd(self, use_carry=True):
     ops, b = self.ops, self.b

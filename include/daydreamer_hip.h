@@ -138,7 +138,10 @@ int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
  * dd_stats_sample_fwd / dd_onehot_sample_host given the same statistics.
  * wt1..wt4: weight caches from dd_scan_wprep for img_in [U][pad32(S+A)], gru_out [3D][D+U],
  * obs_out[:D] [U][D], obs_stats [S][U].  sync2: two zero-initialisable device words (barrier
- * counter, error word - non-zero after the launch if a bounded spin timed out).
+ * counter, error word - non-zero after the launch if a bounded spin timed out).  w_in: the
+ * img_in kernel itself [S+A, U] (the one-hot stoch part of that layer is a gather of its rows);
+ * idx_ws: (B*T + B + 1) * G ints of scratch (drawn classes per row, of the carry, of the
+ * initial state).
  * dd_observe_scan_supported: B <= 64, D and U multiples of 32, classes in {16, 32, 64}. */
 int dd_observe_scan_supported(int B, int D, int U, int G, int C, int A);
 int dd_scan_wprep(const float* W, long ld, int K, int N, int Kp, void* planes, void* stream);
@@ -150,7 +153,8 @@ int dd_observe_scan_fwd(
     const float* g1, const float* b1, const float* gg, const float* bg, const float* g3,
     const float* b3, const float* bias4,
     float* xin, float* z1, float* st1, float* gin, float* z3, float* gst, float* post, float* zo,
-    float* xo, float* st3, float* xq, float* post_logit, unsigned* sync2, void* stream);
+    float* xo, float* st3, float* xq, float* post_logit, const float* w_in, int* idx_ws,
+    unsigned* sync2, void* stream);
 
 /* ---- categorical latent ------------------------------------------------------ */
 

@@ -43,7 +43,8 @@ def scan(flag):
       [P['img_in'].gamma, P['img_in'].beta, g.gamma, g.beta, P['obs_out_h'].gamma,
        P['obs_out_h'].beta, P['obs_stats'].bias],
       [b['xin'], L.a_img_in.z, L.a_img_in.stats, b['gin'], b['z3'], b['gstats'], b['post'],
-       L.a_obs_out.z, L.a_obs_out.out, L.a_obs_out.stats, L.a_obs_stats.z, b['post_logit']], L.scan_sync)
+       L.a_obs_out.z, L.a_obs_out.out, L.a_obs_out.stats, L.a_obs_stats.z, b['post_logit']],
+      P['img_in'].W, L.scan_idx, L.scan_sync)
 
 
 timed('weight planes (4 x dd_scan_wprep)', lambda: [ops.scan_wprep(W, p, k) for W, p, k in L.scan_w])
