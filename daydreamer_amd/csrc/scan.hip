@@ -38,7 +38,6 @@
 namespace {
 
 constexpr float LN_EPS = 1e-3f;
-constexpr int NWG_DEFAULT = 128;   // resident workgroups (column strides x 4 row blocks), DD_SCAN_NWG
 constexpr int SPIN_LIMIT = 1 << 22;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -105,12 +104,18 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
   v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
 }
 
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
+// `prefetch` runs between the arrival and the wait: loads that do not depend on the other
+// workgroups' results (the next phase's weight planes) travel while the barrier completes.
+template <class PF>
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, PF prefetch) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  prefetch();
+  if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
@@ -123,324 +128,507 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
   }
   __syncthreads();
 }
-
-// LayerNorm statistics of the 16 rows of this workgroup's row block: thread t -> row t >> 4,
-// 16 lanes per row.  src rows at stride ld, width W (multiple of 4).  Result in sh[16][2].
-__device__ __forceinline__ void block_stats(const float* src, long ld, int W, const long* rowidx,
-                                            float (*sh)[2]) {
-  const int r = threadIdx.x >> 4, l = threadIdx.x & 15;
-  const float* p = src + rowidx[r] * ld;
-  float s = 0.f;
-  for (int c = l * 4; c < W; c += 64) {
-    const float4 x = *reinterpret_cast<const float4*>(p + c);
-    s += (x.x + x.y) + (x.z + x.w);
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-  const float mean = s / (float)W;
-  float v = 0.f;
-  for (int c = l * 4; c < W; c += 64) {
-    const float4 x = *reinterpret_cast<const float4*>(p + c);
-    const float a = x.x - mean, b = x.y - mean, cc = x.z - mean, d = x.w - mean;
-    v += (a * a + b * b) + (cc * cc + d * d);
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
-  if (l == 0) { sh[r][0] = mean; sh[r][1] = rsqrtf(v / (float)W + LN_EPS); }
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
+  grid_barrier(ctr, target, [] {});
 }
 
-// One 16x16 output tile: acc += A(16 rows x K) @ Wt(plane cache rows n0..n0+15).  `afn(k0, v)`
-// yields this lane's eight A values (row = lane & 15 of the block, k = k0 .. k0+7).  The four
-// waves take k-steps wave, wave+4, ...; the partial tiles are summed through LDS in wave
-// order.  Returns the complete tile element of thread t (row (t&63)>>4)*4 + (t>>6), col t&15).
-template <class AF>
-__device__ __forceinline__ float tile_gemm(AF afn, const unsigned short* wt, int Nn, int Kp, int n0,
-                                           float (*red)[256]) {
+// Activations of the fused scan: every workgroup of a row block rebuilds the phase's whole
+// operand, so the transcendental work is on the critical path 16 times over - hardware exp2 /
+// reciprocal forms (<= 2 ulp of the libm results the per-layer kernels use).
+__device__ __forceinline__ float fexp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float felu_(float x) { return x > 0.f ? x : fexp_(x) - 1.f; }
+__device__ __forceinline__ float fsigmoid_(float x) { return __builtin_amdgcn_rcpf(1.f + fexp_(-x)); }
+__device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + fexp_(2.f * x)); }
+
+// Sum over a row of the block from the lanes' partial sums: the lanes of a row are the four
+// quads (lane & 15 equal) of the four waves.  Fixed order; result on every lane of the row.
+__device__ __forceinline__ float row_reduce(float s, float (*ws)[16]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int kq = (lane >> 4) * 8;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const long plane = (long)Nn * Kp;
-  const unsigned short* wrow = wt + (long)(n0 + (lane & 15)) * Kp + kq;
-  // software pipeline: the operands of k-step i+1 are loaded before the MFMAs of k-step i
-  float v[8], vn[8];
-  uint4 bq[3], bn[3];
-  int k0 = wave * 32;
-  if (k0 < Kp) {
-    afn(k0 + kq, v);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (lane < 16) ws[wave][lane] = s;
+  __syncthreads();
+  const int l = lane & 15;
+  return (ws[0][l] + ws[1][l]) + (ws[2][l] + ws[3][l]);
+}
+
+// Up to MAXT output tiles (16 rows x 16 columns each, columns n0[j]) of one phase against the
+// same operand rows: the A fragments af[NIT][3] (this wave's k-steps wave*32 + 128*it, three
+// bf16 planes) and the weight planes bq of every tile come from the caller (the planes are loaded
+// while the grid barrier before the phase completes); 6 MFMAs per k-step and tile; the four
+// waves' partial tiles are summed through LDS in wave order.  out[j] = the complete element (row ((t&63)>>4)*4 + (t>>6), col t&15) of tile j.
+template <int NIT>
+__device__ __forceinline__ void load_planes(uint4 (&bq)[NIT][3], const unsigned short* wt, long plane,
+                                            int KP, int n0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned short* wrow = wt + (long)(n0 + (lane & 15)) * KP + (lane >> 4) * 8 + wave * 32;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bq[p] = *reinterpret_cast<const uint4*>(wrow + p * plane + k0);
-  }
-  for (; k0 < Kp; k0 += 128) {
-    const int k1 = k0 + 128;
-    if (k1 < Kp) {
-      afn(k1 + kq, vn);
+  for (int it = 0; it < NIT; ++it)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bn[p] = *reinterpret_cast<const uint4*>(wrow + p * plane + k1);
+    for (int p = 0; p < 3; ++p) bq[it][p] = *reinterpret_cast<const uint4*>(wrow + p * plane + it * 128);
+}
+
+template <int KP, int MAXT>
+__device__ __forceinline__ void tiles_gemm(const bf16x8 (&af)[KP / 128][3], const uint4 (&bq)[MAXT][KP / 128][3],
+                                           float (*red)[4][256], float (&out)[MAXT]) {
+  constexpr int NIT = KP / 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();   // red[] free (the previous phase's readers are done)
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bq[j][it][p]);
+      // six cross products, smallest terms first (as k_mfma_gemm_s3)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it][2], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it][0], b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it][1], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it][1], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it][0], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it][0], b[0], acc, 0, 0, 0);
     }
-    bf16x8 a[3], b[3];
-    split8(v, a);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bq[p]);
-    // six cross products, smallest terms first (as k_mfma_gemm_s3)
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-    if (k1 < Kp) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = vn[j];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bq[p] = bn[p];
-    }
+    for (int r = 0; r < 4; ++r) red[j][wave][r * 64 + lane] = acc[r];
   }
-  __syncthreads();   // red[] free (previous tile's readers are done)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][r * 64 + lane] = acc[r];
   __syncthreads();
   const int t = threadIdx.x;
-  return ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) out[j] = ((red[j][0][t] + red[j][1][t]) + red[j][2][t]) + red[j][3][t];
 }
 
+constexpr int NWG = 64, NSTR = NWG / 4;   // 4 row blocks of 16 batch rows x 16 column strides
+constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
+constexpr int cmax_(int a, int b) { return a > b ? a : b; }
+
+// The (16 rows x 8 columns) chunk of a phase's operand this lane built, written by the one
+// workgroup of the row block that owns it (chunk index modulo the column strides): the side
+// outputs the backward pass reads come straight from the registers.
+template <int NIT>
+__device__ __forceinline__ void store_chunks(const float (&v)[NIT][8], float* rowp, int kq, int nstr, bool live) {
+  if (!live) return;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (((it * 16 + (kq >> 3)) % NSTR) == nstr) {
+      float* q = rowp + it * 128 + kq;
+      *reinterpret_cast<float4*>(q) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+      *reinterpret_cast<float4*>(q + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+    }
+  }
+}
+
+#define TSW(i)                                                                             \
+  if ((a.use_carry & 64) && threadIdx.x == 0 && t == 10)                                    \
+  reinterpret_cast<unsigned long long*>(a.ctr + 64)[blockIdx.x * 4 + (i)] = wall_clock64()
+#define TS(i)                                                                              \
+  if ((a.use_carry & 64) && blockIdx.x == 0 && threadIdx.x == 0 && t == 10)                \
+  reinterpret_cast<unsigned long long*>(a.ctr + 2)[i] = wall_clock64()
+
+template <int D, int U, int G, int C, int A>
 __global__ void __launch_bounds__(256, 1)
 k_observe_scan_fwd(ScanArgs a) {
-  __shared__ float red[4][256];
-  __shared__ float sh_stats[16][2];
-  __shared__ long sh_row[16];      // buffer row b*T + t of the block's 16 rows (clamped)
-  __shared__ long sh_prev[16];     // row of step t-1
-  const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int NWG = a.nwg;
-  const int mblk = wg & 3, nstr = wg >> 2, NSTR = NWG / 4;
-  const int D = a.D, U = a.U, S = a.S, C = a.C, F = a.D + a.S, T = a.T;
+  constexpr int S = G * C, F = D + S, XK = S + A;
+  static_assert(D % 128 == 0 && U % 128 == 0 && C % 16 == 0 && G % 4 == 0, "dims");
+  static_assert(U / 16 % NSTR == 0 && (3 * D / 16) % NSTR == 0 && G % NSTR == 0 && S % (NSTR * 64) == 0,
+                "every workgroup owns the same number of column tiles");
+  // column tiles per workgroup and phase
+  constexpr int T1 = U / 16 / NSTR, T2 = 3 * D / 16 / NSTR, T3 = T1;
+  constexpr int TPG = C / 16, GPP = G / NSTR, T4 = GPP * TPG;
+  constexpr int TMAX = cmax_(cmax_(T2, T3), T4);
+  constexpr int NIT2 = (D + U) / 128, NIT3 = D / 128, NIT4 = U / 128;
+  __shared__ float red[TMAX][4][256];
+  // LayerNorm scales / offsets, the initial state and the stats bias: read every step by every
+  // lane, kept in LDS (a global read after each barrier's acquire would go to L2)
+  constexpr int O_G1 = 0, O_B1 = U, O_GG = 2 * U, O_BG = O_GG + 3 * D, O_G3 = O_BG + 3 * D,
+                O_B3 = O_G3 + U, O_INIT = O_B3 + U, O_BIAS = O_INIT + D, NPAR = O_BIAS + S;
+  __shared__ __attribute__((aligned(16))) float par[NPAR];
+  __shared__ int cls_init[G];
+  __shared__ __attribute__((aligned(16))) float xs[16][T4 * 16 + 4];   // P4: the stats of this workgroup's groups
+  __shared__ float ws_a[4][16], ws_b[4][16];   // row_reduce scratch (mean, variance)
+  for (int i = threadIdx.x; i < NPAR; i += 256) {
+    float v;
+    if (i < O_B1) v = a.g1[i];
+    else if (i < O_GG) v = a.b1[i - O_B1];
+    else if (i < O_BG) v = a.gg[i - O_GG];
+    else if (i < O_G3) v = a.bg[i - O_BG];
+    else if (i < O_B3) v = a.g3[i - O_G3];
+    else if (i < O_INIT) v = a.b3[i - O_B3];
+    else if (i < O_BIAS) v = a.init_deter[i - O_INIT];
+    else v = a.bias4[i - O_BIAS];
+    par[i] = v;
+  }
+  if (threadIdx.x < G) cls_init[threadIdx.x] = a.idx_init[threadIdx.x];
+  const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mblk = wg & 3, nstr = wg >> 2;
+  const int T = a.T;
   const int orow = ((lane >> 4) * 4) + (tid >> 6), ocol = tid & 15;   // element of a finished tile
   const int ob = mblk * 16 + orow;                                    // its batch row
   const bool olive = ob < a.B;
   const int ab = min(mblk * 16 + (lane & 15), a.B - 1);               // batch row of the A operand
+  const bool alive = mblk * 16 + (lane & 15) < a.B;
+  const int kq = (lane >> 4) * 8 + wave * 32;                         // this lane's k offset in a k-step
+  const long pl2 = (long)3 * D * (D + U), pl3 = (long)U * D, pl4 = (long)S * U;
   unsigned gen = 0;
   if (a.use_carry & 2) {   // measurement aid: the barriers alone (4 per step), no work
     for (int i = 0; i < 4 * T; ++i) grid_barrier(a.ctr, ++gen * NWG);
     return;
   }
-  for (int t = 0; t < T; ++t) {
-    if (tid < 16) {
-      const int b = min(mblk * 16 + tid, a.B - 1);
-      sh_row[tid] = (long)b * T + t;
-      sh_prev[tid] = (long)b * T + t - 1;
+  // P1's dense action columns of W_img_in for this thread's output columns: step-invariant
+  const int r1 = tid >> 4, c1 = tid & 15;
+  float wa[T1][A];
+#pragma unroll
+  for (int jt = 0; jt < T1; ++jt)
+#pragma unroll
+    for (int j = 0; j < A; ++j) wa[jt][j] = a.w_in[(long)(S + j) * U + (nstr + NSTR * jt) * 16 + c1];
+  // deter_{t-1} of this lane's operand chunk (every workgroup of the row block computes the whole
+  // GRU output in P3): carried in registers from step to step
+  float hcur[NIT3][8];
+#pragma unroll
+  for (int it = 0; it < NIT3; ++it) {
+    if (a.use_carry & 1) ld8(a.carry + (long)ab * F + it * 128 + kq, hcur[it]);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hcur[it][j] = 0.f;
     }
-    __syncthreads();
-    const long arow = (long)ab * T + t, aprev = arow - 1;
-    const float af = a.first[arow];
+  }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const long arow = (long)ab * T + t;
+    const float af_ = a.first[arow];
     const long oidx = (long)ob * T + t;
-    // previous posterior of the A-operand row: carry at t = 0
-    const float* pprev = t > 0 ? a.post + aprev * F : ((a.use_carry & 1) ? a.carry + (long)ab * F : nullptr);
 
+    // (use_carry bits 2..5: measurement aid, skip the body of P1..P4; bit 6: time stamps of
+    // step 10 on workgroup 0 into ctr[2..], 100 MHz wall clock)
+    TS(0);
     // ---------------- P1: z1 = [mask(stoch) | masked action] @ W_img_in
     // The stoch part of the operand is one-hot per group: its product with W is the SUM of the
     // G selected rows of W (1.0 * w is exact, the zero terms vanish) - a gather instead of a
     // K = S contraction; the A action columns are a short dense product.  fp32 adds in group order.
-    {
-      // side output: the masked stoch input (the bulk weight gradient reads xin); the
-      // workgroups of a row block share it, four floats per thread and trip
-      for (int e4 = tid + 256 * nstr; e4 < 16 * S / 4; e4 += 256 * NSTR) {
-        const int r = e4 / (S / 4), kk = (e4 - r * (S / 4)) * 4;
-        const int b = mblk * 16 + r;
-        if (b < a.B) {
-          const long row = (long)b * T + t;
-          const float f = a.first[row];
-          const float* pp = t > 0 ? a.post + (row - 1) * F : ((a.use_carry & 1) ? a.carry + (long)b * F : nullptr);
-          const float4 iv = *reinterpret_cast<const float4*>(a.init_stoch + kk);
-          const float4 pv = pp ? *reinterpret_cast<const float4*>(pp + D + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(a.xin + row * a.XK + kk) =
-              make_float4(pv.x * (1.f - f) + iv.x * f, pv.y * (1.f - f) + iv.y * f,
-                          pv.z * (1.f - f) + iv.z * f, pv.w * (1.f - f) + iv.w * f);
-        }
-      }
-      // thread -> (row r = tid >> 4 of the block, column c = tid & 15 of the tile)
-      const int r = tid >> 4, c = tid & 15;
-      const int b = min(mblk * 16 + r, a.B - 1);
+    if (!(a.use_carry & 4)) {
+      // thread -> (row r1 = tid >> 4 of the block, column c1 = tid & 15 of the tile)
+      const int b = min(mblk * 16 + r1, a.B - 1);
+      const bool live = mblk * 16 + r1 < a.B;
       const long row = (long)b * T + t;
-      const float f = a.first[row];
       // class of every group of this row's masked stoch: the previous draw, or the initial
-      // state's (is_first), or none (no carry at t = 0: zero vector)
-      const int* pidx = t > 0 ? a.idx + (row - 1) * a.G : ((a.use_carry & 1) ? a.idx_carry + (long)b * a.G : nullptr);
-      const int* sel = f != 0.f ? a.idx_init : pidx;
-      for (int nt = nstr; nt < U / 16; nt += NSTR) {
-        const int n = nt * 16 + c;
+      // state's (is_first), or none (-1: no carry at t = 0, zero vector)
+      const int* pidx = t > 0 ? a.idx + (row - 1) * G : ((a.use_carry & 1) ? a.idx_carry + (long)b * G : nullptr);
+      const float f = a.first[row];
+      int cls[G];
+#pragma unroll
+      for (int g4 = 0; g4 < G; g4 += 4) {
+        const int4 q = pidx ? *reinterpret_cast<const int4*>(pidx + g4) : make_int4(-1, -1, -1, -1);
+        cls[g4] = q.x; cls[g4 + 1] = q.y; cls[g4 + 2] = q.z; cls[g4 + 3] = q.w;
+      }
+      float act[A];
+#pragma unroll
+      for (int j = 0; j < A; ++j) act[j] = a.xin[row * XK + S + j];
+      // this workgroup's slice of the masked stoch input (the bulk weight gradient reads xin)
+      int xcls[S / (NSTR * 64)];
+#pragma unroll
+      for (int q = 0; q < S / (NSTR * 64); ++q) {
+        const int col = ((q * NSTR + nstr) * 16 + c1) * 4;
+        xcls[q] = pidx ? pidx[col / C] : -1;
+      }
+      if (f != 0.f) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) cls[g] = cls_init[g];
+#pragma unroll
+        for (int q = 0; q < S / (NSTR * 64); ++q) xcls[q] = cls_init[(((q * NSTR + nstr) * 16 + c1) * 4) / C];
+      }
+#pragma unroll
+      for (int jt = 0; jt < T1; ++jt) {
+        const int n = (nstr + NSTR * jt) * 16 + c1;
+        float w[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) w[g] = cls[g] >= 0 ? a.w_in[(long)(g * C + cls[g]) * U + n] : 0.f;
         float acc = 0.f;
-        if (sel) {
-          for (int g = 0; g < a.G; ++g) acc += a.w_in[(long)(g * C + sel[g]) * U + n];
-        }
-        for (int j = 0; j < a.A; ++j) acc += a.xin[row * a.XK + S + j] * a.w_in[(long)(S + j) * U + n];
-        if (mblk * 16 + r < a.B) a.z1[row * U + n] = acc;
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc += w[g];
+#pragma unroll
+        for (int j = 0; j < A; ++j) acc += act[j] * wa[jt][j];
+        if (live) a.z1[row * U + n] = acc;
+      }
+#pragma unroll
+      for (int q = 0; q < S / (NSTR * 64); ++q) {
+        const int col = ((q * NSTR + nstr) * 16 + c1) * 4, cc = col % C;
+        if (live)
+          *reinterpret_cast<float4*>(a.xin + row * XK + col) =
+              make_float4(xcls[q] == cc ? 1.f : 0.f, xcls[q] == cc + 1 ? 1.f : 0.f,
+                          xcls[q] == cc + 2 ? 1.f : 0.f, xcls[q] == cc + 3 ? 1.f : 0.f);
       }
     }
-    grid_barrier(a.ctr, ++gen * NWG);
+    TS(1); TSW(0);
+    uint4 bq2[T2][NIT2][3];
+    grid_barrier(a.ctr, ++gen * NWG, [&] {
+#pragma unroll
+      for (int j = 0; j < T2; ++j) load_planes<NIT2>(bq2[j], a.wt2, pl2, D + U, (nstr + NSTR * j) * 16);
+    });
+    TS(2);
 
     // ---------------- P2: z3 = [mask(deter) | ELU(LN(z1))] @ W_gru
-    {
-      block_stats(a.z1, U, U, sh_row, sh_stats);
-      __syncthreads();
-      const float mean = sh_stats[lane & 15][0], rstd = sh_stats[lane & 15][1];
-      auto afn = [&](int k, float (&v)[8]) {
-        if (k < D) {
-          float pv[8], iv[8];
-          ld8(a.init_deter + k, iv);
-          if (pprev) ld8(pprev + k, pv);
+    if (!(a.use_carry & 8)) {
+      constexpr int KP = D + U, NIT = NIT2;
+      // the operand loads go first, the statistics' row loads follow them
+      float raw[NIT][8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (pprev ? pv[j] : 0.f) * (1.f - af) + iv[j] * af;
+      for (int it = 0; it < NIT; ++it) {
+        const int k = it * 128 + kq;
+        if (it * 128 >= D) ld8(a.z1 + arow * U + (k - D), raw[it]);   // (D % 128 == 0: a k-step lies in one part)
+      }
+      // LayerNorm statistics of z1 from the operand registers (the row block's lanes hold the
+      // whole row between them)
+      float ps = 0.f;
+#pragma unroll
+      for (int it = D / 128; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ps += raw[it][j];
+      const float mean = row_reduce(ps, ws_a) / (float)U;
+      float pv = 0.f;
+#pragma unroll
+      for (int it = D / 128; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv += (raw[it][j] - mean) * (raw[it][j] - mean);
+      const float rstd = rsqrtf(row_reduce(pv, ws_b) / (float)U + LN_EPS);
+      TS(3);
+      bf16x8 afr[NIT][3];
+      float v[NIT][8];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int k = it * 128 + kq;
+        float gm[8], bt[8];
+        if (it * 128 < D) {
+          ld8(par + O_INIT + k, gm);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[it][j] = hcur[it][j] * (1.f - af_) + gm[j] * af_;
         } else {
-          const int c = k - D;
-          float zz[8], gm[8], bt[8];
-          ld8(a.z1 + arow * U + c, zz); ld8(a.g1 + c, gm); ld8(a.b1 + c, bt);
+          ld8(par + O_G1 + (k - D), gm);
+          ld8(par + O_B1 + (k - D), bt);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = elu_((zz[j] - mean) * rstd * gm[j] + bt[j]);
+          for (int j = 0; j < 8; ++j) v[it][j] = felu_((raw[it][j] - mean) * rstd * gm[j] + bt[j]);
         }
-      };
-      // side outputs: hprev, x1 (shared by the 16 workgroups of the row block), statistics
-      for (int e = tid + 256 * nstr; e < 16 * (D + U); e += 256 * NSTR) {
-        const int r = e / (D + U), kk = e - r * (D + U);
-        const int b = mblk * 16 + r;
-        if (b < a.B) {
-          const long row = (long)b * T + t;
-          float x;
-          if (kk < D) {
-            const float f = a.first[row];
-            const float* pp = t > 0 ? a.post + (row - 1) * F : ((a.use_carry & 1) ? a.carry + (long)b * F : nullptr);
-            x = (pp ? pp[kk] : 0.f) * (1.f - f) + a.init_deter[kk] * f;
-          } else {
-            const int c = kk - D;
-            x = elu_((a.z1[row * U + c] - sh_stats[r][0]) * sh_stats[r][1] * a.g1[c] + a.b1[c]);
-          }
-          a.gin[row * (D + U) + kk] = x;
-        }
+        split8(v[it], afr[it]);
       }
-      if (nstr == 0 && tid < 16 && mblk * 16 + tid < a.B) {
-        a.st1[sh_row[tid] * 2] = sh_stats[tid][0];
-        a.st1[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
-      }
-      for (int nt = nstr; nt < 3 * D / 16; nt += NSTR) {
-        const float r = tile_gemm(afn, a.wt2, 3 * D, D + U, nt * 16, red);
-        if (olive) a.z3[oidx * 3 * D + nt * 16 + ocol] = r;
-      }
+      // side outputs: [hprev | x1] (the GRU operand) and the LayerNorm statistics
+      store_chunks<NIT>(v, a.gin + arow * KP, kq, nstr, alive);
+#pragma unroll
+      for (int it = 0; it < NIT3; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hcur[it][j] = v[it][j];   // the masked deter_{t-1}: P3's h
+      if (nstr == 0 && tid < 16 && alive) *reinterpret_cast<float2*>(a.st1 + arow * 2) = make_float2(mean, rstd);
+      int n0[T2];
+#pragma unroll
+      for (int j = 0; j < T2; ++j) n0[j] = (nstr + NSTR * j) * 16;
+      float out[T2];
+      TS(4);
+      tiles_gemm<KP, T2>(afr, bq2, red, out);
+      TS(5);
+#pragma unroll
+      for (int j = 0; j < T2; ++j)
+        if (olive) a.z3[oidx * 3 * D + n0[j] + ocol] = out[j];
     }
-    grid_barrier(a.ctr, ++gen * NWG);
+    TS(6); TSW(1);
+    uint4 bq3[T3][NIT3][3];
+    grid_barrier(a.ctr, ++gen * NWG, [&] {
+#pragma unroll
+      for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.wt3, pl3, D, (nstr + NSTR * j) * 16);
+    });
+    TS(7);
 
     // ---------------- P3: zo += GRU(LN(z3), hprev) @ W_obs_out[:D]
-    {
-      block_stats(a.z3, 3 * D, 3 * D, sh_row, sh_stats);
-      __syncthreads();
-      auto gate = [&](float zr_, float zc_, float zu_, float gr, float gc, float gu, float br,
-                      float bc, float bu, float hp, float mean, float rstd) {
-        const float yr = (zr_ - mean) * rstd * gr + br;
-        const float yc = (zc_ - mean) * rstd * gc + bc;
-        const float yu = (zu_ - mean) * rstd * gu + bu;
-        const float rr = sigmoidf_(yr), cand = tanhf(rr * yc), uu = sigmoidf_(yu - 1.f);
-        return uu * cand + (1.f - uu) * hp;
-      };
-      auto gru = [&](long row, int j, float mean, float rstd) {
-        const float* zr = a.z3 + row * 3 * D;
-        return gate(zr[j], zr[D + j], zr[2 * D + j], a.gg[j], a.gg[D + j], a.gg[2 * D + j], a.bg[j],
-                    a.bg[D + j], a.bg[2 * D + j], a.gin[row * (D + U) + j], mean, rstd);
-      };
-      const float mean = sh_stats[lane & 15][0], rstd = sh_stats[lane & 15][1];
-      auto afn = [&](int k, float (&v)[8]) {
-        float z0[8], z1_[8], z2[8], g0[8], g1_[8], g2[8], b0[8], b1_[8], b2[8], hp[8];
-        const float* zr = a.z3 + arow * 3 * D;
-        ld8(zr + k, z0); ld8(zr + D + k, z1_); ld8(zr + 2 * D + k, z2);
-        ld8(a.gg + k, g0); ld8(a.gg + D + k, g1_); ld8(a.gg + 2 * D + k, g2);
-        ld8(a.bg + k, b0); ld8(a.bg + D + k, b1_); ld8(a.bg + 2 * D + k, b2);
-        ld8(a.gin + arow * (D + U) + k, hp);
+    if (!(a.use_carry & 16)) {
+      constexpr int NIT = NIT3;
+      float z0[NIT][8], z1_[NIT][8], z2[NIT][8];
+      const float* zr = a.z3 + arow * 3 * D;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          v[j] = gate(z0[j], z1_[j], z2[j], g0[j], g1_[j], g2[j], b0[j], b1_[j], b2[j], hp[j], mean, rstd);
-      };
-      // side outputs: deter_t (shared by the row block's workgroups), GRU statistics
-      for (int e = tid + 256 * nstr; e < 16 * D; e += 256 * NSTR) {
-        const int r = e / D, j = e - r * D;
-        if (mblk * 16 + r < a.B) a.post[sh_row[r] * F + j] = gru(sh_row[r], j, sh_stats[r][0], sh_stats[r][1]);
+      for (int it = 0; it < NIT; ++it) {
+        const int k = it * 128 + kq;
+        ld8(zr + k, z0[it]); ld8(zr + D + k, z1_[it]); ld8(zr + 2 * D + k, z2[it]);
       }
-      if (nstr == 0 && tid < 16 && mblk * 16 + tid < a.B) {
-        a.gst[sh_row[tid] * 2] = sh_stats[tid][0];
-        a.gst[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
+      // zo's old value (the embedding part, written before the scan) for the accumulate
+      float zold[T3];
+#pragma unroll
+      for (int j = 0; j < T3; ++j) zold[j] = olive ? a.zo[oidx * U + (nstr + NSTR * j) * 16 + ocol] : 0.f;
+      float ps = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ps += (z0[it][j] + z1_[it][j]) + z2[it][j];
+      const float mean = row_reduce(ps, ws_a) / (float)(3 * D);
+      float pv = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d0 = z0[it][j] - mean, d1 = z1_[it][j] - mean, d2 = z2[it][j] - mean;
+          pv += (d0 * d0 + d1 * d1) + d2 * d2;
+        }
+      const float rstd = rsqrtf(row_reduce(pv, ws_b) / (float)(3 * D) + LN_EPS);
+      TS(8);
+      bf16x8 afr[NIT][3];
+      float v[NIT][8];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int k = it * 128 + kq;
+        float g0[8], g1_[8], g2[8], b0[8], b1_[8], b2[8];
+        ld8(par + O_GG + k, g0); ld8(par + O_GG + D + k, g1_); ld8(par + O_GG + 2 * D + k, g2);
+        ld8(par + O_BG + k, b0); ld8(par + O_BG + D + k, b1_); ld8(par + O_BG + 2 * D + k, b2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float yr = (z0[it][j] - mean) * rstd * g0[j] + b0[j];
+          const float yc = (z1_[it][j] - mean) * rstd * g1_[j] + b1_[j];
+          const float yu = (z2[it][j] - mean) * rstd * g2[j] + b2[j];
+          const float rr = fsigmoid_(yr), cand = ftanh_(rr * yc), uu = fsigmoid_(yu - 1.f);
+          v[it][j] = uu * cand + (1.f - uu) * hcur[it][j];
+        }
+        split8(v[it], afr[it]);
       }
-      for (int nt = nstr; nt < U / 16; nt += NSTR) {
-        const float r = tile_gemm(afn, a.wt3, U, D, nt * 16, red);
-        if (olive) a.zo[oidx * U + nt * 16 + ocol] += r;
-      }
+      // side outputs: deter_t and the GRU's LayerNorm statistics
+      store_chunks<NIT>(v, a.post + arow * F, kq, nstr, alive);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hcur[it][j] = v[it][j];
+      if (nstr == 0 && tid < 16 && alive) *reinterpret_cast<float2*>(a.gst + arow * 2) = make_float2(mean, rstd);
+      int n0[T3];
+#pragma unroll
+      for (int j = 0; j < T3; ++j) n0[j] = (nstr + NSTR * j) * 16;
+      float out[T3];
+      TS(9);
+      tiles_gemm<D, T3>(afr, bq3, red, out);
+      TS(10);
+#pragma unroll
+      for (int j = 0; j < T3; ++j)
+        if (olive) a.zo[oidx * U + n0[j] + ocol] = zold[j] + out[j];
     }
-    grid_barrier(a.ctr, ++gen * NWG);
+    TS(11); TSW(2);
+    uint4 bq4[T4][NIT4][3];
+    grid_barrier(a.ctr, ++gen * NWG, [&] {
+#pragma unroll
+      for (int j = 0; j < T4; ++j)
+        load_planes<NIT4>(bq4[j], a.wt4, pl4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
+    });
+    TS(12);
 
     // ---------------- P4: xq = ELU(LN(zo)) @ W_obs_stats + b; sample
-    {
-      block_stats(a.zo, U, U, sh_row, sh_stats);
-      __syncthreads();
-      const float mean = sh_stats[lane & 15][0], rstd = sh_stats[lane & 15][1];
-      auto afn = [&](int k, float (&v)[8]) {
-        float zz[8], gm[8], bt[8];
-        ld8(a.zo + arow * U + k, zz); ld8(a.g3 + k, gm); ld8(a.b3 + k, bt);
+    if (!(a.use_carry & 32)) {
+      constexpr int NIT = NIT4;
+      float raw[NIT][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = elu_((zz[j] - mean) * rstd * gm[j] + bt[j]);
-      };
-      // side outputs: xo (shared by the row block's workgroups), LayerNorm statistics
-      for (int e = tid + 256 * nstr; e < 16 * U; e += 256 * NSTR) {
-        const int r = e / U, c = e - r * U;
-        if (mblk * 16 + r < a.B)
-          a.xo[sh_row[r] * U + c] = elu_((a.zo[sh_row[r] * U + c] - sh_stats[r][0]) * sh_stats[r][1] * a.g3[c] + a.b3[c]);
-      }
-      if (nstr == 0 && tid < 16 && mblk * 16 + tid < a.B) {
-        a.st3[sh_row[tid] * 2] = sh_stats[tid][0];
-        a.st3[sh_row[tid] * 2 + 1] = sh_stats[tid][1];
-      }
-      // units of whole latent groups (C / 16 column tiles each), so that the draw of a
-      // (row, group) only reads statistics this workgroup wrote
-      const int tpg = C / 16;
-      for (int g = nstr; g < a.G; g += NSTR) {
-        for (int q = 0; q < tpg; ++q) {
-          const int n0 = g * C + q * 16;
-          const float r = tile_gemm(afn, a.wt4, S, U, n0, red);
-          if (olive) a.xq[oidx * S + n0 + ocol] = r + a.bias4[n0 + ocol];
-        }
-        __syncthreads();
-        // 16 (row, group) items, one LW-lane sub-wave each
-        const int LWc = C <= 16 ? 16 : (C <= 32 ? 32 : 64);
-        const int per_wave = 64 / LWc, wave = tid >> 6;
-        for (int it0 = 0; it0 < 16; it0 += 4 * per_wave) {
-          const int sub = lane / LWc, c = lane % LWc;
-          const int item = it0 + wave * per_wave + sub;
+      for (int it = 0; it < NIT; ++it) ld8(a.zo + arow * U + it * 128 + kq, raw[it]);
+      // the uniforms of this workgroup's (row, group) items
+      constexpr int LWc = C <= 16 ? 16 : (C <= 32 ? 32 : 64);
+      constexpr int per_wave = 64 / LWc, NPASS = cdiv_(16, 4 * per_wave);
+      float uu[GPP][NPASS];
+#pragma unroll
+      for (int gi = 0; gi < GPP; ++gi)
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int item = ps * 4 * per_wave + wave * per_wave + lane / LWc;
           const int b = mblk * 16 + item;
-          const bool live = item < 16 && b < a.B;
-          const bool ok = live && c < C;
-          const long row = live ? (long)b * T + t : 0;
-          const float xv = ok ? a.xq[row * S + g * C + c] : -INFINITY;
-          const float uu = live ? a.u_post[((long)t * a.B + b) * a.G + g] : 0.f;
-          float lg;
-          int idx;
-          if (LWc == 16) stats_item<16>(xv, ok, c, sub, C, a.unimix, 0, uu, lg, idx);
-          else if (LWc == 32) stats_item<32>(xv, ok, c, sub, C, a.unimix, 0, uu, lg, idx);
-          else stats_item<64>(xv, ok, c, sub, C, a.unimix, 0, uu, lg, idx);
-          if (ok) {
-            a.post_logit[row * S + g * C + c] = lg;
-            a.post[row * F + D + g * C + c] = (c == idx) ? 1.f : 0.f;
-            if (c == 0) a.idx[row * a.G + g] = idx;
+          uu[gi][ps] = (item < 16 && b < a.B) ? a.u_post[((long)t * a.B + b) * G + nstr + NSTR * gi] : 0.f;
+        }
+      float ps = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ps += raw[it][j];
+      const float mean = row_reduce(ps, ws_a) / (float)U;
+      float pv = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv += (raw[it][j] - mean) * (raw[it][j] - mean);
+      const float rstd = rsqrtf(row_reduce(pv, ws_b) / (float)U + LN_EPS);
+      TS(13);
+      bf16x8 afr[NIT][3];
+      float v[NIT][8];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int k = it * 128 + kq;
+        float gm[8], bt[8];
+        ld8(par + O_G3 + k, gm); ld8(par + O_B3 + k, bt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[it][j] = felu_((raw[it][j] - mean) * rstd * gm[j] + bt[j]);
+        split8(v[it], afr[it]);
+      }
+      // side outputs: xo (the stats layer's operand) and the LayerNorm statistics
+      store_chunks<NIT>(v, a.xo + arow * U, kq, nstr, alive);
+      if (nstr == 0 && tid < 16 && alive) *reinterpret_cast<float2*>(a.st3 + arow * 2) = make_float2(mean, rstd);
+      // whole latent groups (TPG column tiles each) per workgroup, so that the draw of a
+      // (row, group) only needs statistics this workgroup computed
+      int n0[T4];
+#pragma unroll
+      for (int j = 0; j < T4; ++j) n0[j] = (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16;
+      float out[T4];
+      TS(14);
+      tiles_gemm<U, T4>(afr, bq4, red, out);
+      TS(15);
+#pragma unroll
+      for (int j = 0; j < T4; ++j) {
+        const float x = out[j] + par[O_BIAS + n0[j] + ocol];
+        xs[orow][j * 16 + ocol] = x;
+        if (olive) a.xq[oidx * S + n0[j] + ocol] = x;
+      }
+      __syncthreads();
+      TS(16);
+      // 16 (row, group) items per group, one LWc-lane sub-wave each; this lane's GPP * NPASS
+      // items run in lock-step
+      {
+        constexpr int NI = GPP * NPASS;
+        const int sub = lane / LWc, c = lane % LWc;
+        float xv[NI], uq[NI], lg[NI];
+        bool ok[NI];
+        int idx[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int gi = i / NPASS, ps2 = i % NPASS;
+          const int item = ps2 * 4 * per_wave + wave * per_wave + sub;
+          ok[i] = item < 16 && mblk * 16 + item < a.B && c < C;
+          xv[i] = ok[i] ? xs[item & 15][gi * C + c] : -INFINITY;
+          uq[i] = uu[gi][ps2];
+        }
+        stats_items<LWc, NI>(xv, ok, c, sub, C, a.unimix, 0, uq, lg, idx);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int gi = i / NPASS, ps2 = i % NPASS;
+          const int item = ps2 * 4 * per_wave + wave * per_wave + sub;
+          const int g = nstr + NSTR * gi;
+          if (ok[i]) {
+            const long row = (long)(mblk * 16 + item) * T + t;
+            a.post_logit[row * S + g * C + c] = lg[i];
+            a.post[row * F + D + g * C + c] = (c == idx[i]) ? 1.f : 0.f;
+            if (c == 0) a.idx[row * G + g] = idx[i];
           }
         }
       }
     }
+    TS(17); TSW(3);
     grid_barrier(a.ctr, ++gen * NWG);
+    TS(18);
   }
 }
+#undef TS
+#undef TSW
 
 // class index of every one-hot group: idx[r][g] = argmax_c x[r][g*C + c]
+// -1 for an all-zero group (the zero state); a group that is neither one-hot nor zero cannot
+// go through the gather form of P1: error word 2.
 __global__ void k_onehot_argmax(const float* __restrict__ x, long ldx, int* __restrict__ idx, int rows,
-                                int G, int C) {
+                                int G, int C, unsigned* __restrict__ err) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * G) return;
   const int r = i / G, g = i - r * G;
   const float* p = x + (long)r * ldx + (long)g * C;
-  int best = 0;
-  for (int c = 1; c < C; ++c) best = p[c] > p[best] ? c : best;
-  idx[i] = best;
+  int best = 0, ones = 0, other = 0;
+  for (int c = 0; c < C; ++c) {
+    best = p[c] > p[best] ? c : best;
+    ones += p[c] == 1.f;
+    other += p[c] != 1.f && p[c] != 0.f;
+  }
+  if (other || ones > 1) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  idx[i] = ones == 1 ? best : -1;
 }
 
 // Weight cache: W [K, N] fp32 (row stride ld) -> three bf16 planes [3][N][Kp], exact 3-way
@@ -471,9 +659,16 @@ extern "C" int dd_scan_wprep(const float* W, long ld, int K, int N, int Kp, void
   return 0;
 }
 
+// compiled shapes (deter, units, groups, classes, action dims): loops unroll and the loads of a
+// phase issue together only with compile-time extents
+#define DD_SCAN_SHAPES(X) X(256, 256, 32, 32, 16) X(256, 256, 32, 32, 6)
+
 extern "C" int dd_observe_scan_supported(int B, int D, int U, int G, int C, int A) {
-  return B >= 1 && B <= 64 && D % 32 == 0 && U % 32 == 0 && (C == 16 || C == 32 || C == 64) &&
-         G >= 1 && A >= 0;
+  if (B < 1 || B > 64) return 0;
+#define X(d, u, g, c, a_) if (D == d && U == u && G == g && C == c && A == a_) return 1;
+  DD_SCAN_SHAPES(X)
+#undef X
+  return 0;
 }
 
 extern "C" int dd_observe_scan_fwd(
@@ -491,7 +686,7 @@ extern "C" int dd_observe_scan_fwd(
   ScanArgs a;
   a.B = B; a.T = T; a.D = D; a.U = U; a.G = G; a.C = C; a.A = A; a.S = G * C;
   a.XK = a.S + A; a.XKp = (a.XK + 31) / 32 * 32;
-  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 2); a.unimix = unimix;
+  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 126); a.unimix = unimix;
   a.first = first; a.carry = carry; a.init_deter = init_deter; a.init_stoch = init_stoch;
   a.u_post = u_post;
   a.wt1 = (const unsigned short*)wt1; a.wt2 = (const unsigned short*)wt2;
@@ -502,17 +697,19 @@ extern "C" int dd_observe_scan_fwd(
   a.w_in = w_in;
   const long N = (long)B * T;
   a.idx = idx_ws; a.idx_carry = idx_ws + N * G; a.idx_init = idx_ws + (N + B) * G;
-  static const int nwg_env = getenv("DD_SCAN_NWG") ? atoi(getenv("DD_SCAN_NWG")) : NWG_DEFAULT;
-  a.nwg = nwg_env < 4 ? 4 : (nwg_env > 256 ? 256 : nwg_env / 4 * 4);
-  if (a.use_carry & 1) {
-    k_onehot_argmax<<<(B * G + 255) / 256, 256, 0, st>>>(carry + D, D + a.S, idx_ws + N * G, B, G, C);
-    DD_CHECK_LAUNCH("dd_observe_scan_fwd(argmax carry)");
-  }
-  k_onehot_argmax<<<(G + 255) / 256, 256, 0, st>>>(init_stoch, a.S, idx_ws + (N + B) * G, 1, G, C);
-  DD_CHECK_LAUNCH("dd_observe_scan_fwd(argmax init)");
+  a.nwg = NWG;
   hipError_t e = hipMemsetAsync(sync2, 0, 2 * sizeof(unsigned), st);
   if (e != hipSuccess) { dd_set_error("dd_observe_scan_fwd(memset)", e); return (int)e; }
-  k_observe_scan_fwd<<<a.nwg, 256, 0, st>>>(a);
+  if (a.use_carry & 1) {
+    k_onehot_argmax<<<(B * G + 255) / 256, 256, 0, st>>>(carry + D, D + a.S, idx_ws + N * G, B, G, C, sync2 + 1);
+    DD_CHECK_LAUNCH("dd_observe_scan_fwd(argmax carry)");
+  }
+  k_onehot_argmax<<<(G + 255) / 256, 256, 0, st>>>(init_stoch, a.S, idx_ws + (N + B) * G, 1, G, C, sync2 + 1);
+  DD_CHECK_LAUNCH("dd_observe_scan_fwd(argmax init)");
+  bool launched = false;
+#define X(d, u, g, c, a_) if (!launched && D == d && U == u && G == g && C == c && A == a_) { k_observe_scan_fwd<d, u, g, c, a_><<<a.nwg, 256, 0, st>>>(a); launched = true; }
+  DD_SCAN_SHAPES(X)
+#undef X
   DD_CHECK_LAUNCH("dd_observe_scan_fwd");
   return 0;
 }

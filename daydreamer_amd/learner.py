@@ -371,7 +371,7 @@ class Learner:
                      (self.P['gru'].W, i16(3 * 3 * D * (D + U)), D + U),
                      (self.P['obs_out_h'].W, i16(3 * U * D), D),
                      (self.P['obs_stats'].W, i16(3 * S * U), U)]
-      self.scan_sync = torch.zeros(2, dtype=torch.int32, device=self.device)
+      self.scan_sync = torch.zeros(64 + 2 * 4 * 64, dtype=torch.int32, device=self.device)   # counter, error word, debug stamps
       self.scan_idx = torch.zeros((N + B + 1) * G, dtype=torch.int32, device=self.device)
     # ---- heads on the posterior
     self.acts_wm = {k: self._head_acts(k, N) for k in ('reward', 'cont')}

@@ -7,11 +7,13 @@ import torch
 import helpers
 from daydreamer_amd import learner as LM, hipops, synthetic, config as config_mod, spec as spec_mod
 
-cfg = helpers.make_config(('a1_vision',))
+NAME = sys.argv[1] if len(sys.argv) > 1 else 'a1_vision'
+cfg = helpers.make_config((NAME,))
 plain = config_mod.to_plain(cfg)
-obs, act = synthetic.config_spaces('a1_vision')
+obs, act = synthetic.config_spaces(NAME)
 shapes = {k: v.shape for k, v in obs.items()}
-sp = spec_mod.build_spec(plain, shapes, 16, False)
+adim = act['action'].shape[-1] if hasattr(act['action'], 'shape') else 16
+sp = spec_mod.build_spec(plain, shapes, adim, getattr(act['action'], 'discrete', False))
 B, T = plain['batch_size'], plain['replay_chunk']
 data = synthetic.make_batch(obs, act, B, T, seed=0)
 ops = hipops.HipOps('cuda:0')
@@ -50,7 +52,18 @@ def scan(flag):
 timed('weight planes (4 x dd_scan_wprep)', lambda: [ops.scan_wprep(W, p, k) for W, p, k in L.scan_w])
 timed('fused scan, full (T = %d steps)' % T, lambda: scan(1))
 timed('fused scan, barriers only (4 per step)', lambda: scan(3))
+for nm, bit in (('P1 img_in (gather)', 4), ('P2 gru gemm', 8), ('P3 gru gates + obs_out', 16), ('P4 obs_stats + draw', 32)):
+  timed('fused scan without ' + nm, lambda bit=bit: scan(1 | bit))
 print('error word', int(L.scan_sync[1]))
+scan(1 | 64)
+torch.cuda.synchronize()
+ts = L.scan_sync[2:2 + 38].view(torch.int64).cpu().numpy()
+names = ['step start', 'P1 body', 'barrier 1', 'P2 stats', 'P2 operand', 'P2 gemm', 'P2 stores', 'barrier 2',
+         'P3 stats', 'P3 operand', 'P3 gemm', 'P3 stores', 'barrier 3', 'P4 stats', 'P4 operand', 'P4 gemm',
+         'P4 bias/LDS', 'P4 draw', 'barrier 4']
+print('step 10, workgroup 0 (us since step start / delta):')
+for i in range(1, 19):
+  print(f'  {names[i]:12s} {(ts[i] - ts[0]) / 100:7.2f} {(ts[i] - ts[i - 1]) / 100:6.2f}')
 L.fused_scan = False
 from daydreamer_amd import graphs
 plan = graphs.GraphPlan('cuda:0')
@@ -58,3 +71,11 @@ keep, L.plan = L.plan, plan
 plan.capture(lambda: L.observe_fwd(True))
 L.plan = keep
 timed('launch sequence (graph replay, incl. bulk prior)', plan.replay)
+
+import numpy as np
+arr = L.scan_sync[64:64 + 2 * 4 * 64].view(torch.int64).cpu().numpy().reshape(64, 4)
+print('arrival of the workgroups at the 4 barriers of step 10 (us after the first arrival): median / last; slowest workgroup')
+for i in range(4):
+  d = (arr[:, i] - arr[:, i].min()) / 100
+  print(f'  barrier {i + 1}: {np.median(d):5.2f} {d.max():5.2f}  wg {int(d.argmax())} (row block {int(d.argmax()) & 3}, stride {int(d.argmax()) >> 2});'
+        f' released {(ts[[2, 7, 12, 18][i]] - arr[:, i].max()) / 100:5.2f} us after the last arrival')
