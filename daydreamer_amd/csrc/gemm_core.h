@@ -447,6 +447,115 @@ struct EpiConvUp4 {  // column n = (py, px, cb)
   }
 };
 
+// ---- conv "up", all parities, class pixels grouped by tap validity ----------------------
+// In the form above every class pixel (j, i) contracts over all (k/2)^2 taps, and the taps
+// whose source pixel (j-m, i-mx) lies outside the small image are loaded as zeros: 13-56% of
+// the MFMA work at the decoder / encoder-backward sizes (edge pixels have 1..k/2-1 valid taps
+// per axis).  The valid taps of a pixel form a rectangle [ty0, ty0+nvy) x [tx0, tx0+nvx) that
+// only depends on which edge band j and i lie in, so the class pixels are grouped into the
+// (<= 2*(k/2))^2 bands of equal rectangle: each band is its own contraction (rows = the
+// band's pixels of all images, K = nvy*nvx*Cs, the band's taps only), all bands in one
+// launch (row tile -> band by a table in the kernel arguments).  Skipped products are exact
+// zeros, so the result is bit-identical to the unclassed form.
+struct UpCls {
+  unsigned short j0, njc, i0, nic;
+  unsigned char ty0, nvy, tx0, nvx;
+  int tile0;          // first row tile of the band
+  FastDiv d_ji, d_i;  // band-local row -> (image, jj, ii)
+};
+constexpr int UP_MAXCLS = 36;
+struct UpCtx {        // the band of this workgroup's row tile (wave-uniform)
+  int j0, i0, ty0, tx0, nvx, rmul, keff, row0, rows;
+  FastDiv d_ji, d_i;
+};
+struct NoCtx {};
+template <class AL, class = void> struct has_tile_ctx : std::false_type {};
+template <class AL> struct has_tile_ctx<AL, std::enable_if_t<AL::TILE_CTX>> : std::true_type {};
+template <int BM, class AL>
+__device__ __forceinline__ auto get_tile_ctx(const AL& al, int tmi) {
+  if constexpr (has_tile_ctx<AL>::value) return al.template tile_ctx<BM>(tmi);
+  else return NoCtx{};
+}
+// Tile-context loaders are affine: element (row, k0 + kofs) of the operand lies at
+// ptr[row_base(row) + k_off(k0) + kofs] for every k0 that is a multiple of the k-tile - the
+// row term is per thread and loop-invariant, the k term is wave-uniform (scalar unit), so a
+// staged float4 costs one 64-bit add instead of the ~40 vector instructions of the
+// divide-and-clamp gather (which, not the MFMAs, bounded the unclassed form).
+// (slot s of the band's tap rectangle -> tap (m, mx); s < 16)
+__device__ __forceinline__ void up_tap(const UpCtx& cx, int s, int& m, int& mx) {
+  const int q = (s * cx.rmul) >> 16;   // s / nvx
+  m = cx.ty0 + q;
+  mx = cx.tx0 + s - q * cx.nvx;
+}
+
+struct ConvUpAC {
+  static constexpr bool TILE_CTX = true;
+  const float* small; int n_img, hs, ws, Cs, ncls;
+  FastDiv d_cs;
+  UpCls cls[UP_MAXCLS];
+  template <int BM>
+  __device__ __forceinline__ UpCtx tile_ctx(int tmi) const {
+    int c = 0;
+    for (int q = 1; q < ncls; ++q) c = tmi >= cls[q].tile0 ? q : c;
+    const UpCls& u = cls[c];
+    UpCtx cx;
+    cx.j0 = u.j0; cx.i0 = u.i0; cx.ty0 = u.ty0; cx.tx0 = u.tx0; cx.nvx = u.nvx;
+    cx.keff = (int)u.nvy * (int)u.nvx * Cs;
+    cx.row0 = (tmi - u.tile0) * BM;
+    cx.rows = n_img * (int)u.njc * (int)u.nic;
+    cx.rmul = 65536 / (u.nvx ? u.nvx : 1) + 1;
+    cx.d_ji = u.d_ji; cx.d_i = u.d_i;
+    return cx;
+  }
+  __device__ __forceinline__ const float* ptr() const { return small; }
+  __device__ __forceinline__ long row_base(const UpCtx& cx, int rl) const {
+    const int rr = min(rl, cx.rows - 1);   // rows past the band: duplicates, dropped by the epilogue
+    int n, rem, jj, ii;
+    cx.d_ji.divmod(rr, n, rem);
+    cx.d_i.divmod(rem, jj, ii);
+    return (((long)n * hs + cx.j0 + jj) * ws + cx.i0 + ii) * Cs;
+  }
+  __device__ __forceinline__ int k_off(const UpCtx& cx, int k0) const {
+    int s, c0, m, mx;
+    d_cs.divmod(k0, s, c0);
+    up_tap(cx, s, m, mx);
+    return c0 - (m * ws + mx) * Cs;   // source pixel (j - m, i - mx): in range by construction
+  }
+};
+
+struct ConvUpB4C {
+  const float* w; int Cb, Cs, kw, R;
+  FastDiv d_cs, d_cb;
+  __device__ __forceinline__ const float* ptr() const { return w; }
+  __device__ __forceinline__ long row_base(const UpCtx&, int r) const {
+    const int rr = min(r, R - 1);
+    int q, cb;
+    d_cb.divmod(rr, q, cb);
+    return ((long)((q >> 1) * kw + (q & 1)) * Cb + cb) * Cs;
+  }
+  __device__ __forceinline__ int k_off(const UpCtx& cx, int k0) const {
+    int s, c0, m, mx;
+    d_cs.divmod(k0, s, c0);
+    up_tap(cx, s, m, mx);
+    return c0 + (2 * m * kw + 2 * mx) * Cb * Cs;
+  }
+};
+
+struct EpiConvUp4C {  // column n = (py, px, cb); rows band-local
+  float* big; const float* bias; int hb, wb, Cb;
+  FastDiv d_cb;
+  __device__ __forceinline__ void putc(const UpCtx& cx, int rl, int n, float v) const {
+    if (rl >= cx.rows || n >= 4 * Cb) return;
+    int img, rem, jj, ii, q, cb;
+    cx.d_ji.divmod(rl, img, rem);
+    cx.d_i.divmod(rem, jj, ii);
+    d_cb.divmod(n, q, cb);
+    const int y = 2 * (cx.j0 + jj) + (q >> 1), x = 2 * (cx.i0 + ii) + (q & 1);
+    if (y >= hb || x >= wb) return;
+    big[(((long)img * hb + y) * wb + x) * Cb + cb] = bias ? v + bias[cb] : v;
+  }
+};
+
 template <class EP, class = void> struct epi_reads_c : std::false_type {};
 template <class EP> struct epi_reads_c<EP, std::enable_if_t<EP::READS_C>> : std::true_type {};
 
@@ -461,7 +570,11 @@ template <class EP> struct epi_reads_c<EP, std::enable_if_t<EP::READS_C>> : std:
 // that XCD's L2, instead of once per column tile from eight different L2s (PMC, round 1:
 // 3.0x the algorithmic bytes per launch).  tiles_m < 0 selects the plain column-major order
 // (DD_XCD_SWIZZLE=0, for A/B measurements).
-__device__ __forceinline__ void tile_coords(int tiles_m_signed, int& tm_idx, int& tn_idx) {
+constexpr int TILES_STRIDED = 1 << 30;   // flag in the tiles_m kernel argument
+__device__ __forceinline__ bool tile_coords_strided(int tiles_m, int& tm_idx, int& tn_idx);
+__device__ __forceinline__ bool tile_coords(int tiles_m_signed, int& tm_idx, int& tn_idx) {
+  if (tiles_m_signed > 0 && (tiles_m_signed & TILES_STRIDED))
+    return tile_coords_strided(tiles_m_signed & ~TILES_STRIDED, tm_idx, tn_idx);
   const int T = (int)gridDim.x;
   const int tiles_m = tiles_m_signed < 0 ? -tiles_m_signed : tiles_m_signed;
   int tile = (int)blockIdx.x;
@@ -476,6 +589,22 @@ __device__ __forceinline__ void tile_coords(int tiles_m_signed, int& tm_idx, int
     tm_idx = tile % tiles_m;
     tn_idx = tile / tiles_m;
   }
+  return true;
+}
+
+// Row tiles of unequal cost (tile-context loaders: the tap bands of ConvUpAC, sorted by band):
+// contiguous per-XCD ranges would hand whole bands - all the cheap or all the expensive tiles -
+// to one XCD.  Here XCD x takes every 8th row tile (an even mix of the bands), and the column
+// tiles of a row tile still run back to back on that XCD.  gridDim.x = ceil8(tiles_m) * tiles_n;
+// returns false for the padding workgroups.
+__device__ __forceinline__ bool tile_coords_strided(int tiles_m, int& tm_idx, int& tn_idx) {
+  const int tm8 = (tiles_m + 7) & ~7;
+  const int tiles_n = (int)gridDim.x / tm8;
+  const int b = (int)blockIdx.x, x = b & 7, s = b >> 3;
+  const int rowslot = s / tiles_n;
+  tn_idx = s - rowslot * tiles_n;
+  tm_idx = rowslot * 8 + x;
+  return tm_idx < tiles_m;
 }
 
 inline int xcd_swizzle() {
@@ -502,7 +631,7 @@ k_mfma_gemm(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int tmi, tni;
-  tile_coords(tiles_m, tmi, tni);
+  if (!tile_coords(tiles_m, tmi, tni)) return;
   const int m0 = tmi * BM, n0 = tni * BN;
   const int kb = blockIdx.z * kps;
   const int ke = min(K, kb + kps);
@@ -755,10 +884,16 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NPL * LB::BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int tmi, tni;
-  tile_coords(tiles_m, tmi, tni);
-  const int m0 = tmi * BM, n0 = tni * BN;
+  if (!tile_coords(tiles_m, tmi, tni)) return;
+  // loaders with a per-row-tile context (ConvUpAC: the tap band of the tile): rows are
+  // context-local and the contraction length is the tile's own
+  constexpr bool TC = has_tile_ctx<AL>::value;
+  const auto cx = get_tile_ctx<BM>(al, tmi);
+  int m0 = tmi * BM;
+  const int n0 = tni * BN;
   const int kb = blockIdx.z * kps;
-  const int ke = min(K, kb + kps);
+  int ke = min(K, kb + kps);
+  if constexpr (TC) { m0 = cx.row0; ke = cx.keff; }
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   constexpr int NA = LA::N, NB = LB::N;
@@ -778,20 +913,50 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 
   float ra_[ST][NA][4], rb_[ST][NB][4];
 
+  // tile-context loaders: per-thread element offsets of the staged units at k0 = 0
+  [[maybe_unused]] long abase[TC ? NA : 1], bbase[TC ? NB : 1];
+  if constexpr (TC) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      int r, k; LA::coord(tid, u, r, k);
+      abase[u] = al.row_base(cx, m0 + r) + k;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      int r, k; LB::coord(tid, u, r, k);
+      bbase[u] = bl.row_base(cx, n0 + r) + k;
+    }
+  }
+
   auto gload = [&](int k0, float (&ra)[NA][4], float (&rb)[NB][4], auto full) {
     constexpr bool FULL = decltype(full)::value;
+    if constexpr (TC) {   // (the tile's contraction length is a whole number of k-tiles)
+      const float* pa = al.ptr() + al.k_off(cx, k0);
+      const float* pb = bl.ptr() + bl.k_off(cx, k0);
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        const float4 t = *reinterpret_cast<const float4*>(pa + abase[u]);
+        ra[u][0] = t.x; ra[u][1] = t.y; ra[u][2] = t.z; ra[u][3] = t.w;
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const float4 t = *reinterpret_cast<const float4*>(pb + bbase[u]);
+        rb[u][0] = t.x; rb[u][1] = t.y; rb[u][2] = t.z; rb[u][3] = t.w;
+      }
+      return;
+    }
     if (a_on) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         int r, k; LA::coord(tid, u, r, k);
-        al.template load4<FULL>(m0 + r, k0 + k, ke, ra[u]);
+        if constexpr (!TC) al.template load4<FULL>(m0 + r, k0 + k, ke, ra[u]);
       }
     }
     if (b_on) {
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         int r, k; LB::coord(tid, u, r, k);
-        bl.template load4<FULL>(n0 + r, k0 + k, ke, rb[u]);
+        if constexpr (!TC) bl.template load4<FULL>(n0 + r, k0 + k, ke, rb[u]);
       }
     }
   };
@@ -936,8 +1101,10 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
         }
         if (!batched) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            ep(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col, acc[a][b][r]);
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (TC) ep.putc(cx, m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col, acc[a][b][r]);
+            else ep(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col, acc[a][b][r]);
+          }
         }
       }
 }
@@ -961,10 +1128,20 @@ inline int gemm_mode() {
 // workgroup per CU): distance 4 (BK 16) beats BK 32 x distance 2 and the fp32 loop.
 template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP>
 void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps, int tm) {
-  if (!xcd_swizzle()) tm = -tm;
-  if (gemm_mode() == 0) {
-    k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-    return;
+  // tile order: 0 plain, 1 contiguous range per XCD, 2 row tiles dealt to the XCDs in turn
+  // (always for tile-context loaders: their row tiles are sorted by cost)
+  const int order = has_tile_ctx<AL>::value ? 2 : xcd_swizzle();
+  if (order == 0) tm = -tm;
+  if (order == 2) {
+    const int tiles_n = (int)grid.x / tm;
+    grid.x = (unsigned)(((tm + 7) & ~7) * tiles_n);
+    tm |= TILES_STRIDED;
+  }
+  if constexpr (!has_tile_ctx<AL>::value) {   // (tile-context loaders: split loop only, the caller checks the mode)
+    if (gemm_mode() == 0) {
+      k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+      return;
+    }
   }
   if (gemm_mode() == 1) {
     if constexpr (BM == 64 && BN == 64)
