@@ -36,6 +36,66 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
                                float* wsp, size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_up: geometry");
+  // Banded implicit form (gemm_core.h, ConvUpAC): class pixels grouped by their valid taps, no
+  // out-of-range tap is multiplied.  Even k: all four parities in one contraction (N = 4*Cb);
+  // odd k: one contraction per parity (the parities have different tap counts).
+  static const int classed = getenv("DD_UP_CLASSED") ? atoi(getenv("DD_UP_CLASSED")) : 1;
+  const bool band_ok = classed && gemm_mode() != 0 && aligned16(small) && aligned16(w) && Cs % 16 == 0 &&
+                       hb <= 128 && wb <= 128 && (k % 2 == 0 ? 4 * Cb >= 64 : Cb >= 64);
+  if (band_ok) {
+    struct Band { int p0, np, t0, nv; };
+    auto bands = [](int npix, int nsrc, int nk, Band* out) {   // consecutive pixels with the same valid taps
+      int nb = 0;
+      for (int j = 0; j < npix; ++j) {
+        const int t0 = j - nsrc + 1 > 0 ? j - nsrc + 1 : 0, t1 = j < nk - 1 ? j : nk - 1;
+        const int nv = t1 >= t0 ? t1 - t0 + 1 : 0, tt = nv ? t0 : 0;
+        if (nb && out[nb - 1].t0 == tt && out[nb - 1].nv == nv) ++out[nb - 1].np;
+        else out[nb++] = Band{j, 1, tt, nv};
+      }
+      return nb;
+    };
+    const int four = k % 2 == 0;
+    bool fits = true;
+    for (int par = 0; par < (four ? 1 : 4) && fits; ++par) {
+      const int py = four ? 0 : par >> 1, px = four ? 0 : par & 1;
+      Band by[64], bx[64];
+      fits = bands((hb - py + 1) / 2, hs, (k - py + 1) / 2, by) * bands((wb - px + 1) / 2, ws_, (k - px + 1) / 2, bx) <= UP_MAXCLS;
+    }
+    if (fits) {
+      for (int par = 0; par < (four ? 1 : 4); ++par) {
+        const int py = four ? 0 : par >> 1, px = four ? 0 : par & 1;
+        const int nj = (hb - py + 1) / 2, ni = (wb - px + 1) / 2;       // class pixels
+        const int nky = (k - py + 1) / 2, nkx = (k - px + 1) / 2;       // taps per axis
+        if (nj <= 0 || ni <= 0) continue;
+        Band by[64], bx[64];
+        const int nby = bands(nj, hs, nky, by), nbx = bands(ni, ws_, nkx, bx);
+        ConvUpAC al{small, n_img, hs, ws_, Cs, nby * nbx, FastDiv(Cs), {}};
+        int tiles = 0, c = 0;
+        for (int a = 0; a < nby; ++a)
+          for (int b = 0; b < nbx; ++b, ++c) {
+            UpCls& u = al.cls[c];
+            u.j0 = (unsigned short)by[a].p0; u.njc = (unsigned short)by[a].np;
+            u.i0 = (unsigned short)bx[b].p0; u.nic = (unsigned short)bx[b].np;
+            u.ty0 = (unsigned char)by[a].t0; u.nvy = (unsigned char)by[a].nv;
+            u.tx0 = (unsigned char)bx[b].t0; u.nvx = (unsigned char)bx[b].nv;
+            if (!u.nvy || !u.nvx) u.nvy = u.nvx = 0;   // no valid tap: bias only
+            u.tile0 = tiles;
+            u.d_ji = FastDiv(by[a].np * bx[b].np); u.d_i = FastDiv(bx[b].np);
+            tiles += dd_ceil_div(n_img * by[a].np * bx[b].np, 128);
+          }
+        const int N = four ? 4 * Cb : Cb, K = nky * nkx * Cs;
+        EpiConvUp4C ep{big, bias, hb, wb, Cb, four, par, FastDiv(Cb)};
+        ConvUpB4C bl{w, Cb, Cs, k, N, four, par, FastDiv(Cs), FastDiv(Cb)};
+        const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
+        if (N > 64)
+          launch_tile<128, 128, true, true>(dim3(tiles * dd_ceil_div(N, 128), 1, 1), st, al, bl, ep, K, kps, tiles);
+        else
+          launch_tile<128, 64, true, true>(dim3(tiles, 1, 1), st, al, bl, ep, K, kps, tiles);
+        DD_CHECK_LAUNCH("dd_conv2d_s2_up");
+      }
+      return 0;
+    }
+  }
   const int kkc = k * k * Cb;
   const size_t per_img = (size_t)hs * ws_ * kkc * sizeof(float);
   // GEMM + col2im instead of the implicit parity form when (a) there are few output
@@ -75,51 +135,6 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
     return 0;
   }
   const int vec = aligned16(small) && aligned16(w) && (Cs % 4 == 0);
-  static const int classed = getenv("DD_UP_CLASSED") ? atoi(getenv("DD_UP_CLASSED")) : 1;
-  if (uni_ok && classed && gemm_mode() != 0 && Cs % 16 == 0) {
-    // all parities in one contraction, class pixels in bands of equal tap rectangle
-    const int nj = (hb + 1) / 2, ni = (wb + 1) / 2, nk = k / 2;
-    struct Band { int p0, np, t0, nv; };
-    auto bands = [&](int npix, int nsrc, Band* out) {   // consecutive pixels with the same valid taps
-      int nb = 0;
-      for (int j = 0; j < npix; ++j) {
-        const int t0 = j - nsrc + 1 > 0 ? j - nsrc + 1 : 0, t1 = j < nk - 1 ? j : nk - 1;
-        const int nv = t1 >= t0 ? t1 - t0 + 1 : 0, tt = nv ? t0 : 0;
-        if (nb && out[nb - 1].t0 == tt && out[nb - 1].nv == nv) ++out[nb - 1].np;
-        else out[nb++] = Band{j, 1, tt, nv};
-      }
-      return nb;
-    };
-    Band by[64], bx[64];
-    DD_REQUIRE(nj <= 64 && ni <= 64, "dd_conv2d_s2_up: image too large for the band table");
-    const int nby = bands(nj, hs, by), nbx = bands(ni, ws_, bx);
-    if (nby * nbx <= UP_MAXCLS) {
-      ConvUpAC al{small, n_img, hs, ws_, Cs, nby * nbx, FastDiv(Cs), {}};
-      int tiles = 0, c = 0;
-      for (int a = 0; a < nby; ++a)
-        for (int b = 0; b < nbx; ++b, ++c) {
-          UpCls& u = al.cls[c];
-          u.j0 = (unsigned short)by[a].p0; u.njc = (unsigned short)by[a].np;
-          u.i0 = (unsigned short)bx[b].p0; u.nic = (unsigned short)bx[b].np;
-          u.ty0 = (unsigned char)by[a].t0; u.nvy = (unsigned char)by[a].nv;
-          u.tx0 = (unsigned char)bx[b].t0; u.nvx = (unsigned char)bx[b].nv;
-          if (!u.nvy || !u.nvx) u.nvy = u.nvx = 0;   // no valid tap: bias only
-          u.tile0 = tiles;
-          u.d_ji = FastDiv(by[a].np * bx[b].np); u.d_i = FastDiv(bx[b].np);
-          tiles += dd_ceil_div(n_img * by[a].np * bx[b].np, 128);
-        }
-      const int N = 4 * Cb, K = nk * nk * Cs;
-      EpiConvUp4C ep{big, bias, hb, wb, Cb, FastDiv(Cb)};
-      ConvUpB4C bl{w, Cb, Cs, k, N, FastDiv(Cs), FastDiv(Cb)};
-      const int kps = ((K + BKBIG - 1) / BKBIG) * BKBIG + BKBIG;
-      if (N > 64)
-        launch_tile<128, 128, true, true>(dim3(tiles * dd_ceil_div(N, 128), 1, 1), st, al, bl, ep, K, kps, tiles);
-      else
-        launch_tile<128, 64, true, true>(dim3(tiles, 1, 1), st, al, bl, ep, K, kps, tiles);
-      DD_CHECK_LAUNCH("dd_conv2d_s2_up");
-      return 0;
-    }
-  }
   if (uni_ok) {  // all parities in one contraction
     const int nj = (hb + 1) / 2, ni = (wb + 1) / 2, nk = k / 2;
     const int M = n_img * nj * ni, N = 4 * Cb, K = nk * nk * Cs;

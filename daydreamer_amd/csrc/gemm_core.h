@@ -523,14 +523,18 @@ struct ConvUpAC {
   }
 };
 
+// filter operand of the banded form.  four: column n = (py, px, cb), all parities in one
+// contraction (even k); else one parity (py, px) per launch, column n = cb (odd k: the
+// parities have different tap counts).
 struct ConvUpB4C {
-  const float* w; int Cb, Cs, kw, R;
+  const float* w; int Cb, Cs, kw, R, four, par;   // par = 2*py + px when !four
   FastDiv d_cs, d_cb;
   __device__ __forceinline__ const float* ptr() const { return w; }
   __device__ __forceinline__ long row_base(const UpCtx&, int r) const {
     const int rr = min(r, R - 1);
     int q, cb;
-    d_cb.divmod(rr, q, cb);
+    if (four) d_cb.divmod(rr, q, cb);
+    else { q = par; cb = rr; }
     return ((long)((q >> 1) * kw + (q & 1)) * Cb + cb) * Cs;
   }
   __device__ __forceinline__ int k_off(const UpCtx& cx, int k0) const {
@@ -541,15 +545,16 @@ struct ConvUpB4C {
   }
 };
 
-struct EpiConvUp4C {  // column n = (py, px, cb); rows band-local
-  float* big; const float* bias; int hb, wb, Cb;
+struct EpiConvUp4C {  // rows band-local; column n = (py, px, cb) or cb (see ConvUpB4C)
+  float* big; const float* bias; int hb, wb, Cb, four, par;
   FastDiv d_cb;
   __device__ __forceinline__ void putc(const UpCtx& cx, int rl, int n, float v) const {
-    if (rl >= cx.rows || n >= 4 * Cb) return;
+    if (rl >= cx.rows || n >= (four ? 4 * Cb : Cb)) return;
     int img, rem, jj, ii, q, cb;
     cx.d_ji.divmod(rl, img, rem);
     cx.d_i.divmod(rem, jj, ii);
-    d_cb.divmod(n, q, cb);
+    if (four) d_cb.divmod(n, q, cb);
+    else { q = par; cb = n; }
     const int y = 2 * (cx.j0 + jj) + (q >> 1), x = 2 * (cx.i0 + ii) + (q & 1);
     if (y >= hb || x >= wb) return;
     big[(((long)img * hb + y) * wb + x) * Cb + cb] = bias ? v + bias[cb] : v;

@@ -131,7 +131,11 @@ CONVS = [  # n, hb, Cb, hs, Cs, k, u8
     (2, 14, 32, 6, 64, 4, False), (5, 6, 64, 2, 128, 4, False),
     (4, 5, 64, 1, 320, 5, False), (3, 13, 32, 5, 64, 5, False),
     (2, 30, 16, 13, 32, 6, False), (2, 64, 3, 30, 16, 6, False),
-    (2, 128, 6, 64, 32, 2, False), (1, 64, 3, 31, 16, 4, False), (2, 20, 5, 8, 12, 5, False)]
+    (2, 128, 6, 64, 32, 2, False), (1, 64, 3, 31, 16, 4, False), (2, 20, 5, 8, 12, 5, False),
+    # the model's own layer geometry (banded transposed conv: all four parities for even k with an
+    # output row that only receives the bias at 31 = 2*13 + 4 + 1, one contraction per parity for odd k)
+    (3, 13, 128, 5, 256, 5, False), (2, 30, 64, 13, 128, 6, False), (2, 31, 64, 14, 128, 4, False),
+    (3, 14, 128, 6, 256, 4, False), (130, 6, 64, 2, 64, 4, False), (2, 9, 64, 3, 32, 5, False)]
 
 
 @pytest.mark.parametrize('n,hb,Cb,hs,Cs,k,u8', CONVS)
