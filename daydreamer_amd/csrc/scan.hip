@@ -612,6 +612,358 @@ k_observe_scan_fwd(ScanArgs a) {
 #undef TS
 #undef TSW
 
+// ===========================================================================================
+// Fused reverse scan: the data-gradient backward of the T obs_steps in one persistent launch.
+//
+// Reference: the gradient tf.GradientTape derives for RSSM.observe (nets.py:66-76, 99-160); the
+// launch sequence it replaces is Learner.observe_bwd's loop (stats_bwd, obs_stats dgrad,
+// LN-ELU bwd, obs_out dgrad, GRU bwd, GRU dgrad, LN-ELU bwd, img_in dgrad, reset mask).
+// Same decomposition as the forward scan (4 row blocks x 16 column strides, consumer-side
+// row-wise work, weight planes prefetched during the barrier); per step t = T-1 .. 0:
+//   Q1  dxo   = dxq_t @ W_stats^T                                       (K = S)
+//   Q2  dzo   = LN-ELU'(dxo; zo, xo);  ddeter_t += dzo @ W_out_h^T      (K = U)
+//   Q3  dz3, dy3, dh = GRU'(ddeter_t; z3, hprev);  [dh | dx1] += dz3 @ W_gru^T   (K = 3D)
+//       dfeat[t-1, :D] += (1 - first_t) * dh
+//   Q4  dz1   = LN-ELU'(dx1; z1, x1);  dxs = dz1 @ W_in_s^T             (K = U)
+//       dfeat[t-1, D:] += (1 - first_t) * dxs;  dxq_{t-1} = stats'(xq_{t-1}; dlogit, dfeat[t-1, D:])
+// dxq_{T-1} comes from the caller (dd_stats_sample_bwd on the last step's rows).  Every buffer
+// the bulk weight-gradient contractions read afterwards (dxq, dxo, dzo, dz3, dy3, [dh | dx1], dz1,
+// dxs) is written as the launch sequence writes it.
+struct ScanBwdArgs {
+  int B, T, flags;
+  float unimix;
+  const float* first;      // [N]
+  // forward activations (rows b*T + t)
+  const float *xq, *zo, *xo, *st3, *z3, *gst, *gin, *z1, *st1;
+  const float* dlogit;     // [N, S] KL gradient w.r.t. the posterior logits
+  // weight planes [3][N][K] (rows = output columns of the backward contraction)
+  const unsigned short *w1, *w2, *w3, *w4;
+  const float *g3, *gg, *bg, *g1;   // LayerNorm scales (GRU: scale and offset)
+  // gradients
+  float* dfeat;            // [N, D+S] in/out
+  float* dxq;              // [N, S]
+  float* dxo;              // [N, U]
+  float* dzo;              // [N, U]
+  float* dz3;              // [N, 3D]
+  float* dy3;              // [N, 3D]
+  float* dgin;             // [N, D+U]  [dh | dx1]
+  float* dz1;              // [N, U]
+  float* dxs;              // [N, S]
+  unsigned* ctr;
+};
+
+// two row sums at once (see row_reduce)
+__device__ __forceinline__ void row_reduce2(float& a, float& b, float (*ws)[2][16]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+  a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+  if (lane < 16) { ws[wave][0][lane] = a; ws[wave][1][lane] = b; }
+  __syncthreads();
+  const int l = lane & 15;
+  a = (ws[0][0][l] + ws[1][0][l]) + (ws[2][0][l] + ws[3][0][l]);
+  b = (ws[0][1][l] + ws[1][1][l]) + (ws[2][1][l] + ws[3][1][l]);
+}
+
+// sum over the 16 lanes that hold one row of a finished tile (lanes with equal lane >> 4)
+__device__ __forceinline__ float tile_row_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 16);
+  return v;
+}
+__device__ __forceinline__ float tile_row_max(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 16));
+  return v;
+}
+
+// LayerNorm + ELU backward on the operand registers (k_ln_act_bwd): dy at the ELU output ->
+// dz at the LayerNorm input, W = row width, NIT k-steps of this lane.
+template <int W, int NIT>
+__device__ __forceinline__ void ln_elu_bwd(const float (&dy)[NIT][8], const float (&z)[NIT][8],
+                                           const float (&o)[NIT][8], float mean, float rstd,
+                                           const float* gamma_lds, int kq, float (*ws)[2][16],
+                                           float (&dz)[NIT][8]) {
+  float g[NIT][8], xh[NIT][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    float gm[8];
+    ld8(gamma_lds + it * 128 + kq, gm);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = dy[it][j] * (o[it][j] > 0.f ? 1.f : o[it][j] + 1.f);
+      xh[it][j] = (z[it][j] - mean) * rstd;
+      g[it][j] = d * gm[j];
+      s1 += g[it][j];
+      s2 += g[it][j] * xh[it][j];
+    }
+  }
+  row_reduce2(s1, s2, ws);
+  s1 /= (float)W; s2 /= (float)W;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dz[it][j] = rstd * (g[it][j] - s1 - xh[it][j] * s2);
+}
+
+#define TSB(i)                                                                             \
+  if ((a.flags & 64) && blockIdx.x == 0 && threadIdx.x == 0 && t == 10)                     \
+  reinterpret_cast<unsigned long long*>(a.ctr + 2)[i] = wall_clock64()
+
+template <int D, int U, int G, int C>
+__global__ void __launch_bounds__(256, 1)
+k_observe_scan_bwd(ScanBwdArgs a) {
+  constexpr int S = G * C, F = D + S;
+  static_assert(D % 128 == 0 && U % 128 == 0 && C % 16 == 0, "dims");
+  static_assert(U / 16 == NSTR && D / 16 == NSTR && G % NSTR == 0,
+                "one column tile per workgroup in Q1 / Q2, whole groups in Q4");
+  constexpr int T3 = (D + U) / 16 / NSTR;        // Q3 column tiles per workgroup ([dh | dx1])
+  constexpr int TPG = C / 16, GPP = G / NSTR, T4 = GPP * TPG;
+  constexpr int TMAX = cmax_(T3, T4);
+  constexpr int NIT1 = S / 128, NIT2 = U / 128, NIT3 = 3 * D / 128, NIT4 = U / 128, ND = D / 128;
+  __shared__ float red[TMAX][4][256];
+  constexpr int O_G3 = 0, O_GG = U, O_BG = O_GG + 3 * D, O_G1 = O_BG + 3 * D, NPAR = O_G1 + U;
+  __shared__ __attribute__((aligned(16))) float par[NPAR];
+  __shared__ __attribute__((aligned(16))) float dh_lds[16][D + 4];   // Q3: (1 - update) * dhn of the row block
+  __shared__ float ws_a[4][2][16], ws_b[4][2][16];
+  for (int i = threadIdx.x; i < NPAR; i += 256) {
+    float v;
+    if (i < O_GG) v = a.g3[i];
+    else if (i < O_BG) v = a.gg[i - O_GG];
+    else if (i < O_G1) v = a.bg[i - O_BG];
+    else v = a.g1[i - O_G1];
+    par[i] = v;
+  }
+  const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mblk = wg & 3, nstr = wg >> 2;
+  const int T = a.T;
+  const int orow = ((lane >> 4) * 4) + (tid >> 6), ocol = tid & 15;
+  const int ob = mblk * 16 + orow;
+  const bool olive = ob < a.B;
+  const int ab = min(mblk * 16 + (lane & 15), a.B - 1);
+  const bool alive = mblk * 16 + (lane & 15) < a.B;
+  const int kq = (lane >> 4) * 8 + wave * 32;
+  const long pl1 = (long)U * S, pl2 = (long)D * U, pl3 = (long)(D + U) * 3 * D, pl4 = (long)S * U;
+  const float um = 1.f - a.unimix;
+  unsigned gen = 0;
+  __syncthreads();
+  uint4 bq1[1][NIT1][3];
+  load_planes<NIT1>(bq1[0], a.w1, pl1, S, nstr * 16);
+  for (int t = T - 1; t >= 0; --t) {
+    const long arow = (long)ab * T + t;
+    const long oidx = (long)ob * T + t;
+    TSB(0);
+    // ---------------- Q1: dxo = dxq_t @ W_stats^T
+    {
+      float raw[NIT1][8];
+#pragma unroll
+      for (int it = 0; it < NIT1; ++it) ld8(a.dxq + arow * S + it * 128 + kq, raw[it]);
+      bf16x8 afr[NIT1][3];
+#pragma unroll
+      for (int it = 0; it < NIT1; ++it) split8(raw[it], afr[it]);
+      float out[1];
+      tiles_gemm<S, 1>(afr, bq1, red, out);
+      if (olive) a.dxo[oidx * U + nstr * 16 + ocol] = out[0];
+    }
+    TSB(1);
+    uint4 bq2[1][NIT2][3];
+    grid_barrier(a.ctr, ++gen * NWG, [&] { load_planes<NIT2>(bq2[0], a.w2, pl2, U, nstr * 16); });
+    TSB(2);
+
+    // ---------------- Q2: dzo = LN-ELU'(dxo);  ddeter_t += dzo @ W_out_h^T
+    {
+      float dy[NIT2][8], z[NIT2][8], o[NIT2][8], dz[NIT2][8];
+#pragma unroll
+      for (int it = 0; it < NIT2; ++it) {
+        const int k = it * 128 + kq;
+        ld8(a.dxo + arow * U + k, dy[it]); ld8(a.zo + arow * U + k, z[it]); ld8(a.xo + arow * U + k, o[it]);
+      }
+      const float2 st = *reinterpret_cast<const float2*>(a.st3 + arow * 2);
+      const float dold = olive ? a.dfeat[oidx * F + nstr * 16 + ocol] : 0.f;
+      ln_elu_bwd<U, NIT2>(dy, z, o, st.x, st.y, par + O_G3, kq, ws_a, dz);
+      store_chunks<NIT2>(dz, a.dzo + arow * U, kq, nstr, alive);
+      bf16x8 afr[NIT2][3];
+#pragma unroll
+      for (int it = 0; it < NIT2; ++it) split8(dz[it], afr[it]);
+      float out[1];
+      tiles_gemm<U, 1>(afr, bq2, red, out);
+      if (olive) a.dfeat[oidx * F + nstr * 16 + ocol] = dold + out[0];
+    }
+    TSB(3);
+    uint4 bq3[T3][NIT3][3];
+    grid_barrier(a.ctr, ++gen * NWG, [&] {
+#pragma unroll
+      for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.w3, pl3, 3 * D, (nstr + NSTR * j) * 16);
+    });
+    TSB(4);
+
+    // ---------------- Q3: GRU backward;  [dh | dx1] = [(1-u) dhn | 0] + dz3 @ W_gru^T
+    {
+      float d[ND][8], z0[ND][8], z1_[ND][8], z2[ND][8], hp[ND][8];
+      const float* zr = a.z3 + arow * 3 * D;
+#pragma unroll
+      for (int it = 0; it < ND; ++it) {
+        const int k = it * 128 + kq;
+        ld8(a.dfeat + arow * F + k, d[it]);
+        ld8(zr + k, z0[it]); ld8(zr + D + k, z1_[it]); ld8(zr + 2 * D + k, z2[it]);
+        ld8(a.gin + arow * (D + U) + k, hp[it]);
+      }
+      const float2 st = *reinterpret_cast<const float2*>(a.gst + arow * 2);
+      const float mean = st.x, rstd = st.y;
+      const float fo = olive ? a.first[oidx] : 1.f;
+      float dprev[T3];
+#pragma unroll
+      for (int j = 0; j < T3; ++j) {
+        const int col = (nstr + NSTR * j) * 16 + ocol;
+        dprev[j] = (olive && t > 0 && col < D) ? a.dfeat[(oidx - 1) * F + col] : 0.f;
+      }
+      float dy[NIT3][8], xh[NIT3][8], g[NIT3][8], dhd[ND][8];   // index q * ND + it: gate q
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int it = 0; it < ND; ++it) {
+        const int k = it * 128 + kq;
+        float g0[8], g1_[8], g2[8], b0[8], b1_[8], b2[8];
+        ld8(par + O_GG + k, g0); ld8(par + O_GG + D + k, g1_); ld8(par + O_GG + 2 * D + k, g2);
+        ld8(par + O_BG + k, b0); ld8(par + O_BG + D + k, b1_); ld8(par + O_BG + 2 * D + k, b2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xr = (z0[it][j] - mean) * rstd, xc = (z1_[it][j] - mean) * rstd,
+                      xu = (z2[it][j] - mean) * rstd;
+          const float yr = xr * g0[j] + b0[j], yc = xc * g1_[j] + b1_[j], yu = xu * g2[j] + b2[j];
+          const float r = fsigmoid_(yr), cand = ftanh_(r * yc), u = fsigmoid_(yu - 1.f);
+          const float dd = d[it][j];
+          const float du = dd * (cand - hp[it][j]), dc = dd * u;
+          dhd[it][j] = dd * (1.f - u);
+          const float dpre = dc * (1.f - cand * cand);
+          const float dyc = dpre * r, dyr = dpre * yc * r * (1.f - r), dyu = du * u * (1.f - u);
+          dy[it][j] = dyr; dy[ND + it][j] = dyc; dy[2 * ND + it][j] = dyu;
+          xh[it][j] = xr; xh[ND + it][j] = xc; xh[2 * ND + it][j] = xu;
+          g[it][j] = dyr * g0[j]; g[ND + it][j] = dyc * g1_[j]; g[2 * ND + it][j] = dyu * g2[j];
+          s1 += (g[it][j] + g[ND + it][j]) + g[2 * ND + it][j];
+          s2 += (g[it][j] * xr + g[ND + it][j] * xc) + g[2 * ND + it][j] * xu;
+        }
+      }
+      store_chunks<NIT3>(dy, a.dy3 + arow * 3 * D, kq, nstr, alive);
+      row_reduce2(s1, s2, ws_b);
+      s1 /= (float)(3 * D); s2 /= (float)(3 * D);
+      float dz[NIT3][8];
+      bf16x8 afr[NIT3][3];
+#pragma unroll
+      for (int i = 0; i < NIT3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dz[i][j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        split8(dz[i], afr[i]);
+      }
+      store_chunks<NIT3>(dz, a.dz3 + arow * 3 * D, kq, nstr, alive);
+      // the direct path (1 - update) * dhn of the whole row block, for the tile epilogue
+#pragma unroll
+      for (int it = 0; it < ND; ++it) {
+        float* q = &dh_lds[lane & 15][it * 128 + kq];
+        *reinterpret_cast<float4*>(q) = make_float4(dhd[it][0], dhd[it][1], dhd[it][2], dhd[it][3]);
+        *reinterpret_cast<float4*>(q + 4) = make_float4(dhd[it][4], dhd[it][5], dhd[it][6], dhd[it][7]);
+      }
+      float out[T3];
+      tiles_gemm<3 * D, T3>(afr, bq3, red, out);   // (its barriers order the dh_lds writes before the reads)
+#pragma unroll
+      for (int j = 0; j < T3; ++j) {
+        const int col = (nstr + NSTR * j) * 16 + ocol;
+        if (olive) {
+          if (col < D) {
+            const float dh = dh_lds[orow][col] + out[j];
+            a.dgin[oidx * (D + U) + col] = dh;
+            if (t > 0) a.dfeat[(oidx - 1) * F + col] = dprev[j] + dh * (1.f - fo);
+          } else {
+            a.dgin[oidx * (D + U) + col] = out[j];
+          }
+        }
+      }
+    }
+    TSB(5);
+    uint4 bq4[T4][NIT4][3];
+    grid_barrier(a.ctr, ++gen * NWG, [&] {
+#pragma unroll
+      for (int j = 0; j < T4; ++j)
+        load_planes<NIT4>(bq4[j], a.w4, pl4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
+    });
+    TSB(6);
+
+    // ---------------- Q4: dz1 = LN-ELU'(dx1);  dxs = dz1 @ W_in_s^T;  mask;  dxq_{t-1}
+    {
+      float dy[NIT4][8], z[NIT4][8], o[NIT4][8], dz[NIT4][8];
+#pragma unroll
+      for (int it = 0; it < NIT4; ++it) {
+        const int k = it * 128 + kq;
+        ld8(a.dgin + arow * (D + U) + D + k, dy[it]); ld8(a.z1 + arow * U + k, z[it]);
+        ld8(a.gin + arow * (D + U) + D + k, o[it]);
+      }
+      const float2 st = *reinterpret_cast<const float2*>(a.st1 + arow * 2);
+      // the previous step's stats inputs at this thread's tile elements
+      const float fo = olive ? a.first[oidx] : 1.f;
+      float xv[T4], dl[T4], dsold[T4];
+#pragma unroll
+      for (int j = 0; j < T4; ++j) {
+        const int col = (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16 + ocol;
+        const bool on = olive && t > 0;
+        xv[j] = on ? a.xq[(oidx - 1) * S + col] : 0.f;
+        dl[j] = on ? a.dlogit[(oidx - 1) * S + col] : 0.f;
+        dsold[j] = on ? a.dfeat[(oidx - 1) * F + D + col] : 0.f;
+      }
+      ln_elu_bwd<U, NIT4>(dy, z, o, st.x, st.y, par + O_G1, kq, ws_a, dz);
+      store_chunks<NIT4>(dz, a.dz1 + arow * U, kq, nstr, alive);
+      bf16x8 afr[NIT4][3];
+#pragma unroll
+      for (int it = 0; it < NIT4; ++it) split8(dz[it], afr[it]);
+      float out[T4];
+      tiles_gemm<U, T4>(afr, bq4, red, out);
+#pragma unroll
+      for (int j = 0; j < T4; ++j) {
+        const int col = (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16 + ocol;
+        if (olive) a.dxs[oidx * S + col] = out[j];
+      }
+      if (t > 0) {
+        // stats backward of step t-1 for this workgroup's groups (k_stats_bwd): the softmax of a
+        // (row, group) spans the TPG tiles of the group, 16 lanes each
+#pragma unroll
+        for (int gi = 0; gi < GPP; ++gi) {
+          float m = -INFINITY;
+#pragma unroll
+          for (int q = 0; q < TPG; ++q) m = fmaxf(m, xv[gi * TPG + q]);
+          m = tile_row_max(m);
+          float e[TPG], sum = 0.f;
+#pragma unroll
+          for (int q = 0; q < TPG; ++q) { e[q] = dd_exp_det(xv[gi * TPG + q] - m); sum += e[q]; }
+          sum = tile_row_sum(sum);
+          float pr[TPG], dp[TPG], dot = 0.f, ds[TPG];
+#pragma unroll
+          for (int q = 0; q < TPG; ++q) {
+            const int j = gi * TPG + q;
+            pr[q] = e[q] / sum;
+            const float pm = dd_unimix_prob(e[q], sum, a.unimix, C);
+            ds[q] = dsold[j] + out[j] * (1.f - fo);
+            dp[q] = um * (ds[q] + dl[j] / pm);
+            dot += dp[q] * pr[q];
+          }
+          dot = tile_row_sum(dot);
+#pragma unroll
+          for (int q = 0; q < TPG; ++q) {
+            const int j = gi * TPG + q;
+            const int col = (nstr + NSTR * gi) * C + q * 16 + ocol;
+            if (olive) {
+              a.dfeat[(oidx - 1) * F + D + col] = ds[q];
+              a.dxq[(oidx - 1) * S + col] = pr[q] * (dp[q] - dot);
+            }
+            (void)j;
+          }
+        }
+      }
+    }
+    TSB(7);
+    grid_barrier(a.ctr, ++gen * NWG, [&] { load_planes<NIT1>(bq1[0], a.w1, pl1, S, nstr * 16); });
+    TSB(8);
+  }
+}
+#undef TSB
+
 // class index of every one-hot group: idx[r][g] = argmax_c x[r][g*C + c]
 // -1 for an all-zero group (the zero state); a group that is neither one-hot nor zero cannot
 // go through the gather form of P1: error word 2.
@@ -647,7 +999,61 @@ __global__ void k_scan_wprep(const float* __restrict__ W, long ld, int K, int N,
   }
 }
 
+// Weight cache of the reverse scan: W [N, K] fp32 (row stride ld; the backward contraction
+// multiplies by W^T, so the cache rows are W's rows) -> three bf16 planes [3][N][K].
+__global__ void k_scan_wprep_rows(const float* __restrict__ W, long ld, int N, int K,
+                                  unsigned short* __restrict__ out) {
+  const long total = (long)N * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    unsigned h, m, l;
+    split3(W[(long)n * ld + k], h, m, l);
+    out[i] = (unsigned short)(h >> 16);
+    out[total + i] = (unsigned short)(m >> 16);
+    out[2 * total + i] = (unsigned short)(l >> 16);
+  }
+}
+
 }  // namespace
+
+extern "C" int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* planes, void* stream) {
+  DD_REQUIRE(N > 0 && K > 0 && K % 8 == 0, "dd_scan_wprep_rows: shape");
+  const long total = (long)N * K;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  k_scan_wprep_rows<<<blocks, 256, 0, (hipStream_t)stream>>>(W, ld, N, K, (unsigned short*)planes);
+  DD_CHECK_LAUNCH("dd_scan_wprep_rows");
+  return 0;
+}
+
+extern "C" int dd_observe_scan_bwd(
+    int B, int T, int D, int U, int G, int C, int flags, float unimix, const float* first,
+    const float* xq, const float* zo, const float* xo, const float* st3, const float* z3,
+    const float* gst, const float* gin, const float* z1, const float* st1, const float* dlogit,
+    const void* w1, const void* w2, const void* w3, const void* w4,
+    const float* g3, const float* gg, const float* bg, const float* g1,
+    float* dfeat, float* dxq, float* dxo, float* dzo, float* dz3, float* dy3, float* dgin,
+    float* dz1, float* dxs, unsigned* sync2, void* stream) {
+  DD_REQUIRE(dd_observe_scan_supported(B, D, U, G, C, 16), "dd_observe_scan_bwd: unsupported shape");
+  hipStream_t st = (hipStream_t)stream;
+  ScanBwdArgs a;
+  a.B = B; a.T = T; a.flags = flags; a.unimix = unimix; a.first = first;
+  a.xq = xq; a.zo = zo; a.xo = xo; a.st3 = st3; a.z3 = z3; a.gst = gst; a.gin = gin; a.z1 = z1; a.st1 = st1;
+  a.dlogit = dlogit;
+  a.w1 = (const unsigned short*)w1; a.w2 = (const unsigned short*)w2;
+  a.w3 = (const unsigned short*)w3; a.w4 = (const unsigned short*)w4;
+  a.g3 = g3; a.gg = gg; a.bg = bg; a.g1 = g1;
+  a.dfeat = dfeat; a.dxq = dxq; a.dxo = dxo; a.dzo = dzo; a.dz3 = dz3; a.dy3 = dy3; a.dgin = dgin;
+  a.dz1 = dz1; a.dxs = dxs; a.ctr = sync2;
+  hipError_t e = hipMemsetAsync(sync2, 0, 2 * sizeof(unsigned), st);
+  if (e != hipSuccess) { dd_set_error("dd_observe_scan_bwd(memset)", e); return (int)e; }
+  if (D == 256 && U == 256 && G == 32 && C == 32)
+    k_observe_scan_bwd<256, 256, 32, 32><<<NWG, 256, 0, st>>>(a);
+  else
+    DD_REQUIRE(false, "dd_observe_scan_bwd: shape not compiled");
+  DD_CHECK_LAUNCH("dd_observe_scan_bwd");
+  return 0;
+}
 
 extern "C" int dd_scan_wprep(const float* W, long ld, int K, int N, int Kp, void* planes, void* stream) {
   DD_REQUIRE(Kp >= K && Kp % 32 == 0 && N % 16 == 0, "dd_scan_wprep: Kp multiple of 32 >= K, N multiple of 16");

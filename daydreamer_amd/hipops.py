@@ -43,6 +43,8 @@ _SIGS = {
     'dd_observe_scan_supported': [c_i] * 6,
     'dd_scan_wprep': [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     'dd_observe_scan_fwd': [c_i] * 8 + [c_f] + [c_p] * 32,
+    'dd_scan_wprep_rows': [c_p, c_l, c_i, c_i, c_p, c_p],
+    'dd_observe_scan_bwd': [c_i] * 7 + [c_f] + [c_p] * 30,
     'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_f, c_p, c_p],
     'dd_onehot_sample_host': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i],
     'dd_stats_sample_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
@@ -352,6 +354,25 @@ class HipOps:
         *[w.data_ptr() for w in wts], *[v.data_ptr() for v in vecs],
         *[t.data_ptr() for t in bufs], w_in.data_ptr(), idx_ws.data_ptr(), sync2.data_ptr(),
         self.stream), 'dd_observe_scan_fwd')
+
+  def scan_wprep_rows(self, W, planes):
+    """Weight cache of the fused reverse scan: W [N, K] fp32 -> bf16 planes [3, N, K]."""
+    N, K = W.shape
+    assert W.stride(1) == 1 and planes.dtype == torch.int16 and planes.numel() == 3 * N * K
+    self._check(self.lib.dd_scan_wprep_rows(W.data_ptr(), W.stride(0), N, K, planes.data_ptr(),
+                                            self.stream), 'dd_scan_wprep_rows')
+
+  def observe_scan_bwd(self, B, T, D, U, G, C, flags, unimix, first, acts, dlogit, wts, vecs, grads,
+                       sync2):
+    """acts: xq, zo, xo, st3, z3, gst, gin, z1, st1; wts: 4 row-plane caches (obs_stats,
+    obs_out_h, gru, img_in_s); vecs: g3, gg, bg, g1; grads: dfeat, dxq, dxo, dzo, dz3, dy3, dgin,
+    dz1, dxs (all contiguous, rows b*T + t)."""
+    for t in list(acts) + list(grads) + [dlogit]:
+      assert t.is_contiguous()
+    self._check(self.lib.dd_observe_scan_bwd(
+        B, T, D, U, G, C, int(flags), unimix, first.data_ptr(), *[t.data_ptr() for t in acts],
+        dlogit.data_ptr(), *[w.data_ptr() for w in wts], *[v.data_ptr() for v in vecs],
+        *[t.data_ptr() for t in grads], sync2.data_ptr(), self.stream), 'dd_observe_scan_bwd')
 
   # ---- categorical latent -----------------------------------------------------
 

@@ -361,6 +361,7 @@ class Learner:
     # carry state between train calls
     b['carry'] = z(B, F)
     # fused observe scan (csrc/scan.hip): transposed bf16 weight planes + barrier words
+    self.fused_scan_bwd = False
     self.fused_scan = (bool(self.cfg.get('hip', {}).get('fused_scan', True)) and
                        self.dtype == torch.float32 and hasattr(self.ops, 'observe_scan_fwd') and
                        self.ops.observe_scan_supported(B, D, U, G, self.C, A))
@@ -371,6 +372,9 @@ class Learner:
                      (self.P['gru'].W, i16(3 * 3 * D * (D + U)), D + U),
                      (self.P['obs_out_h'].W, i16(3 * U * D), D),
                      (self.P['obs_stats'].W, i16(3 * S * U), U)]
+      self.fused_scan_bwd = bool(self.cfg.get('hip', {}).get('fused_scan_bwd', True)) and hasattr(self.ops, 'observe_scan_bwd')
+      self.scan_wb = [(self.P['obs_stats'].W, i16(3 * U * S)), (self.P['obs_out_h'].W, i16(3 * D * U)),
+                      (self.P['gru'].W, i16(3 * (D + U) * 3 * D)), (self.P['img_in_s'].W, i16(3 * S * U))]
       self.scan_sync = torch.zeros(64 + 2 * 4 * 64, dtype=torch.int32, device=self.device)   # counter, error word, debug stamps
       self.scan_idx = torch.zeros((N + B + 1) * G, dtype=torch.int32, device=self.device)
     # ---- heads on the posterior
@@ -773,6 +777,27 @@ class Learner:
          self.a_obs_out.z, self.a_obs_out.out, self.a_obs_out.stats, self.a_obs_stats.z,
          b['post_logit']], P['img_in'].W, self.scan_idx, self.scan_sync)
 
+  def observe_scan_bwd_fused(self):
+    """The data gradient of the T obs_steps as one persistent launch (dd_observe_scan_bwd): same
+    buffers as the launch sequence below, same values up to the summation order of the small
+    contractions."""
+    ops, b, P = self.ops, self.b, self.P
+    B, T, D = self.B, self.T, self.D
+    last = lambda buf: buf.view(B, T, -1)[:, T - 1]
+    Aq, Ao, Ai = self.a_obs_stats, self.a_obs_out, self.a_img_in
+    ops.stats_bwd(last(Aq.z), last(b['dpost_logit']), b['dfeat'].view(B, T, -1)[:, T - 1, D:],
+                  last(Aq.dout), self.G, self.C, self.unimix)
+    for W, planes in self.scan_wb:   # (the weights of this step: unchanged since the forward scan)
+      ops.scan_wprep_rows(W, planes)
+    g = P['gru_h']
+    ops.observe_scan_bwd(
+        B, T, D, self.U, self.G, self.C, 0, self.unimix, b['first'],
+        [Aq.z, Ao.z, Ao.out, Ao.stats, b['z3'], b['gstats'], b['gin'], Ai.z, Ai.stats],
+        b['dpost_logit'], [w[1] for w in self.scan_wb],
+        [P['obs_out_h'].gamma, g.gamma, g.beta, P['img_in'].gamma],
+        [b['dfeat'], Aq.dout, Ao.dout, Ao.dz, b['dz3'], b['dy3'], b['dgin'], Ai.dz, b['dxin_s']],
+        self.scan_sync)
+
   def observe_fwd(self, use_carry=True):
     ops, b = self.ops, self.b
     B, T, D, S, F = self.B, self.T, self.D, self.S, self.F
@@ -830,7 +855,9 @@ class Learner:
                   self.a_img_stats.dout, self.G, self.C, self.unimix)
     self.prior_bwd(b['post'][:, :D], b['dfeat'][:, :D], self.a_img_out,
                    self.a_img_stats, None, params=True)
-    for t in reversed(range(T)):
+    if self.fused_scan_bwd:
+      self.observe_scan_bwd_fused()
+    for t in (() if self.fused_scan_bwd else reversed(range(T))):
       sel = bt(t)
       ddeter, dstoch = dfeat[:, t, :D], dfeat[:, t, D:]
       # posterior sample + statistics

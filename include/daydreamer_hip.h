@@ -156,6 +156,29 @@ int dd_observe_scan_fwd(
     float* xo, float* st3, float* xq, float* post_logit, const float* w_in, int* idx_ws,
     unsigned* sync2, void* stream);
 
+/* Weight cache of the reverse scan: W [N, K] fp32 (row stride ld) -> bf16 planes [3][N][K]
+ * (the backward contractions multiply by W^T: cache rows = W's rows). */
+int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* planes, void* stream);
+
+/* Fused reverse observe scan: the data gradient of the T obs_steps (what tf.GradientTape derives
+ * for RSSM.observe, nets.py:66-76,99-160) in one persistent launch; replaces the per-step launch
+ * sequence stats bwd / obs_stats dgrad / LN-ELU bwd / obs_out dgrad / GRU bwd / GRU dgrad /
+ * LN-ELU bwd / img_in dgrad / reset mask.  Rows are b*T + t.  On entry dfeat [N, D+S] holds the
+ * heads' gradient w.r.t. every posterior, dlogit the KL gradient w.r.t. the posterior logits and
+ * dxq the stats gradient of the LAST step's rows (dd_stats_sample_bwd); on return dxq, dxo, dzo,
+ * dz3, dy3, dgin = [dh | dx1], dz1, dxs hold what the bulk weight-gradient contractions read.
+ * w1..w4: dd_scan_wprep_rows planes of obs_stats [U,S], obs_out (deter rows) [D,U], gru [D+U,3D],
+ * img_in (stoch rows) [S,U].  flags bit 6: time stamps (measurement aid).  sync2: as in the
+ * forward scan.  Shapes: dd_observe_scan_supported. */
+int dd_observe_scan_bwd(
+    int B, int T, int D, int U, int G, int C, int flags, float unimix, const float* first,
+    const float* xq, const float* zo, const float* xo, const float* st3, const float* z3,
+    const float* gst, const float* gin, const float* z1, const float* st1, const float* dlogit,
+    const void* w1, const void* w2, const void* w3, const void* w4,
+    const float* g3, const float* gg, const float* bg, const float* g1,
+    float* dfeat, float* dxq, float* dxo, float* dzo, float* dz3, float* dy3, float* dgin,
+    float* dz1, float* dxs, unsigned* sync2, void* stream);
+
 /* ---- categorical latent ------------------------------------------------------ */
 
 /* logit = log((1-unimix)*softmax(x)+unimix/C); stoch = one_hot(draw).

@@ -189,6 +189,55 @@ def test_fused_observe_scan_equals_launch_sequence(hip):
     torch.cuda.empty_cache()
 
 
+def test_fused_reverse_scan_equals_launch_sequence(hip):
+  """csrc/scan.hip k_observe_scan_bwd: the data gradient of the T obs_steps as ONE persistent
+  launch against the per-layer launch sequence, on the same forward state and the same incoming
+  gradients (random dfeat / KL gradients), at the full configs[1] size and on a ragged batch:
+  every buffer the bulk weight-gradient contractions read and the resulting parameter
+  gradients agree to float reassociation (and the hardware exp2 / reciprocal forms of the gates)."""
+  for (B, T, first_mid) in ((50, 50, False), (21, 7, True)):
+    cfg = helpers.make_config(('a1_vision',), batch_size=B, replay_chunk=T)
+    plain, sp, shapes, params, data, _, _ = helpers.make_problem(
+        cfg, image=64, vector=16, action=16, terminals=0.02, smooth=True)
+    if first_mid:
+      data['is_first'][3, 4] = True
+      data['is_first'][20, 2] = True
+    L = learner_mod.Learner(sp, hip, 'cuda:0', B, T, params=params, noise_seed=5)
+    assert L.fused_scan and L.fused_scan_bwd
+    L.upload(data)
+    L.reset_carry()
+    L.phase_prep()
+    L.encoder_fwd()
+    L.initial_fwd()
+    L.observe_fwd(True)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    rnd = lambda t, s: torch.randn(t.shape, generator=gen, device='cuda') * s
+    seeds = {k: rnd(L.b[k], s) for k, s in (('dfeat', 1e-2), ('dpost_logit', 1e-3), ('dprior_logit', 1e-3))}
+    names = ('dfeat', 'dz3', 'dy3', 'dgin', 'dxin_s')
+    acts = (('Aq.dout', lambda l: l.a_obs_stats.dout), ('Ao.dout', lambda l: l.a_obs_out.dout),
+            ('Ao.dz', lambda l: l.a_obs_out.dz), ('Ai.dz', lambda l: l.a_img_in.dz))
+    got = []
+    for fused in (True, False):
+      L.fused_scan_bwd = fused
+      for k, v in seeds.items():
+        L.b[k].copy_(v)
+      L.groups['model'].gflat.zero_()
+      L.observe_bwd()
+      torch.cuda.synchronize()
+      out = {k: L.b[k].clone() for k in names}
+      out.update({k: f(L).clone() for k, f in acts})
+      out['grads'] = L.groups['model'].gflat.clone()
+      got.append(out)
+    assert int(L.scan_sync[1]) == 0, 'a grid-barrier spin timed out'
+    for k in got[0]:
+      x, y = got[0][k].double(), got[1][k].double()
+      err = float((x - y).abs().max() / (y.abs().max() + 1e-30))
+      print(f'reverse scan B{B} T{T} {k}: {err:.2e}')
+      assert err < 2e-5, (k, err)
+    del L, got
+    torch.cuda.empty_cache()
+
+
 def test_full_size_properties(hip):
   """BASELINE configs[1] at full size (batch 50 x seq 50 x horizon 15): the oracle
   is too slow here, so check size-independent properties instead: finite losses,

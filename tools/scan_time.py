@@ -79,3 +79,47 @@ for i in range(4):
   d = (arr[:, i] - arr[:, i].min()) / 100
   print(f'  barrier {i + 1}: {np.median(d):5.2f} {d.max():5.2f}  wg {int(d.argmax())} (row block {int(d.argmax()) & 3}, stride {int(d.argmax()) >> 2});'
         f' released {(ts[[2, 7, 12, 18][i]] - arr[:, i].max()) / 100:5.2f} us after the last arrival')
+
+
+# ---- reverse scan
+L.fused_scan = True
+gen = torch.Generator(device='cuda').manual_seed(3)
+seed = {k: torch.randn(L.b[k].shape, generator=gen, device='cuda') * sc
+        for k, sc in (('dfeat', 1e-2), ('dpost_logit', 1e-3), ('dprior_logit', 1e-3))}
+def reseed():
+  for k, v in seed.items():
+    L.b[k].copy_(v)
+def scan_bwd(flags=0):
+  b, P = L.b, L.P
+  Aq, Ao, Ai = L.a_obs_stats, L.a_obs_out, L.a_img_in
+  g = P['gru_h']
+  ops.observe_scan_bwd(
+      L.B, L.T, L.D, L.U, L.G, L.C, flags, L.unimix, b['first'],
+      [Aq.z, Ao.z, Ao.out, Ao.stats, b['z3'], b['gstats'], b['gin'], Ai.z, Ai.stats],
+      b['dpost_logit'], [w[1] for w in L.scan_wb],
+      [P['obs_out_h'].gamma, g.gamma, g.beta, P['img_in'].gamma],
+      [b['dfeat'], Aq.dout, Ao.dout, Ao.dz, b['dz3'], b['dy3'], b['dgin'], Ai.dz, b['dxin_s']],
+      L.scan_sync)
+reseed()
+L.fused_scan_bwd = True
+L.observe_scan_bwd_fused()
+timed('reverse scan kernel alone (T = %d steps)' % T, lambda: (reseed(), scan_bwd()))
+timed('  (the three seed copies in that figure)', reseed)
+for fused in (False, True):
+  L.fused_scan_bwd = fused
+  p2 = graphs.GraphPlan('cuda:0')
+  keep, L.plan = L.plan, p2
+  reseed()
+  p2.capture(lambda: L.observe_bwd())
+  L.plan = keep
+  timed('observe_bwd incl. bulk weight gradients, ' + ('fused reverse scan' if fused else 'launch sequence'),
+        lambda: (reseed(), p2.replay()))
+reseed()
+scan_bwd(64)
+torch.cuda.synchronize()
+ts = L.scan_sync[2:2 + 20].view(torch.int64).cpu().numpy()
+names = ['start', 'Q1 dxo', 'barrier 1', 'Q2 ln + dgrad', 'barrier 2', 'Q3 gru + dgrad', 'barrier 3', 'Q4 ln + dgrad + stats', 'barrier 4']
+print('reverse scan, step 10, workgroup 0 (us since step start / delta):')
+for i in range(1, 9):
+  print(f'  {names[i]:24s} {(ts[i] - ts[0]) / 100:7.2f} {(ts[i] - ts[i - 1]) / 100:6.2f}')
+print('error word', int(L.scan_sync[1]))
