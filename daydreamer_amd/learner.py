@@ -764,7 +764,7 @@ class Learner:
     """The T obs_steps as one persistent launch (dd_observe_scan_fwd): same buffers, same
     values up to the summation order of the small contractions."""
     ops, b, P = self.ops, self.b, self.P
-    for W, planes, kp in self.scan_w:   # the weights changed in the last optimizer step
+    for W, planes, kp in self.scan_w[1:]:   # the weights changed in the last optimizer step (P1 gathers img_in rows in fp32: no planes)
       ops.scan_wprep(W, planes, kp)
     g = P['gru_h']
     ops.observe_scan_fwd(
