@@ -818,7 +818,10 @@ __device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) {
 template <int BX, bool KC, int BK>
 struct PlaneS3 {
   // bytes per k-octet (KC) / per k (RC); the pad staggers bank quarters
-  static constexpr int STR = KC ? BX * 16 + (BK == 16 ? 64 : 32) : BX * 2 + 64;
+#ifndef DD_RCPAD
+#define DD_RCPAD 64
+#endif
+  static constexpr int STR = KC ? BX * 16 + (BK == 16 ? 64 : 32) : BX * 2 + DD_RCPAD;
   static constexpr int BYTES = KC ? (BK / 8) * STR : BK * STR;
   // float4 units staged per tile: KC chunks (row, 4 k), RC chunks (4 rows, k); UNITS / 256 per
   // thread, every thread active (a partially active workgroup puts the loads behind a
@@ -874,13 +877,31 @@ struct PlaneS3 {
   }
 };
 
+// Workgroups per CU the register allocation is held to.  -DDD_OCC3=2 -DDD_RCPAD=32 asks for three
+// on the 128x128 tile when at least one operand is k-contiguous (LDS image 50.7 / 53.0 KB,
+// <= 168 VGPRs without spills): measured -6..7 % on the NT shapes and -1..3 % on NN in isolation
+// (the loop's MFMA half and its staging half barely overlap inside one workgroup,
+// profiles/r02_gemm_ablation_128tile.txt), sequential step 40.4 -> 40.2 ms, but the pipelined
+// step 33.5 -> 33.9 ms (same box, alternating runs): three resident workgroups leave the other
+// stream's kernels less room.  Not the default.
+#ifndef DD_OCC3
+#define DD_OCC3 0
+#endif
+#if DD_OCC3 == 2
+#define DD_OCC(BM, BN, AKC, BKC) (((BM) == 128 && (BN) == 128 && ((AKC) || (BKC))) ? 3 : 2)
+#elif DD_OCC3 == 1
+#define DD_OCC(BM, BN, AKC, BKC) (((BM) == 128 && (BN) == 128 && (AKC) && (BKC)) ? 3 : 2)
+#else
+#define DD_OCC(BM, BN, AKC, BKC) 2
+#endif
+
 // A2: a second accumulator per output block for the three small-term products.  A wave of a
 // 64x64 tile owns ONE 32x32 block, so its six products per k-step form one dependent MFMA
 // chain (each waits for the previous result); two chains of three halve that latency.  The
 // partial sums are added once, after the K loop (small terms + large terms).
 template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int NP = 6, int BK = 16,
           int ST = 1, bool IL = false, bool A2 = false>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, DD_OCC(BM, BN, AKC, BKC))
 k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   constexpr int NPL = NP == 1 ? 1 : (NP == 3 ? 2 : 3);     // planes kept
   using LA = PlaneS3<BM, AKC, BK>;
