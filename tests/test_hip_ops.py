@@ -135,7 +135,11 @@ CONVS = [  # n, hb, Cb, hs, Cs, k, u8
     # the model's own layer geometry (banded transposed conv: all four parities for even k with an
     # output row that only receives the bias at 31 = 2*13 + 4 + 1, one contraction per parity for odd k)
     (3, 13, 128, 5, 256, 5, False), (2, 30, 64, 13, 128, 6, False), (2, 31, 64, 14, 128, 4, False),
-    (3, 14, 128, 6, 256, 4, False), (130, 6, 64, 2, 64, 4, False), (2, 9, 64, 3, 32, 5, False)]
+    (3, 14, 128, 6, 256, 4, False), (130, 6, 64, 2, 64, 4, False), (2, 9, 64, 3, 32, 5, False),
+    # thin image side with 64 feature channels (GEMM + col2im form): the decoder's RGB layer, an
+    # encoder-geometry k = 4 layer, an odd kernel on an odd size, one- and two-channel images
+    (3, 64, 3, 30, 64, 6, False), (2, 64, 3, 31, 64, 4, False), (2, 33, 3, 15, 64, 5, False),
+    (1, 20, 2, 8, 64, 6, False), (40, 64, 1, 30, 64, 6, False)]
 
 
 @pytest.mark.parametrize('n,hb,Cb,hs,Cs,k,u8', CONVS)

@@ -17,4 +17,8 @@ for mode in 1 0; do
 done
 bash $GRAFT_REPO_ROOT/tools/pmc_bench.sh > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_hbm_traffic.csv 2>&1
 cd $GRAFT_REPO_ROOT
+(timeout 200 python tools/phase_times.py > gpurun_out/${tag}_phase_times.txt 2>&1)
+(timeout 200 python tools/scan_time.py > gpurun_out/${tag}_fused_scan_times.txt 2>&1)
+(timeout 200 python tools/trace_shapes.py > gpurun_out/${tag}_contraction_call_sites.txt 2>&1)
+(for c in a1 xarm ur5_multicam a1_scaled; do timeout 250 python bench.py --config $c --no-cpu-baseline 2>/dev/null | grep -a -o '{"metric.*'; done > gpurun_out/${tag}_bench_other_configs.jsonl)
 tail -4 gpurun_out/${tag}_pytest_gpu.log; cat gpurun_out/${tag}_smoke.log | tail -2; head -c 500 gpurun_out/${tag}_bench.json; echo; head -c 300 gpurun_out/${tag}_bench_2ranks_shared_gpu.json; echo; tail -12 gpurun_out/${tag}_pmc_hbm_traffic.csv
