@@ -20,5 +20,5 @@ cd $GRAFT_REPO_ROOT
 (timeout 200 python tools/phase_times.py > gpurun_out/${tag}_phase_times.txt 2>&1)
 (timeout 200 python tools/scan_time.py > gpurun_out/${tag}_fused_scan_times.txt 2>&1)
 (timeout 200 python tools/trace_shapes.py > gpurun_out/${tag}_contraction_call_sites.txt 2>&1)
-(for c in a1 xarm ur5_multicam a1_scaled; do timeout 250 python bench.py --config $c --no-cpu-baseline 2>/dev/null | grep -a -o '{"metric.*'; done > gpurun_out/${tag}_bench_other_configs.jsonl)
-tail -4 gpurun_out/${tag}_pytest_gpu.log; cat gpurun_out/${tag}_smoke.log | tail -2; head -c 500 gpurun_out/${tag}_bench.json; echo; head -c 300 gpurun_out/${tag}_bench_2ranks_shared_gpu.json; echo; tail -12 gpurun_out/${tag}_pmc_hbm_traffic.csv
+# the other BASELINE configs at their per-GPU shard (configs[2] 50 / 2 GPUs, [3] 64 / 4, [4] 256 / 8)
+(for c in "a1 --batch 16 --length 16" "xarm --batch 25 --length 50" "ur5_multicam --batch 16 --length 64" "a1_scaled --batch 32 --length 64"; do timeout 400 python bench.py --config $c --no-cpu-baseline 2>/dev/null | grep -a -o '{"metric.*'; done > gpurun_out/${tag}_bench_other_configs.jsonl)
