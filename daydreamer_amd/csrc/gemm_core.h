@@ -895,6 +895,16 @@ struct PlaneS3 {
 #define DD_OCC(BM, BN, AKC, BKC) 2
 #endif
 
+// Raised wave priority around the MFMA block of a k-step (s_setprio): the waves of the two
+// resident workgroups then alternate roles - one issues its MFMAs while the other stages -
+// instead of both competing for the matrix pipe and then both staging.  DD_PRIO_MASK selects
+// the operand layouts it is applied to: bit 0 k-contiguous x k-contiguous, 1 kc x rc, 2 rc x rc,
+// 3 rc x kc.
+#ifndef DD_PRIO_MASK
+#define DD_PRIO_MASK 9
+#endif
+#define DD_PRIO_ON(AKC, BKC) (((DD_PRIO_MASK) >> (((AKC) ? 0 : 2) + (((AKC) != (BKC)) ? 1 : 0))) & 1)
+
 // A2: a second accumulator per output block for the three small-term products.  A wave of a
 // 64x64 tile owns ONE 32x32 block, so its six products per k-step form one dependent MFMA
 // chain (each waits for the previous result); two chains of three halve that latency.  The
@@ -1007,6 +1017,7 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
     }
   };
   auto compute = [&](int buf) {
+    if constexpr (DD_PRIO_ON(AKC, BKC)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[TM][NPL], bf[TN][NPL];
@@ -1045,6 +1056,7 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 #endif
           }
     }
+    if constexpr (DD_PRIO_ON(AKC, BKC)) __builtin_amdgcn_s_setprio(0);
   };
 
   // k-tiles 0..nfull-1 are whole, tile nfull (if any) is the K tail.  ST tiles are in

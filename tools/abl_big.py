@@ -8,12 +8,12 @@ lib.dd_gemm_f32.argtypes = [P, P, P, I, I, I, L, L, L, I, I, F, F, P, P, Z, P, P
 ws = torch.empty(256 << 20, dtype=torch.uint8, device='cuda')
 st = torch.cuda.current_stream().cuda_stream
 out = []
-for (M, N, K, tb) in [(40000, 512, 512, 0), (40000, 512, 512, 1), (40000, 512, 1280, 0), (40000, 1280, 512, 1), (4096, 4096, 4096, 0)]:
-  A = torch.randn(M, K, device='cuda'); B = torch.randn((N, K) if tb else (K, N), device='cuda')
+for (M, N, K, ta, tb) in [(40000, 512, 512, 0, 0), (40000, 512, 512, 0, 1), (40000, 1280, 512, 0, 1), (512, 512, 40000, 1, 0), (1280, 512, 40000, 1, 0), (512, 512, 40000, 1, 1), (4096, 4096, 4096, 0, 0)]:
+  A = torch.randn((K, M) if ta else (M, K), device='cuda'); B = torch.randn((N, K) if tb else (K, N), device='cuda')
   C = torch.zeros(M, N, device='cuda')
   flag = ctypes.c_int(0)
   def run():
-    lib.dd_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, K, (K if tb else N), N, 0, tb, 1.0, 0.0,
+    lib.dd_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, (M if ta else K), (K if tb else N), N, ta, tb, 1.0, 0.0,
                     None, ws.data_ptr(), ws.numel(), ctypes.byref(flag), st)
   for _ in range(5): run()
   torch.cuda.synchronize()
@@ -22,7 +22,7 @@ for (M, N, K, tb) in [(40000, 512, 512, 0), (40000, 512, 512, 1), (40000, 512, 1
   for _ in range(10): run()
   e1.record(); torch.cuda.synchronize()
   us = e0.elapsed_time(e1) / 10 * 1e3
-  ref = A.double() @ (B.double().T if tb else B.double())
+  ref = (A.double().T if ta else A.double()) @ (B.double().T if tb else B.double())
   err = float((C.double() - ref).abs().max() / ref.abs().max()) if flag.value == 0 else -1.0
-  out.append(f'{M}x{N}x{K}{"T" if tb else ""}: {us:6.1f}us (S{flag.value} err {err:.1e})')
+  out.append(f'{M}x{N}x{K}{"T" if ta else "N"}{"T" if tb else "N"}: {us:6.1f}us (S{flag.value} err {err:.1e})')
 print(f'{sys.argv[2]:10s} ' + ' | '.join(out))
