@@ -160,12 +160,19 @@ __device__ __forceinline__ float row_reduce(float s, float (*ws)[16]) {
 template <int NIT>
 __device__ __forceinline__ void load_planes(uint4 (&bq)[NIT][3], const unsigned short* wt, long plane,
                                             int KP, int n0) {
+  // wave-uniform base (tile, plane: scalar registers) + one 32-bit lane offset + immediates: the
+  // per-(tile, plane) 64-bit vector addresses this replaces were hoisted out of the time loop by
+  // the compiler and, for every tile of every phase, filled the register file
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned short* wrow = wt + (long)(n0 + (lane & 15)) * KP + (lane >> 4) * 8 + wave * 32;
+  const unsigned lane_off = (unsigned)(((lane & 15) * KP + (lane >> 4) * 8 + wave * 32) * 2);
 #pragma unroll
-  for (int it = 0; it < NIT; ++it)
+  for (int p = 0; p < 3; ++p) {
+    // (32-bit scalar arithmetic: a 64-bit multiply has no scalar form and would drag the base into vector registers)
+    const unsigned uoff = __builtin_amdgcn_readfirstlane((unsigned)(n0 * KP + p * (int)plane) * 2u);
+    const char* base = reinterpret_cast<const char*>(wt) + uoff;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bq[it][p] = *reinterpret_cast<const uint4*>(wrow + p * plane + it * 128);
+    for (int it = 0; it < NIT; ++it) bq[it][p] = *reinterpret_cast<const uint4*>(base + lane_off + it * 256);
+  }
 }
 
 template <int KP, int MAXT>
@@ -192,6 +199,52 @@ __device__ __forceinline__ void tiles_gemm(const bf16x8 (&af)[KP / 128][3], cons
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[j][wave][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) out[j] = ((red[j][0][t] + red[j][1][t]) + red[j][2][t]) + red[j][3][t];
+}
+
+// The same with the weight planes streamed in units of NITC k-steps of a tile: two units in
+// registers, unit u + 1 is loaded while unit u runs its MFMAs; unit 0 comes from the caller
+// (loaded during the grid barrier) - for phases whose tiles' planes together exceed the register
+// file (deter = units = 512: the GRU contraction has six 1024-deep tiles per workgroup).
+// n0[j]: first column of tile j.
+template <int KP, int MAXT, int NITC>
+__device__ __forceinline__ void tiles_gemm_stream(const bf16x8 (&af)[KP / 128][3], uint4 (&bq)[2][NITC][3],
+                                                  const unsigned short* wt, long plane,
+                                                  const int (&n0)[MAXT], float (*red)[4][256],
+                                                  float (&out)[MAXT]) {
+  constexpr int NIT = KP / 128, H = NIT / NITC, NU = MAXT * H;
+  static_assert(NIT % NITC == 0, "k-steps per unit");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();   // red[] free (the previous phase's readers are done)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int j = u / H, h = u % H;
+    if (u + 1 < NU)
+      load_planes<NITC>(bq[(u + 1) & 1], wt + ((u + 1) % H) * NITC * 128, plane, KP, n0[(u + 1) / H]);
+    __builtin_amdgcn_sched_barrier(0);   // (no further hoisting: one unit ahead is what the registers hold)
+#pragma unroll
+    for (int it = 0; it < NITC; ++it) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bq[u & 1][it][p]);
+      const int ia = h * NITC + it;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ia][2], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ia][0], b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ia][1], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ia][1], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ia][0], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ia][0], b[0], acc, 0, 0, 0);
+    }
+    if (h == H - 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[j][wave][r * 64 + lane] = acc[r];
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   __syncthreads();
   const int t = threadIdx.x;
@@ -360,10 +413,18 @@ k_observe_scan_fwd(ScanArgs a) {
       }
     }
     TS(1); TSW(0);
-    uint4 bq2[T2][NIT2][3];
+    // (weight planes of all T2 tiles in registers if they fit - 48 vector registers per tile and
+    // k-step of 128 - else streamed in units of four k-steps, two units in flight)
+    constexpr bool ALL2 = T2 * NIT2 <= 12;
+    constexpr int NITC2 = NIT2 % 4 == 0 ? 4 : NIT2;
+    uint4 bq2[ALL2 ? T2 : 2][ALL2 ? NIT2 : NITC2][3];
     grid_barrier(a.ctr, ++gen * NWG, [&] {
+      if constexpr (ALL2) {
 #pragma unroll
-      for (int j = 0; j < T2; ++j) load_planes<NIT2>(bq2[j], a.wt2, pl2, D + U, (nstr + NSTR * j) * 16);
+        for (int j = 0; j < T2; ++j) load_planes<NIT2>(bq2[j], a.wt2, pl2, D + U, (nstr + NSTR * j) * 16);
+      } else {
+        load_planes<NITC2>(bq2[0], a.wt2, pl2, D + U, nstr * 16);
+      }
     });
     TS(2);
 
@@ -422,7 +483,8 @@ k_observe_scan_fwd(ScanArgs a) {
       for (int j = 0; j < T2; ++j) n0[j] = (nstr + NSTR * j) * 16;
       float out[T2];
       TS(4);
-      tiles_gemm<KP, T2>(afr, bq2, red, out);
+      if constexpr (ALL2) tiles_gemm<KP, T2>(afr, bq2, red, out);
+      else tiles_gemm_stream<KP, T2, NITC2>(afr, bq2, a.wt2, pl2, n0, red, out);
       TS(5);
 #pragma unroll
       for (int j = 0; j < T2; ++j)
@@ -503,11 +565,17 @@ k_observe_scan_fwd(ScanArgs a) {
         if (olive) a.zo[oidx * U + n0[j] + ocol] = zold[j] + out[j];
     }
     TS(11); TSW(2);
-    uint4 bq4[T4][NIT4][3];
+    constexpr bool ALL4 = T4 * NIT4 <= 12;
+    constexpr int NITC4 = NIT4 % 4 == 0 ? 4 : NIT4;
+    uint4 bq4[ALL4 ? T4 : 2][ALL4 ? NIT4 : NITC4][3];
     grid_barrier(a.ctr, ++gen * NWG, [&] {
+      if constexpr (ALL4) {
 #pragma unroll
-      for (int j = 0; j < T4; ++j)
-        load_planes<NIT4>(bq4[j], a.wt4, pl4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
+        for (int j = 0; j < T4; ++j)
+          load_planes<NIT4>(bq4[j], a.wt4, pl4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
+      } else {
+        load_planes<NITC4>(bq4[0], a.wt4, pl4, U, nstr * C);
+      }
     });
     TS(12);
 
@@ -563,7 +631,8 @@ k_observe_scan_fwd(ScanArgs a) {
       for (int j = 0; j < T4; ++j) n0[j] = (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16;
       float out[T4];
       TS(14);
-      tiles_gemm<U, T4>(afr, bq4, red, out);
+      if constexpr (ALL4) tiles_gemm<U, T4>(afr, bq4, red, out);
+      else tiles_gemm_stream<U, T4, NITC4>(afr, bq4, a.wt4, pl4, n0, red, out);
       TS(15);
 #pragma unroll
       for (int j = 0; j < T4; ++j) {
@@ -1026,6 +1095,10 @@ extern "C" int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* p
   return 0;
 }
 
+extern "C" int dd_observe_scan_bwd_supported(int B, int D, int U, int G, int C) {
+  return B >= 1 && B <= 64 && D == 256 && U == 256 && G == 32 && C == 32;
+}
+
 extern "C" int dd_observe_scan_bwd(
     int B, int T, int D, int U, int G, int C, int flags, float unimix, const float* first,
     const float* xq, const float* zo, const float* xo, const float* st3, const float* z3,
@@ -1034,7 +1107,7 @@ extern "C" int dd_observe_scan_bwd(
     const float* g3, const float* gg, const float* bg, const float* g1,
     float* dfeat, float* dxq, float* dxo, float* dzo, float* dz3, float* dy3, float* dgin,
     float* dz1, float* dxs, unsigned* sync2, void* stream) {
-  DD_REQUIRE(dd_observe_scan_supported(B, D, U, G, C, 16), "dd_observe_scan_bwd: unsupported shape");
+  DD_REQUIRE(dd_observe_scan_bwd_supported(B, D, U, G, C), "dd_observe_scan_bwd: unsupported shape");
   hipStream_t st = (hipStream_t)stream;
   ScanBwdArgs a;
   a.B = B; a.T = T; a.flags = flags; a.unimix = unimix; a.first = first;
@@ -1067,7 +1140,7 @@ extern "C" int dd_scan_wprep(const float* W, long ld, int K, int N, int Kp, void
 
 // compiled shapes (deter, units, groups, classes, action dims): loops unroll and the loads of a
 // phase issue together only with compile-time extents
-#define DD_SCAN_SHAPES(X) X(256, 256, 32, 32, 16) X(256, 256, 32, 32, 6)
+#define DD_SCAN_SHAPES(X) X(256, 256, 32, 32, 16) X(256, 256, 32, 32, 6) X(512, 512, 32, 32, 6)
 
 extern "C" int dd_observe_scan_supported(int B, int D, int U, int G, int C, int A) {
   if (B < 1 || B > 64) return 0;

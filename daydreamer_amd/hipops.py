@@ -44,6 +44,7 @@ _SIGS = {
     'dd_scan_wprep': [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     'dd_observe_scan_fwd': [c_i] * 8 + [c_f] + [c_p] * 32,
     'dd_scan_wprep_rows': [c_p, c_l, c_i, c_i, c_p, c_p],
+    'dd_observe_scan_bwd_supported': [c_i] * 5,
     'dd_observe_scan_bwd': [c_i] * 7 + [c_f] + [c_p] * 30,
     'dd_stats_sample_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_f, c_p, c_p],
     'dd_onehot_sample_host': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i],
@@ -354,6 +355,9 @@ class HipOps:
         *[w.data_ptr() for w in wts], *[v.data_ptr() for v in vecs],
         *[t.data_ptr() for t in bufs], w_in.data_ptr(), idx_ws.data_ptr(), sync2.data_ptr(),
         self.stream), 'dd_observe_scan_fwd')
+
+  def observe_scan_bwd_supported(self, B, D, U, G, C):
+    return bool(self.lib.dd_observe_scan_bwd_supported(B, D, U, G, C))
 
   def scan_wprep_rows(self, W, planes):
     """Weight cache of the fused reverse scan: W [N, K] fp32 -> bf16 planes [3, N, K]."""

@@ -372,7 +372,9 @@ class Learner:
                      (self.P['gru'].W, i16(3 * 3 * D * (D + U)), D + U),
                      (self.P['obs_out_h'].W, i16(3 * U * D), D),
                      (self.P['obs_stats'].W, i16(3 * S * U), U)]
-      self.fused_scan_bwd = bool(self.cfg.get('hip', {}).get('fused_scan_bwd', True)) and hasattr(self.ops, 'observe_scan_bwd')
+      self.fused_scan_bwd = (bool(self.cfg.get('hip', {}).get('fused_scan_bwd', True)) and
+                             hasattr(self.ops, 'observe_scan_bwd') and
+                             self.ops.observe_scan_bwd_supported(B, D, U, G, self.C))
       self.scan_wb = [(self.P['obs_stats'].W, i16(3 * U * S)), (self.P['obs_out_h'].W, i16(3 * D * U)),
                       (self.P['gru'].W, i16(3 * (D + U) * 3 * D)), (self.P['img_in_s'].W, i16(3 * S * U))]
       self.scan_sync = torch.zeros(64 + 2 * 4 * 64, dtype=torch.int32, device=self.device)   # counter, error word, debug stamps

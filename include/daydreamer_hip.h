@@ -169,7 +169,9 @@ int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* planes, void
  * dz3, dy3, dgin = [dh | dx1], dz1, dxs hold what the bulk weight-gradient contractions read.
  * w1..w4: dd_scan_wprep_rows planes of obs_stats [U,S], obs_out (deter rows) [D,U], gru [D+U,3D],
  * img_in (stoch rows) [S,U].  flags bit 6: time stamps (measurement aid).  sync2: as in the
- * forward scan.  Shapes: dd_observe_scan_supported. */
+ * forward scan.  Shapes: dd_observe_scan_bwd_supported (deter = units = 256, 32 x 32 latents;
+ * the forward scan is also compiled for 512). */
+int dd_observe_scan_bwd_supported(int B, int D, int U, int G, int C);
 int dd_observe_scan_bwd(
     int B, int T, int D, int U, int G, int C, int flags, float unimix, const float* first,
     const float* xq, const float* zo, const float* xo, const float* st3, const float* z3,

@@ -137,10 +137,17 @@ def test_fused_observe_scan_equals_launch_sequence(hip):
   backward pass reads must agree to float reassociation, the drawn latents exactly - except in
   sequences where a draw sat on a CDF edge and flipped (the two paths sum the small contractions
   in different orders); those are counted and must be rare.  The barrier's error word stays 0."""
-  for (B, T, first_mid) in ((50, 50, False), (21, 7, True)):
-    cfg = helpers.make_config(('a1_vision',), batch_size=B, replay_chunk=T)
-    plain, sp, shapes, params, data, _, _ = helpers.make_problem(
-        cfg, image=64, vector=16, action=16, terminals=0.02, smooth=True)
+  for (name, B, T, first_mid) in (('a1_vision', 50, 50, False), ('a1_vision', 21, 7, True), ('xarm', 25, 50, False),
+                                  ('a1_vision', 64, 3, False), ('a1_vision', 1, 2, False)):
+    cfg = helpers.make_config((name,), batch_size=B, replay_chunk=T)
+    if name == 'xarm':   # deter = units = 512, one-hot 6-way actions: the streamed-plane variant of the kernel
+      cfg = cfg.update({'encoder.mlp_keys': 'vector', 'decoder.mlp_keys': 'vector',
+                        'encoder.cnn_keys': 'image', 'decoder.cnn_keys': 'image'})
+      plain, sp, shapes, params, data, _, _ = helpers.make_problem(
+          cfg, image=64, vector=20, action=6, terminals=0.02, smooth=True, discrete=True)
+    else:
+      plain, sp, shapes, params, data, _, _ = helpers.make_problem(
+          cfg, image=64, vector=16, action=16, terminals=0.02, smooth=True)
     if first_mid:
       data['is_first'][3, 4] = True
       data['is_first'][20, 2] = True
@@ -165,7 +172,7 @@ def test_fused_observe_scan_equals_launch_sequence(hip):
     ib = Bq.b['post'][:, D:].view(B, T, G, C).argmax(-1)
     assert torch.equal(A.b['post'][:, D:].sum(-1), torch.full((B * T,), float(G), device='cuda'))
     same = (ia == ib).all(-1).all(-1)          # sequences with identical draws throughout
-    print(f'fused scan B{B} T{T}: {int((~same).sum())} of {B} sequences contain a flipped draw')
+    print(f'fused scan {name} B{B} T{T}: {int((~same).sum())} of {B} sequences contain a flipped draw')
     assert int((~same).sum()) <= max(1, B // 25)
     rows = same.repeat_interleave(T)
     def cmp(x, y, what, tol=2e-5):
@@ -195,7 +202,7 @@ def test_fused_reverse_scan_equals_launch_sequence(hip):
   gradients (random dfeat / KL gradients), at the full configs[1] size and on a ragged batch:
   every buffer the bulk weight-gradient contractions read and the resulting parameter
   gradients agree to float reassociation (and the hardware exp2 / reciprocal forms of the gates)."""
-  for (B, T, first_mid) in ((50, 50, False), (21, 7, True)):
+  for (B, T, first_mid) in ((50, 50, False), (21, 7, True), (64, 3, False), (1, 2, False)):
     cfg = helpers.make_config(('a1_vision',), batch_size=B, replay_chunk=T)
     plain, sp, shapes, params, data, _, _ = helpers.make_problem(
         cfg, image=64, vector=16, action=16, terminals=0.02, smooth=True)
