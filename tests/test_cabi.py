@@ -39,3 +39,18 @@ def test_product_never_imports_oracle():
   for path in (ROOT / 'daydreamer_amd').glob('*.py'):
     text = path.read_text()
     assert 'import oracle' not in text and 'from oracle' not in text, path
+
+
+def test_persistent_scan_shape_queries():
+  """dd_observe_scan_supported / dd_observe_scan_bwd_supported are host logic (no launch): the
+  learner falls back to the per-layer launch sequence wherever they say no."""
+  lib = ctypes.CDLL(str(ROOT / 'daydreamer_amd' / 'libdaydreamer_hip.so'))
+  fwd, bwd = lib.dd_observe_scan_supported, lib.dd_observe_scan_bwd_supported
+  # (B, deter, units, groups, classes, action dims)
+  assert fwd(50, 256, 256, 32, 32, 16) == 1 and bwd(50, 256, 256, 32, 32) == 1      # configs[1]
+  assert fwd(64, 256, 256, 32, 32, 16) == 1 and fwd(1, 256, 256, 32, 32, 6) == 1
+  assert fwd(65, 256, 256, 32, 32, 16) == 0 and bwd(65, 256, 256, 32, 32) == 0      # > 4 row blocks of 16
+  assert fwd(0, 256, 256, 32, 32, 16) == 0
+  assert fwd(25, 512, 512, 32, 32, 6) == 1 and bwd(25, 512, 512, 32, 32) == 0       # xarm / ur5: forward only
+  assert fwd(32, 4096, 256, 64, 64, 16) == 0 and bwd(32, 4096, 256, 64, 64) == 0    # a1_scaled: launch sequence
+  assert fwd(16, 128, 128, 8, 32, 6) == 0
