@@ -16,14 +16,18 @@ and every rank (one process per GPU, torch.distributed over RCCL) takes rows
 controllers are summed over ranks.
 """
 
+import atexit
 import os
 import queue
 import threading
+import time
+import weakref
 
 import numpy as np
 import torch
 
 from . import config as config_mod
+from . import graphs
 from . import learner as learner_mod
 from . import replay as replay_mod
 from . import spec as spec_mod
@@ -54,9 +58,19 @@ class Batcher:
   """`batch_size` replay generators zipped into [B,T,...] minibatches by a prefetch thread
   (role of embodied.Prefetch, reference core/prefetch.py:15-67).  With a GPU `device` the
   thread also stages the minibatch: it stacks into rotating pinned host buffers and issues
-  the host-to-device copies on its own stream, so `Agent.train` receives device tensors
-  (its own upload becomes a device-to-device copy) and the PCIe transfer of minibatch k+1
-  overlaps the train step of minibatch k."""
+  the host-to-device copies on the process's copy stream, so `Agent.train` receives device
+  tensors (its own upload becomes a device-to-device copy) and the PCIe transfer of minibatch
+  k+1 overlaps the train step of minibatch k.
+
+  Thread discipline: all pinned buffer sets are allocated at once when the first minibatch is
+  known, and every HIP runtime call of the thread (allocations, copy issue, event record /
+  query) is made under graphs.API_LOCK - the lock graph capture and graph launches hold - so
+  the thread is never inside the runtime while the learner thread captures or launches a
+  graph.  The thread waits for events by polling outside the lock.  `close()` (also run at
+  interpreter exit and when the owning agent is collected) stops the thread; a daemon thread
+  left inside a torch call at interpreter shutdown aborts the process."""
+
+  _LIVE = weakref.WeakSet()
 
   def __init__(self, generator_fn, batch_size, prefetch=2, device=None, sharded=False):
     # `sharded`: batch_size is this rank's share of the global batch; minibatches are
@@ -65,62 +79,105 @@ class Batcher:
     self._gens = [generator_fn() for _ in range(batch_size)]
     self._queue = queue.Queue(maxsize=prefetch)
     self._error = None
+    self._stop = threading.Event()
     self._device = device if (device is not None and torch.device(device).type == 'cuda') else None
     self._sets = prefetch + 2  # pinned buffer sets in rotation
+    self._stream = graphs.stream(self._device, 'copy') if self._device is not None else None
     self._thread = threading.Thread(target=self._work, daemon=True)
+    Batcher._LIVE.add(self)
     self._thread.start()
+
+  def _put(self, item):
+    while not self._stop.is_set():
+      try:
+        self._queue.put(item, timeout=0.05)
+        return True
+      except queue.Full:
+        continue
+    return False
+
+  def _wait(self, ev):
+    """Event wait without blocking inside the runtime: query under the lock, sleep outside."""
+    while not self._stop.is_set():
+      with graphs.API_LOCK:
+        if ev.query():
+          return
+      time.sleep(0.0002)
 
   def _work(self):
     try:
       if self._device is None:
-        while True:
+        while not self._stop.is_set():
           items = [next(g) for g in self._gens]
-          self._queue.put(self._mark({k: np.stack([it[k] for it in items], 0) for k in items[0]}))
-      torch.cuda.set_device(self._device)
-      stream = torch.cuda.Stream(self._device)
-      pinned, done = [None] * self._sets, [None] * self._sets
+          if not self._put(self._mark({k: np.stack([it[k] for it in items], 0) for k in items[0]})):
+            return
+        return
+      with graphs.API_LOCK:
+        torch.cuda.set_device(self._device)
+      stream = self._stream
+      pinned, done = None, [None] * self._sets
       n = 0
-      while True:
+      while not self._stop.is_set():
         items = [next(g) for g in self._gens]
         i = n % self._sets
         n += 1
         if done[i] is not None:
-          done[i].synchronize()  # the copy out of this pinned set has finished
-        if pinned[i] is None:
-          pinned[i] = {
-              k: torch.empty((len(items),) + np.shape(v), dtype=torch.from_numpy(np.asarray(v)[None]).dtype
-                             ).pin_memory() for k, v in items[0].items()}
+          self._wait(done[i])  # the copy out of this pinned set has finished
+        if pinned is None:
+          with graphs.API_LOCK:
+            pinned = [{
+                k: torch.empty((len(items),) + np.shape(v), dtype=torch.from_numpy(np.asarray(v)[None]).dtype
+                               ).pin_memory() for k, v in items[0].items()} for _ in range(self._sets)]
         host = pinned[i]
         for k, t in host.items():
           np.stack([it[k] for it in items], 0, out=t.numpy())
-        with torch.cuda.stream(stream):
-          dev = {k: t.to(self._device, non_blocking=True) for k, t in host.items()}
-          ev = torch.cuda.Event()
-          ev.record(stream)
+        with graphs.API_LOCK:
+          with torch.cuda.stream(stream):
+            dev = {k: t.to(self._device, non_blocking=True) for k, t in host.items()}
+            ev = torch.cuda.Event()
+            ev.record(stream)
         done[i] = ev
-        self._queue.put((self._mark(dev), ev))
+        if not self._put((self._mark(dev), ev)):
+          return
     except Exception as e:  # surfaced on the consumer side
       self._error = e
-      self._queue.put(None)
+      self._put(None)
 
   def _mark(self, batch):
     return ShardedBatch(batch) if self._sharded else batch
+
+  def close(self, join=False):
+    """Stop the prefetch thread (idempotent).  Non-blocking by default: it may be called from
+    a finalizer while the caller holds graphs.API_LOCK, which the thread may be waiting for."""
+    self._stop.set()
+    t = self._thread
+    if join and t is not threading.current_thread() and t.is_alive():
+      t.join(timeout=10.0)
 
   def __iter__(self):
     return self
 
   def __next__(self):
+    if self._stop.is_set():
+      raise StopIteration
     batch = self._queue.get()
     if batch is None:
       raise self._error
     if self._device is None:
       return batch
     dev, ev = batch
-    cur = torch.cuda.current_stream(self._device)
-    cur.wait_event(ev)
-    for t in dev.values():
-      t.record_stream(cur)  # allocated on the copy stream, consumed on this one
+    with graphs.API_LOCK:
+      cur = torch.cuda.current_stream(self._device)
+      cur.wait_event(ev)
+      for t in dev.values():
+        t.record_stream(cur)  # allocated on the copy stream, consumed on this one
     return dev
+
+
+@atexit.register
+def _close_batchers():
+  for b in list(Batcher._LIVE):
+    b.close(join=True)
 
 
 class Pipeline:
@@ -158,8 +215,8 @@ class Pipeline:
     # candidate's graphs are destroyed while their owner is alive.
     key = str(torch.device(device))
     if key not in Pipeline.POOLS:
-      Pipeline.POOLS[key] = ([torch.cuda.Stream(device) for _ in range(4)],
-                             torch.cuda.Stream(device))
+      Pipeline.POOLS[key] = ([graphs.stream(device, f'pipe{i}') for i in range(4)],
+                             graphs.stream(device, 'read'))
     self.key = key
     self.pool, self.s3 = Pipeline.POOLS[key]          # s3: metric read-out
     self.cands = [(a, b) for a in range(4) for b in range(4) if a != b]
@@ -460,9 +517,15 @@ class Agent:
       assert B % self.world == 0, (B, self.world)
       B //= self.world
     if isinstance(owner, replay_mod.DeviceReplay):
+      if sharded and not getattr(owner, '_rank_seeded', False):
+        # every rank draws its own B / world rows: replays that hold the same episodes (all
+        # ranks loaded one directory) must not draw the same rows with the same default seed
+        owner.reseed(self.rank)
       it = owner.batches(B)
       return (ShardedBatch(b) for b in it) if sharded else it
-    return Batcher(generator_fn, B, device=self.device, sharded=sharded)
+    batcher = Batcher(generator_fn, B, device=self.device, sharded=sharded)
+    weakref.finalize(self, batcher.close)   # the dataset belongs to this agent
+    return batcher
 
   def train(self, data, state=None):
     cls = ShardedBatch if isinstance(data, ShardedBatch) else dict
@@ -519,7 +582,7 @@ class Agent:
              'kl_loss': L.b['kl']}.get(name)
       if src is None:
         raise NotImplementedError(f'priority: {name}')
-      key = data['key']
+      key = self._shard(data)['key']   # this rank's rows, like the priorities below
       outs = {'key': key.cpu().numpy() if isinstance(key, torch.Tensor) else key,
               'priority': src.view(L.B, L.T).cpu().numpy().copy()}
     return outs, TrainState(L), metrics

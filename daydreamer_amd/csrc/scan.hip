@@ -28,8 +28,12 @@
 //
 // Grid barrier: one monotonic counter, arrive = release fence + relaxed agent-scope add, wait =
 // relaxed agent-scope polling by one lane + acquire fence (MI355X_MICROARCH.md, valid forms);
-// every spin is bounded - on a timeout the error word is set and the kernel runs on (garbage
-// out, never a hang).  NWG <= CU count, one workgroup per CU, so all workgroups are resident.
+// every spin is bounded - on a timeout bit 0 of the error word is set and the kernel runs on
+// (garbage out, never a hang).  The error word is STICKY: launches reset the counter only, the
+// host clears the word after reading it, and Learner.read_metrics raises on a non-zero word
+// (like check_numerics, tfutils.py:207,249) - a step that timed out never trains silently.
+// NWG <= CU count, one workgroup per CU, so all workgroups become resident as soon as
+// concurrent grids of other streams drain (nothing they run waits on this kernel).
 #include "latent_core.h"
 #include <math.h>
 #include <stdlib.h>
@@ -120,7 +124,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, PF 
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > SPIN_LIMIT) {
-        __hip_atomic_store(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
     }
@@ -1048,7 +1052,7 @@ __global__ void k_onehot_argmax(const float* __restrict__ x, long ldx, int* __re
     ones += p[c] == 1.f;
     other += p[c] != 1.f && p[c] != 0.f;
   }
-  if (other || ones > 1) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (other || ones > 1) __hip_atomic_fetch_or(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   idx[i] = ones == 1 ? best : -1;
 }
 
@@ -1118,7 +1122,7 @@ extern "C" int dd_observe_scan_bwd(
   a.g3 = g3; a.gg = gg; a.bg = bg; a.g1 = g1;
   a.dfeat = dfeat; a.dxq = dxq; a.dxo = dxo; a.dzo = dzo; a.dz3 = dz3; a.dy3 = dy3; a.dgin = dgin;
   a.dz1 = dz1; a.dxs = dxs; a.ctr = sync2;
-  hipError_t e = hipMemsetAsync(sync2, 0, 2 * sizeof(unsigned), st);
+  hipError_t e = hipMemsetAsync(sync2, 0, sizeof(unsigned), st);
   if (e != hipSuccess) { dd_set_error("dd_observe_scan_bwd(memset)", e); return (int)e; }
   if (D == 256 && U == 256 && G == 32 && C == 32)
     k_observe_scan_bwd<256, 256, 32, 32><<<NWG, 256, 0, st>>>(a);
@@ -1177,7 +1181,7 @@ extern "C" int dd_observe_scan_fwd(
   const long N = (long)B * T;
   a.idx = idx_ws; a.idx_carry = idx_ws + N * G; a.idx_init = idx_ws + (N + B) * G;
   a.nwg = NWG;
-  hipError_t e = hipMemsetAsync(sync2, 0, 2 * sizeof(unsigned), st);
+  hipError_t e = hipMemsetAsync(sync2, 0, sizeof(unsigned), st);
   if (e != hipSuccess) { dd_set_error("dd_observe_scan_fwd(memset)", e); return (int)e; }
   if (a.use_carry & 1) {
     k_onehot_argmax<<<(B * G + 255) / 256, 256, 0, st>>>(carry + D, D + a.S, idx_ws + N * G, B, G, C, sync2 + 1);

@@ -1,16 +1,68 @@
-"""HIP-graph execution plan for the learner step.
+"""HIP-graph execution plan for the learner step, and the process-level launch runtime.
 
-The train step is thousands of small dependent kernel launches (a T-step and an
-H-step scan); replaying them from captured HIP graphs removes the host launch
-cost.  The step is cut into graph segments at the few points that need host
-or collective work (data-parallel all-reduces, the slow-critic copy whose
-schedule is a host counter); `cut(fn)` marks such a point.  PyTorch is used only
-for its stream / graph handles.
+The train step is thousands of small dependent kernel launches (a T-step and an H-step
+scan); replaying them from captured HIP graphs removes the host launch cost.  The step is
+cut into graph segments at the few points that need host or collective work (data-parallel
+all-reduces, the slow-critic copy whose schedule is a host counter); `cut(fn)` marks such a
+point.  Role in the reference: the tf.function concrete-function cache of TFAgent.train
+(tfagent.py:56-70).
+
+Lifetime rules (the round-2 driver run died with SIGSEGV inside a graph replay):
+
+  * streams: one process-owned HIP stream per (device, role) from the library
+    (`dd_stream_create`), wrapped for torch with ExternalStream.  `torch.cuda.Stream()` hands
+    out handles of a 32-entry round-robin pool shared with everything else in the process
+    (other agents, the prefetch thread, torch.distributed): a capturing stream could BE the
+    stream another thread was issuing on, which invalidates or corrupts the capture.
+  * graph executables are owned by the library (`dd_graph_capture_end`) and registered here;
+    they are never destroyed while the process runs (dropping a plan only drops its Python
+    handles), so no executable can be freed under work that is still queued.
+  * every capture and graph launch happens under API_LOCK; the prefetch thread
+    (agent.Batcher) takes the same lock around its own runtime calls, so no other host thread
+    of this package is inside the HIP runtime while a capture or a launch is.
 """
 
-import warnings
+import ctypes
+import threading
 
 import torch
+
+from . import hipops
+
+API_LOCK = threading.RLock()
+
+# Debug check (tests switch it on): count the caching allocator's allocations over a capture.
+# The capture is not known to the allocator, so a tensor allocated inside a captured segment
+# would be recycled while the graph still writes to it; the learner's captured code allocates
+# nothing.  The counter is process-wide: off by default, because another thread of the caller
+# (a data loader) may legitimately allocate at the same time.
+CHECK_CAPTURE_ALLOCS = False
+
+_STREAMS = {}   # (device index, role) -> torch.cuda.ExternalStream
+_EXECS = []     # every graph executable of the process (kept alive)
+
+
+def stream(device, role):
+  """The process-owned stream of `role` on `device` (created on first use, never destroyed)."""
+  device = torch.device(device)
+  idx = device.index if device.index is not None else torch.cuda.current_device()
+  key = (idx, role)
+  with API_LOCK:
+    s = _STREAMS.get(key)
+    if s is None:
+      lib = hipops.load_library()
+      out = ctypes.c_void_p()
+      with torch.cuda.device(idx):
+        rc = lib.dd_stream_create(ctypes.byref(out))
+      if rc != 0:
+        raise RuntimeError(f'dd_stream_create failed ({rc}): {lib.dd_last_error().decode()}')
+      s = torch.cuda.ExternalStream(out.value, device=torch.device('cuda', idx))
+      _STREAMS[key] = s
+    return s
+
+
+def n_live_graphs():
+  return len(_EXECS)
 
 
 class EagerPlan:
@@ -28,41 +80,52 @@ class EagerPlan:
 
 class GraphPlan:
 
-  def __init__(self, device):
+  def __init__(self, device, role='plan'):
     self.device = torch.device(device)
     self.items = []
-    self.cur = None
     self.capturing = False
-    self.stream = torch.cuda.Stream(self.device)
+    self.lib = hipops.load_library()
+    # all sequential plans of the process share one stream: they are issued by one thread, in
+    # program order
+    self.stream = stream(self.device, role)
+
+  def _check(self, rc, what):
+    if rc != 0:
+      raise RuntimeError(f'{what} failed ({rc}): {self.lib.dd_last_error().decode()}')
 
   def _begin(self):
-    self.cur = torch.cuda.CUDAGraph()
-    # thread_local: the RCCL watchdog thread of torch.distributed may touch the
-    # device while this thread captures
-    self.cur.capture_begin(capture_error_mode='thread_local')
+    self._check(self.lib.dd_graph_capture_begin(self.stream.cuda_stream), 'dd_graph_capture_begin')
 
   def _end(self):
-    with warnings.catch_warnings():
-      # a segment between two adjacent cut points holds no kernels: fine
-      warnings.filterwarnings('ignore', message='The CUDA Graph is empty')
-      self.cur.capture_end()
-    self.items.append(('graph', self.cur))
-    self.cur = None
+    exe, nodes = ctypes.c_void_p(), ctypes.c_int()
+    self._check(self.lib.dd_graph_capture_end(self.stream.cuda_stream, ctypes.byref(exe),
+                                              ctypes.byref(nodes)), 'dd_graph_capture_end')
+    # (a segment between two adjacent cut points holds no kernels: exe is NULL, launch a no-op)
+    if exe.value:
+      _EXECS.append(exe.value)
+    self.items.append(('graph', exe.value))
 
   def capture(self, fn):
     """Record fn() (which issues kernels on the current stream and calls
     cut(...) at host/collective points) without executing it."""
-    torch.cuda.synchronize(self.device)
-    self.stream.wait_stream(torch.cuda.current_stream(self.device))
-    with torch.cuda.stream(self.stream):
-      self.capturing = True
-      self._begin()
-      try:
-        fn()
-      finally:
-        self._end()
-        self.capturing = False
-    torch.cuda.current_stream(self.device).wait_stream(self.stream)
+    with API_LOCK:
+      torch.cuda.synchronize(self.device)
+      check = CHECK_CAPTURE_ALLOCS
+      allocs = torch.cuda.memory_stats(self.device).get('allocation.all.allocated', 0) if check else 0
+      self.stream.wait_stream(torch.cuda.current_stream(self.device))
+      with torch.cuda.stream(self.stream):
+        self.capturing = True
+        self._begin()
+        try:
+          fn()
+        finally:
+          self.capturing = False
+          self._end()
+      torch.cuda.current_stream(self.device).wait_stream(self.stream)
+      if check:
+        after = torch.cuda.memory_stats(self.device).get('allocation.all.allocated', 0)
+        if after != allocs:
+          raise RuntimeError(f'{after - allocs} device allocations inside a captured segment')
 
   def cut(self, fn):
     if not self.capturing:
@@ -90,29 +153,35 @@ class GraphPlan:
     self.items.append(('cond', (pred, g)))
     self._begin()
 
-  def _run(self, start=0, stop=None):
+  def _launch(self, exe, stream):
+    if exe:
+      self._check(self.lib.dd_graph_launch(exe, stream.cuda_stream), 'dd_graph_launch')
+
+  def _run(self, stream, start=0, stop=None):
     for kind, item in self.items[start:stop]:
       if kind == 'graph':
-        item.replay()
+        self._launch(item, stream)
       elif kind == 'cond':
         if item[0]():
-          item[1].replay()
+          self._launch(item[1], stream)
       else:
         item()
 
   def replay(self):
-    cur = torch.cuda.current_stream(self.device)
-    self.stream.wait_stream(cur)
-    with torch.cuda.stream(self.stream):
-      self._run()
-    cur.wait_stream(self.stream)
+    with API_LOCK:
+      cur = torch.cuda.current_stream(self.device)
+      self.stream.wait_stream(cur)
+      with torch.cuda.stream(self.stream):
+        self._run(self.stream)
+      cur.wait_stream(self.stream)
 
   def replay_on(self, stream, start=0, stop=None):
     """Enqueue the plan (or its items [start:stop]) on `stream` and return without joining
     any other stream (the caller orders streams with events: agent.Agent's two-stream
     pipeline)."""
-    with torch.cuda.stream(stream):
-      self._run(start, stop)
+    with API_LOCK:
+      with torch.cuda.stream(stream):
+        self._run(stream, start, stop)
 
   @property
   def n_graphs(self):

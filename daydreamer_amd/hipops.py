@@ -85,6 +85,13 @@ _SIGS = {
     'dd_batch_prep': [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_p],
     'dd_tanh_fwd': [c_p, c_p, c_i, c_p],
     'dd_tanh_bwd': [c_p, c_p, c_p, c_i, c_f, c_p],
+    'dd_stream_create': [ctypes.POINTER(c_p)],
+    'dd_stream_destroy': [c_p],
+    'dd_graph_capture_begin': [c_p],
+    'dd_graph_capture_end': [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i)],
+    'dd_graph_launch': [c_p, c_p],
+    'dd_graph_destroy': [c_p],
+    'dd_install_crash_handler': [],
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])

@@ -134,12 +134,12 @@ class Learner:
     # a side HIP stream to overlap weight-gradient contractions with the
     # latency-bound reverse scan (None: everything runs in program order)
     self.ops2 = ops2
-    self.side_stream = (torch.cuda.Stream(self.device)
+    self.side_stream = (graphs.stream(self.device, 'side')
                         if ops2 is not None and self.device.type == 'cuda' else None)
     # ops_b2: the behaviour phase's own side context: the reward / cont / slow-critic heads of
     # finished time chunks run next to the rest of the (latency-bound) imagination rollout
     self.ops_b2 = ops_b2
-    self.side_stream_b = (torch.cuda.Stream(self.device)
+    self.side_stream_b = (graphs.stream(self.device, 'side_b')
                           if ops_b2 is not None and self.device.type == 'cuda' else None)
     self.dtype = dtype  # float32 in the product; tests may use float64
     self.cfg = cfg = spec.cfg
@@ -1460,6 +1460,8 @@ class Learner:
     """The device tensors a metrics read-out needs (name -> tensor)."""
     t = dict(sums=self.stat_sums, maxs=self.stat_maxs, wmkl=self.wmkl_scale, sc=self.sc,
              actent_scale=self.actent_scale, bal=self.bal)
+    if getattr(self, 'scan_sync', None) is not None:
+      t['scan_err'] = self.scan_sync[1:2]   # sticky error word of the persistent scan kernels
     for g in ('model', 'critic', 'actor'):
       t[f'opt_{g}'] = self.groups[g].opt_state
     if not self.discrete:
@@ -1491,6 +1493,14 @@ class Learner:
         bal = self.bal.clone()
         self.comm.allreduce_sum(bal)
         host['bal'] = bal.cpu().numpy()
+    if 'scan_err' in host and int(host['scan_err'][0]) != 0:
+      # a fused observe scan ran on after a grid-barrier timeout (bit 0) or met a carried state
+      # that was not one-hot (bit 1): its outputs are garbage.  Raise like check_numerics
+      # (tfutils.py:207,249) instead of training on them; the word is cleared for the next step.
+      code = int(host['scan_err'][0])
+      self.scan_sync[1:2].zero_()
+      raise RuntimeError(f'fused observe scan failed (error word {code}: '
+                         f'{"grid-barrier timeout" if code & 1 else "carried stoch not one-hot"})')
     sums, maxs = host['sums'], host['maxs']
     N, H, w = self.N, self.H, self.world
     counts = dict(imag_value=(H + 1) * N * w)

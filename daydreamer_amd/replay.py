@@ -67,6 +67,7 @@ class DeviceReplay:
     self.minlen = minlen
     self.prio_starts = prio_starts
     self.prio_ends = prio_ends
+    self._seed = int(seed)
     self.random = np.random.RandomState(seed=seed)
     self.device = torch.device(device)
     self._ops = ops
@@ -86,6 +87,16 @@ class DeviceReplay:
     self.stamps = {}             # episode id -> insertion time (epoch seconds, strictly increasing)
     self._seq = 0
     self._out = {}               # batch size -> output buffers
+
+  def reseed(self, rank):
+    """Rank-dependent sampling stream (data-parallel learners with a rank-sharded dataset:
+    Agent.dataset calls this once, so replays holding the same episodes draw different rows)."""
+    base = getattr(self, '_seed', 0)
+    self.random = np.random.RandomState(seed=base + 7919 * int(rank))
+    prios = getattr(self, 'prios', None)
+    if prios is not None:
+      prios.random = np.random.RandomState(seed=base + 7919 * int(rank))
+    self._rank_seeded = True
 
   # ------------------------------------------------------------ embodied.Replay
 
@@ -314,11 +325,16 @@ class PriorityTable:
       weights = fresh.astype(np.float64)
     n = len(weights)
     uniform = np.full(n, 1.0 / n)
-    if self.prio_starts or self.prio_ends:
+    if (self.prio_starts or self.prio_ends) and n > 1:
+      # (an episode of exactly one chunk has a single start: the reference's up-weighting,
+      # prios.py:88-92, multiplies it by both factors and divides by a zero sum -> NaN
+      # probabilities; such an episode keeps its plain uniform start instead)
       extra = len(self.steps[key]) - n
-      uniform[0] *= extra * self.prio_starts
-      uniform[-1] *= extra * self.prio_ends
-      uniform /= uniform.sum()
+      up = uniform.copy()
+      up[0] *= extra * self.prio_starts
+      up[-1] *= extra * self.prio_ends
+      if up.sum() > 0:
+        uniform = up / up.sum()
     mass = weights.sum()
     weighted = uniform if mass == 0 else weights / mass
     self.start_probs[key] = self.fraction * weighted + (1 - self.fraction) * uniform

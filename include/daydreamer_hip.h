@@ -137,8 +137,10 @@ int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
  * post_logit.  The draw is the shared sampler (latent_core.h): same indices as
  * dd_stats_sample_fwd / dd_onehot_sample_host given the same statistics.
  * wt1..wt4: weight caches from dd_scan_wprep for img_in [U][pad32(S+A)], gru_out [3D][D+U],
- * obs_out[:D] [U][D], obs_stats [S][U].  sync2: two zero-initialisable device words (barrier
- * counter, error word - non-zero after the launch if a bounded spin timed out).  w_in: the
+ * obs_out[:D] [U][D], obs_stats [S][U].  sync2: two zero-initialised device words (barrier
+ * counter, error word).  The launch resets the counter only; the error word is sticky (bit 0: a
+ * bounded grid-barrier spin timed out, bit 1: a carried / initial stoch group was not one-hot):
+ * the host reads it after the step, raises on non-zero and clears it.  w_in: the
  * img_in kernel itself [S+A, U] (the one-hot stoch part of that layer is a gather of its rows);
  * idx_ws: (B*T + B + 1) * G ints of scratch (drawn classes per row, of the carry, of the
  * initial state).
@@ -339,6 +341,22 @@ int dd_replay_gather(const void* ring, long row_bytes, const long long* starts, 
                      void* out, int first_flag, void* stream);
 int dd_tanh_fwd(const float* x, float* y, int n, void* stream);
 int dd_tanh_bwd(const float* x, const float* dy, float* dx, int n, float beta, void* stream);
+
+/* ---- launch runtime: process-owned streams and HIP-graph segments ------------------------
+ * Role of the reference's concrete-function cache (tfagent.py:56-70, tf.function :60-64): the
+ * step is captured once and replayed.  Streams are created per role by the library (never a
+ * handle of a shared pool); a graph executable lives until dd_graph_destroy, which is only
+ * safe after a device synchronisation.  dd_graph_capture_end returns *exec_out = NULL for a
+ * segment without nodes; dd_graph_launch(NULL, ..) is a no-op. */
+int dd_stream_create(void** stream_out);
+int dd_stream_destroy(void* stream);
+int dd_graph_capture_begin(void* stream);
+int dd_graph_capture_end(void* stream, void** exec_out, int* nodes_out);
+int dd_graph_launch(void* exec, void* stream);
+int dd_graph_destroy(void* exec);
+/* Native (C) backtrace to stderr on SIGSEGV / SIGBUS / SIGABRT / SIGFPE / SIGILL, then the
+ * previously installed handler runs (Python's faulthandler, or the default action). */
+int dd_install_crash_handler(void);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,10 @@ def hip():
   import torch
   from daydreamer_amd import hipops
   assert torch.cuda.is_available(), 'gpu test collected without a GPU'
+  # native frames next to faulthandler's Python ones if the process dies in the HIP runtime
+  hipops.load_library().dd_install_crash_handler()
+  from daydreamer_amd import graphs
+  graphs.CHECK_CAPTURE_ALLOCS = True   # captured segments must not allocate
   return hipops.HipOps('cuda:0')
 
 

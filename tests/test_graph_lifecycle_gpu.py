@@ -1,0 +1,154 @@
+"""Lifetime of HIP graphs, streams and the prefetch thread across agents (the round-2 driver
+run died with SIGSEGV inside a graph replay of a fresh agent).  Mirrors the reference contract
+that `Agent.train` can be called from a process that builds several agents and feeds them from
+prefetch threads (tfagent.py:56-70, core/prefetch.py:15-67)."""
+
+import gc
+import itertools
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _agent(B, T, H, **hip):
+  from daydreamer_amd import agent as agent_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=B, replay_chunk=T, imag_horizon=H)
+  cfg = cfg.update({f'hip.{k}': v for k, v in hip.items()})
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  return agent_mod.Agent(obs, act, None, cfg), obs, act
+
+
+def _gen(obs, act, T):
+  from daydreamer_amd import synthetic
+  def gen():
+    for s in itertools.count():
+      ep = synthetic.make_batch(obs, act, 1, T, seed=s % 5, smooth_images=True)
+      yield {k: v[0] for k, v in ep.items()}
+  return gen
+
+
+def test_streams_are_process_owned(hip):
+  """One HIP stream per (device, role), created by the library: never a handle of torch's
+  round-robin stream pool, which other threads / agents / torch.distributed share."""
+  from daydreamer_amd import graphs
+  roles = ('plan', 'side', 'side_b', 'copy', 'pipe0', 'pipe1', 'pipe2', 'pipe3', 'read')
+  ours = {r: graphs.stream('cuda:0', r) for r in roles}
+  assert all(graphs.stream('cuda:0', r) is ours[r] for r in roles)
+  ptrs = {s.cuda_stream for s in ours.values()}
+  assert len(ptrs) == len(roles) and 0 not in ptrs
+  pool = {torch.cuda.Stream('cuda:0').cuda_stream for _ in range(80)}   # cycles the whole pool
+  assert not (pool & ptrs)
+
+
+@pytest.mark.parametrize('modes', [('seq', 'pipe'), ('batcher', 'seq', 'pipe')])
+def test_agents_created_and_dropped_in_a_loop(hip, modes):
+  """x24 {build an agent, eager step, capture, replays, drop it, collect, empty the cache}:
+  graph executables of dropped agents stay registered (never freed under queued work), every
+  new agent captures and replays on the same process-owned streams."""
+  from daydreamer_amd import graphs, synthetic
+  before = graphs.n_live_graphs()
+  for it in range(24):
+    mode = modes[it % len(modes)]
+    B, T, H = 4 + 2 * (it % 2), 6 + 2 * (it % 3), 3 + it % 2
+    ag, obs, act = _agent(B, T, H, pipeline=(mode == 'pipe'))
+    state = None
+    if mode == 'batcher':
+      ds = iter(ag.dataset(_gen(obs, act, T)))
+      for i in range(4):
+        _, state, mets = ag.train(next(ds), state)
+    else:
+      data = synthetic.make_batch(obs, act, B, T, seed=it, smooth_images=True)
+      for i in range(4):
+        _, state, mets = ag.train(data, state)
+      mets = ag.flush() or mets
+    assert helpers.metrics_finite(mets), (it, mode)
+    assert ag._plan is not None and ag._plan.n_graphs >= 2
+    del ag, state
+    gc.collect()
+    if it % 3 == 2:
+      torch.cuda.empty_cache()
+  torch.cuda.synchronize()
+  assert graphs.n_live_graphs() > before   # nothing was destroyed
+
+
+def test_capture_and_replay_next_to_foreign_stream_traffic(hip):
+  """Another thread cycling through torch's stream pool with copies and allocations (what a
+  data loader or torch.distributed does) while agents capture and replay: the learner's
+  streams are its own, so the capture can never land on a stream that thread issues on."""
+  from daydreamer_amd import graphs, synthetic
+  stop = threading.Event()
+  errors = []
+  graphs.CHECK_CAPTURE_ALLOCS = False   # (process-wide counter: the other thread allocates)
+  def noise():
+    try:
+      torch.cuda.set_device(0)
+      src = torch.empty(1 << 20, dtype=torch.uint8).pin_memory()
+      while not stop.is_set():
+        s = torch.cuda.Stream('cuda:0')
+        with torch.cuda.stream(s):
+          d = src.to('cuda:0', non_blocking=True)
+          d.add_(1)
+        s.synchronize()
+    except Exception as e:   # pragma: no cover
+      errors.append(e)
+  th = threading.Thread(target=noise, daemon=True)
+  th.start()
+  try:
+    for it in range(6):
+      ag, obs, act = _agent(4, 6, 3)
+      ds = iter(ag.dataset(_gen(obs, act, 6)))
+      state = None
+      for i in range(5):
+        _, state, mets = ag.train(next(ds), state)
+        assert helpers.metrics_finite(mets)
+      del ag, ds, state
+      gc.collect()
+  finally:
+    stop.set()
+    th.join(timeout=20)
+    graphs.CHECK_CAPTURE_ALLOCS = True
+  assert not errors, errors
+
+
+def test_dropped_agent_stops_its_prefetch_thread(hip):
+  ag, obs, act = _agent(4, 6, 3)
+  ds = ag.dataset(_gen(obs, act, 6))
+  batch = next(ds)
+  assert batch['image'].is_cuda
+  thread = ds._thread
+  assert thread.is_alive()
+  del ag, batch
+  gc.collect()
+  thread.join(timeout=10)
+  assert not thread.is_alive()
+  with pytest.raises(StopIteration):
+    next(ds)
+
+
+def test_scan_error_word_is_sticky_and_raises(hip):
+  """A grid-barrier timeout inside a persistent scan kernel must surface as an exception of
+  train() (check_numerics semantics, tfutils.py:207,249), not as silent garbage."""
+  from daydreamer_amd import synthetic
+  cfgs = helpers.make_config(('a1_vision',), batch_size=4, replay_chunk=6, imag_horizon=3)
+  from daydreamer_amd import agent as agent_mod
+  obs, act = synthetic.config_spaces('a1_vision')
+  ag = agent_mod.Agent(obs, act, None, cfgs)
+  data = synthetic.make_batch(obs, act, 4, 6, seed=0, smooth_images=True)
+  _, state, mets = ag.train(data)
+  L = ag.learner
+  assert L.fused_scan, 'a1 shapes run the persistent scan'
+  _, state, mets = ag.train(data, state)
+  assert int(L.scan_sync[1]) == 0
+  L.scan_sync[1] = 1                       # what a timed-out spin leaves behind
+  with pytest.raises(RuntimeError, match='grid-barrier timeout'):
+    ag.train(data, state)                  # launches reset the counter only: the word survives
+  assert int(L.scan_sync[1]) == 0          # cleared by the read-out
+  _, state, mets = ag.train(data, state)
+  assert helpers.metrics_finite(mets)

@@ -255,3 +255,34 @@ def test_prioritized_batches_and_eviction():
   rep.prioritize(batch['key'].numpy(), np.ones((5, 8)))
   chunk = next(rep.dataset())
   assert chunk['key'].shape == (8, 3) and chunk['prob'].shape == (8,) and chunk['is_first'][0]
+
+
+def test_prioritized_episode_of_exactly_one_chunk():
+  """length == chunk: a single start per episode.  The reference's start / end up-weighting
+  (prios.py:88-92) turns its probability into 0 / 0; here it stays a valid distribution."""
+  rep = replay_mod.DevicePrioritized(chunk=8, capacity=200, device='cpu', ops=ref_ops.RefOps('cpu'),
+                                     prio_starts=0.0, prio_ends=1.0)
+  for traj in episodes([8, 8, 20]):
+    rep.add_traj(traj)
+  for key, p in rep.prios.start_probs.items():
+    assert np.isfinite(p).all() and abs(p.sum() - 1) < 1e-12, (key, p)
+  batch = rep.sample_batch(6)
+  assert batch['key'].shape == (6, 8, 3)
+
+
+def test_reseed_gives_ranks_their_own_draws():
+  """Rank-sharded dataset (Agent.dataset with world > 1): replays with identical contents and
+  the default seed must not hand every rank the same rows."""
+  picks = []
+  for rank in range(2):
+    rep = make(500, 8)
+    for traj in episodes([40, 50, 60]):
+      rep.add_traj(traj)
+    rep.reseed(rank)
+    picks.append(rep.sample_batch(16)['tag'][:, 0].numpy().copy())
+  assert not np.array_equal(picks[0], picks[1])
+  rep0 = make(500, 8)
+  for traj in episodes([40, 50, 60]):
+    rep0.add_traj(traj)
+  rep0.reseed(0)   # rank 0 keeps the seed-0 stream of the single-process learner
+  assert np.array_equal(rep0.sample_batch(16)['tag'][:, 0].numpy(), picks[0])
