@@ -59,7 +59,7 @@ extern "C" int dd_graph_capture_end(void* stream, void** exec_out, int* nodes_ou
   size_t n = 0;
   hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
   if (e != hipSuccess) {
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     dd_set_error("dd_graph_capture_end(nodes)", e);
     return (int)e;
   }
@@ -68,7 +68,7 @@ extern "C" int dd_graph_capture_end(void* stream, void** exec_out, int* nodes_ou
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
-      hipGraphDestroy(graph);
+      (void)hipGraphDestroy(graph);
       dd_set_error("dd_graph_capture_end(instantiate)", e);
       return (int)e;
     }

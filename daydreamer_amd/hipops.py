@@ -85,6 +85,9 @@ _SIGS = {
     'dd_batch_prep': [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_p],
     'dd_tanh_fwd': [c_p, c_p, c_i, c_p],
     'dd_tanh_bwd': [c_p, c_p, c_p, c_i, c_f, c_p],
+    'dd_imag_wprep': [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
+    'dd_imagine_rollout_supported': [c_i] * 9,
+    'dd_imagine_rollout_fwd': [c_i] * 8 + [c_f] * 3 + [ctypes.POINTER(c_p), c_i, c_p],
     'dd_stream_create': [ctypes.POINTER(c_p)],
     'dd_stream_destroy': [c_p],
     'dd_graph_capture_begin': [c_p],
@@ -384,6 +387,31 @@ class HipOps:
         B, T, D, U, G, C, int(flags), unimix, first.data_ptr(), *[t.data_ptr() for t in acts],
         dlogit.data_ptr(), *[w.data_ptr() for w in wts], *[v.data_ptr() for v in vecs],
         *[t.data_ptr() for t in grads], sync2.data_ptr(), self.stream), 'dd_observe_scan_bwd')
+
+  # ---- fused imagination rollout ------------------------------------------------------
+
+  def imagine_rollout_supported(self, D, U, G, C, A, actor_units, actor_layers, prior_layers, discrete):
+    return bool(self.lib.dd_imagine_rollout_supported(D, U, G, C, A, actor_units, actor_layers,
+                                                      prior_layers, int(bool(discrete))))
+
+  def imag_wprep(self, W, planes, col0=0):
+    """Weight cache of the fused rollout: W [K, n] fp32 -> columns col0.. of fragment-major bf16
+    planes [Npad/16, K/32, 3, 64, 8] (zero-initialised by the caller where padded)."""
+    K, n = W.shape
+    assert W.stride(1) == 1 and planes.dtype == torch.int16
+    self._check(self.lib.dd_imag_wprep(W.data_ptr(), W.stride(0), K, n, col0, planes.data_ptr(),
+                                       self.stream), 'dd_imag_wprep')
+
+  def imagine_rollout_fwd(self, N, H, D, U, G, C, A, actor_units, unimix, lo, hi, tensors):
+    """tensors: the 65 device tensors of dd_imagine_rollout_fwd, in header order."""
+    n = len(tensors)
+    assert n in (65, 66)   # (66: + time-stamp buffer, tools/imag_time.py)
+    for t in tensors:
+      assert t.is_contiguous() or t.dim() == 2   # (kernel row slices: contiguous rows)
+    arr = (c_p * n)(*[t.data_ptr() for t in tensors])
+    self._check(self.lib.dd_imagine_rollout_fwd(
+        N, H, D, U, G, C, A, actor_units, unimix, lo, hi, arr, n, self.stream),
+        'dd_imagine_rollout_fwd')
 
   # ---- categorical latent -----------------------------------------------------
 

@@ -418,6 +418,26 @@ class Learner:
         'cont': self._head_acts('cont', M),
         'critic': self._head_acts('critic', H * N),
         'critic_target': self._head_acts('critic_target', M)}
+    # fused imagination rollout (csrc/imag.hip): fragment-major bf16 weight planes
+    ca = self.cfg['actor']
+    self.fused_imag = (bool(self.cfg.get('hip', {}).get('fused_imag', True)) and
+                       self.dtype == torch.float32 and hasattr(self.ops, 'imagine_rollout_fwd') and H >= 1 and
+                       self.ops.imagine_rollout_supported(D, U, G, self.C, A, ca['units'], ca['layers'],
+                                                          self.n_prior, self.discrete))
+    if self.fused_imag:
+      i16 = lambda k, n: torch.zeros(3 * k * ((n + 15) // 16 * 16), dtype=torch.int16, device=self.device)
+      layers, outs = self.heads['actor']
+      pl = self.imag_planes = {}
+      pl['actor0'] = (layers[0].W[:D], i16(D, ca['units']), 0)
+      for i in range(1, ca['layers']):
+        pl[f'actor{i}'] = (layers[i].W, i16(ca['units'], ca['units']), 0)
+      head = i16(ca['units'], 2 * A)
+      pl['head_m'] = (outs[0].W, head, 0)
+      pl['head_s'] = (outs[1].W, head, A)
+      pl['gru'] = (self.P['gru'].W, i16(D + U, 3 * D), 0)
+      for i in range(self.n_prior):
+        pl[f'img_out{i}'] = (self.P[f'img_out_{i}'].W, i16(D if i == 0 else U, U), 0)
+      pl['stats'] = (self.P['img_stats'].W, i16(U, S), 0)
     for k in ('value', 'cont', 'weight', 'value2', 'ent_row'):
       b['i_' + k] = z(M)
     for k in ('reward', 'ret', 'ret2', 'diff', 'crit_loss', 'actor_loss',
@@ -1065,6 +1085,11 @@ class Learner:
     traj = b['traj']
     ca = cfg['actor']
     lo, hi = ca['minstd'], ca['maxstd']
+    if self.fused_imag:
+      self.imagine_rollout_fused()
+      if on_state:
+        on_state(H)
+      return
     if on_state:
       on_state(0)
     for t in range(H + 1):
@@ -1086,6 +1111,33 @@ class Learner:
                       self.G, self.C, self.unimix, 0)
         if on_state:
           on_state(t + 1)
+
+  def imagine_rollout_fused(self):
+    """The H img_steps and H + 1 policy evaluations as one persistent launch
+    (dd_imagine_rollout_fwd): same buffers as the launch sequence above, same values up to the
+    summation order of the contractions (the one-hot stoch inputs are gathered, not multiplied)."""
+    ops, b, cfg = self.ops, self.b, self.cfg
+    ca = cfg['actor']
+    for W, planes, col0 in self.imag_planes.values():   # the weights changed in the optimizer steps
+      ops.imag_wprep(W, planes, col0)
+    pl = self.imag_planes
+    layers, outs = self.heads['actor']
+    acts, oacts = self.acts_im['actor']
+    t = [b['traj'], b['u_img'], b['eps']]
+    for i in range(ca['layers']):
+      t += [pl[f'actor{i}'][1], layers[i].gamma, layers[i].beta, acts[i].z, acts[i].stats, acts[i].out]
+    t += [layers[0].W, pl['head_m'][1], outs[0].bias, outs[1].bias, oacts[0].z, oacts[1].z]
+    P, ai = self.P, self.ai_img_in
+    t += [P['img_in'].W, P['img_in'].gamma, P['img_in'].beta, ai.z, ai.stats, ai.out]
+    t += [pl['gru'][1], P['gru_h'].gamma, P['gru_h'].beta, b['iz3'], b['igstats']]
+    for i in range(self.n_prior):
+      L, a = P[f'img_out_{i}'], self.ai_img_out[i]
+      t += [pl[f'img_out{i}'][1], L.gamma, L.beta, a.z, a.stats, a.out]
+    t += [pl['stats'][1], P['img_stats'].bias, self.ai_img_stats.z]
+    if getattr(self, 'imag_stamps', None) is not None:   # measurement aid (tools/imag_time.py)
+      t.append(self.imag_stamps)
+    ops.imagine_rollout_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'],
+                            self.unimix, ca['minstd'], ca['maxstd'], t)
 
   HEAD_CHUNK = 4  # time rows per chunk of the overlapped head evaluation
 

@@ -342,6 +342,23 @@ int dd_replay_gather(const void* ring, long row_bytes, const long long* starts, 
 int dd_tanh_fwd(const float* x, float* y, int n, void* stream);
 int dd_tanh_bwd(const float* x, const float* dy, float* dx, int n, float beta, void* stream);
 
+/* ---- fused imagination rollout ------------------------------------------------------------
+ * WorldModel.imagine (agent.py:234-254) as one persistent launch: per 16-row block of the N
+ * start states, all H steps of {actor MLP + normal head + action sample, RSSM.img_step
+ * (nets.py:119-138), categorical draw}.  Rows never interact, so there is no grid-wide
+ * synchronisation.  Writes every buffer the per-layer launch sequence writes (pre-norm z,
+ * LayerNorm statistics, outputs per layer, z3, raw statistics, traj[1..H], actions).
+ * dd_imag_wprep: W [K, n] fp32 -> columns col0.. of the fragment-major bf16 plane cache
+ * [Npad/16][K/32][3][64 lanes][8] of a [K, Npad] operand (exact 3-way split).
+ * dd_imagine_rollout_fwd: `ptrs` is a HOST array of n_ptrs = 65 device pointers, order documented
+ * at the definition (csrc/imag.hip).  Shapes: dd_imagine_rollout_supported. */
+int dd_imag_wprep(const float* W, long ld, int K, int n, int col0, void* planes, void* stream);
+int dd_imagine_rollout_supported(int D, int U, int G, int C, int A, int actor_units,
+                                 int actor_layers, int prior_layers, int discrete);
+int dd_imagine_rollout_fwd(int N, int H, int D, int U, int G, int C, int A, int actor_units,
+                           float unimix, float lo, float hi, const void* const* ptrs,
+                           int n_ptrs, void* stream);
+
 /* ---- launch runtime: process-owned streams and HIP-graph segments ------------------------
  * Role of the reference's concrete-function cache (tfagent.py:56-70, tf.function :60-64): the
  * step is captured once and replayed.  Streams are created per role by the library (never a

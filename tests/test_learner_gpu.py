@@ -196,6 +196,71 @@ def test_fused_observe_scan_equals_launch_sequence(hip):
     torch.cuda.empty_cache()
 
 
+def test_fused_imagination_rollout_equals_launch_sequence(hip):
+  """csrc/imag.hip: WorldModel.imagine (H img_steps + H + 1 policy evaluations) as ONE persistent
+  launch against the per-layer launch sequence, inside a whole train step on the same minibatch
+  and weights, at the full configs[1] size, on a ragged row count (N = 21 * 7 = 147: a partly
+  filled 16-row block) and for the 6-dim action space.  Rows whose latent draws all agree must
+  agree in every buffer the backward pass reads to float reassociation; a draw that sat on a CDF
+  edge flips the rest of that row's trajectory (the one-hot inputs are gathered instead of
+  multiplied, so the small contractions sum in a different order) - such rows are counted and
+  must be rare.  The losses of the step agree to the tolerance of the oracle parity tests."""
+  for (name, B, T, H, adim) in (('a1_vision', 50, 50, 15, 16), ('a1_vision', 21, 7, 5, 16),
+                                ('a1_vision', 2, 3, 2, 6)):
+    cfg = helpers.make_config((name,), batch_size=B, replay_chunk=T, imag_horizon=H)
+    plain, sp, shapes, params, data, _, _ = helpers.make_problem(
+        cfg, image=64, vector=16, action=adim, terminals=0.02, smooth=True)
+    Ls, mets = [], []
+    for fused in (True, False):
+      plain2 = dict(plain, hip=dict(plain.get('hip', {}), fused_imag=fused))
+      sp2 = type(sp)(**{**sp.__dict__, 'cfg': plain2})
+      L = learner_mod.Learner(sp2, hip, 'cuda:0', B, T, params=params, noise_seed=7)
+      assert L.fused_imag == fused
+      L.upload(data)
+      L.train_step_device(use_carry=False)
+      torch.cuda.synchronize()
+      mets.append(L.read_metrics())
+      Ls.append(L)
+    A, Bq = Ls
+    N, G, C, D, F = A.N, A.G, A.C, A.D, A.F
+    sa = A.b['traj'][:, :, D:F].reshape(H + 1, N, G, C)
+    sb = Bq.b['traj'][:, :, D:F].reshape(H + 1, N, G, C)
+    assert torch.equal(sa.sum(-1), torch.ones_like(sa.sum(-1)))          # one-hot everywhere
+    same = (sa.argmax(-1) == sb.argmax(-1)).all(-1).all(0)                # rows with identical draws throughout
+    flipped = int((~same).sum())
+    print(f'fused imagination {name} B{B} T{T} H{H} A{adim}: {flipped} of {N} rows contain a flipped draw')
+    assert flipped <= max(1, N // 40)
+    def cmp(x, y, what, rows_per_t, tol=5e-5):
+      x = x.reshape(rows_per_t, N, -1)[:, same].double()
+      y = y.reshape(rows_per_t, N, -1)[:, same].double()
+      err = float((x - y).abs().max() / (y.abs().max() + 1e-30))
+      assert err < tol, (what, err)
+    cmp(A.b['traj'], Bq.b['traj'], 'traj', H + 1)
+    la, lb = A.acts_im['actor'], Bq.acts_im['actor']
+    for i in range(len(la[0])):
+      cmp(la[0][i].z, lb[0][i].z, f'actor{i}.z', H + 1)
+      cmp(la[0][i].stats, lb[0][i].stats, f'actor{i}.stats', H + 1)
+      cmp(la[0][i].out, lb[0][i].out, f'actor{i}.out', H + 1)
+    for i in range(2):
+      cmp(la[1][i].z, lb[1][i].z, f'actor head {i}', H + 1)
+    cmp(A.ai_img_in.z, Bq.ai_img_in.z, 'img_in.z', H)
+    cmp(A.ai_img_in.stats, Bq.ai_img_in.stats, 'img_in.stats', H)
+    cmp(A.ai_img_in.out, Bq.ai_img_in.out, 'img_in.out', H)
+    cmp(A.b['iz3'], Bq.b['iz3'], 'z3', H)
+    cmp(A.b['igstats'], Bq.b['igstats'], 'gstats', H)
+    for i in range(A.n_prior):
+      cmp(A.ai_img_out[i].z, Bq.ai_img_out[i].z, f'img_out{i}.z', H)
+      cmp(A.ai_img_out[i].stats, Bq.ai_img_out[i].stats, f'img_out{i}.stats', H)
+      cmp(A.ai_img_out[i].out, Bq.ai_img_out[i].out, f'img_out{i}.out', H)
+    cmp(A.ai_img_stats.z, Bq.ai_img_stats.z, 'img_stats', H)
+    if flipped == 0:
+      for k in ('model_loss', 'extr_critic_loss', 'actor_loss', 'actor_grad_norm', 'extr_critic_grad_norm'):
+        a_, b_ = float(mets[0][k]), float(mets[1][k])
+        assert abs(a_ - b_) <= 1e-3 * max(abs(b_), 1e-2), (k, a_, b_)
+    del Ls, A, Bq
+    torch.cuda.empty_cache()
+
+
 def test_fused_reverse_scan_equals_launch_sequence(hip):
   """csrc/scan.hip k_observe_scan_bwd: the data gradient of the T obs_steps as ONE persistent
   launch against the per-layer launch sequence, on the same forward state and the same incoming
