@@ -45,6 +45,19 @@ from daydreamer_amd import synthetic
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
+def kernel_sources_sha():
+  """Hash of the HIP sources: the PMC traffic record (profiles/pmc_hbm_traffic.json, collected by
+  a separate rocprofv3 --pmc run, tools/pmc_bench.sh) is only quoted for the kernels it measured."""
+  import hashlib
+  h = hashlib.sha256()
+  src = os.path.join(ROOT, 'daydreamer_amd', 'csrc')
+  for name in sorted(os.listdir(src)):
+    if name.endswith(('.hip', '.h')):
+      h.update(name.encode())
+      h.update(open(os.path.join(src, name), 'rb').read())
+  return h.hexdigest()[:16]
+
+
 def make_config(name):
   cfgs = config_mod.load_configs()
   return config_mod.Config(cfgs['defaults']).update(cfgs[name])
@@ -272,16 +285,21 @@ def main():
     alg_bytes = sum(int(lab.rsplit(' B', 1)[1]) for lab, _, _, _ in trace)
     pmc = None
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
+    pmc_note = None
     if os.path.exists(pmc_path) and args.config == 'a1_vision':
       pmc = json.load(open(pmc_path))
+      if pmc.get('kernel_sources_sha') != kernel_sources_sha():
+        pmc_note = ('profiles/pmc_hbm_traffic.json was measured on other kernel sources '
+                    f'({pmc.get("kernel_sources_sha")}): not quoted')
+        pmc = None
     ach = tot_f / tot_t / 1e12
     roof = dict(
         bound='mfma',
-        kernel='k_mfma_gemm_s3<*> (fp32 GEMM + implicit-GEMM conv on the bf16 matrix pipe: exact 3-way bf16 split, 6 products, fp32 accumulate; incl. split-K reduce)',
+        kernel='k_mfma_gemm_s3<*> + k_imagine_rollout<*> (fp32 GEMM, implicit-GEMM conv and the fused imagination rollout on the bf16 matrix pipe: exact 3-way bf16 split, 6 products, fp32 accumulate; incl. split-K reduce)',
         achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
         frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
         traffic=None if pmc is None else pmc['bytes_per_launch'],
-        traffic_source=None if pmc is None else pmc.get('source'),
+        traffic_source=pmc_note if pmc is None else pmc.get('source'),
         algorithmic_bytes_per_launch=round(alg_bytes / max(len(trace), 1)),
         launches_per_step=len(trace),
         avg_launch_us=round(1e6 * tot_t / max(len(trace), 1), 2),

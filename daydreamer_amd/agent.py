@@ -270,6 +270,12 @@ class Pipeline:
       a, b = self.cands[c]
     else:
       a, b = min(self.periods, key=self.periods.get)
+      if self.comm is not None:
+        # data parallel: every rank measured its own periods in lock-step; all of them run the
+        # pair rank 0 chose (different pairs per rank = different skew at every collective)
+        pick = torch.tensor([a, b], dtype=torch.int64, device=self.device)
+        self.comm.dist.broadcast(pick, src=0, group=self.comm.group)
+        a, b = int(pick[0]), int(pick[1])
       self.tuned = True
       self.ticks = []
       Pipeline.BEST[self.key] = (a, b)

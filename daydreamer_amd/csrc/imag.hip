@@ -47,6 +47,7 @@ struct LayerP {            // a Linear + LayerNorm + ELU layer in one row space
 
 struct ImagArgs {
   int N, H;
+  int t0, t1;              // this launch runs the policy of steps t0 .. t1 - 1 and the img_steps of those < H
   float unimix, lo, hi;
   float* traj;             // [H+1, N, F + A]
   const float* u_img;      // [H, N, G]
@@ -346,7 +347,7 @@ __device__ __forceinline__ int draw_item32(const float (&x)[32], float u, float 
   return idx;
 }
 
-#define TS(i) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && t == 1) a.dbg[i] = wall_clock64()
+#define TS(i) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && t == a.t0 + 1) a.dbg[i] = wall_clock64()
 
 template <int D, int U, int G, int C, int A, int AU>
 __global__ void __launch_bounds__(256, 1)
@@ -376,7 +377,7 @@ k_imagine_rollout(ImagArgs a) {
   const long gg = min(row0 + gr, (long)N - 1);
   const bool glive = row0 + gr < N;
 
-  // ---- prologue: start state (traj[0]) -> deter in LDS, classes of the one-hot stoch
+  // ---- prologue: state of step t0 (traj[t0]) -> deter in LDS, classes of the one-hot stoch
   for (int i = tid; i < A * U; i += 256) wact[i] = a.w_in[(long)S * U + i];
   for (int i = tid; i < AU; i += 256) {
 #pragma unroll
@@ -390,7 +391,8 @@ k_imagine_rollout(ImagArgs a) {
     par[8 * AU + 3 * D + i] = a.gru.beta[i];
   }
   {
-    const float* t0 = a.traj + gg * W;
+    const float* ts = a.traj + ((long)a.t0 * N) * W;
+    const float* t0 = ts + gg * W;
 #pragma unroll
     for (int i = 0; i < D / 128; ++i) {
       float v[8];
@@ -402,7 +404,7 @@ k_imagine_rollout(ImagArgs a) {
     for (int it = sub; it < 16 * G; it += 8) {
       const int r = it & 15, g = it >> 4;
       const long rr = min(row0 + r, (long)N - 1);
-      const float x = a.traj[rr * W + D + g * C + c];
+      const float x = ts[rr * W + D + g * C + c];
       unsigned long long b = __ballot(x == 1.f);
       b = (b >> ((lane >> 5) * 32)) & 0xFFFFFFFFull;
       if (c == 0) cls[r][g] = b ? __ffsll((long long)b) - 1 : -1;
@@ -416,7 +418,7 @@ k_imagine_rollout(ImagArgs a) {
   Stream<4, 8> sO;      // img_out: K = D or U, U columns
   Stream<8, 8> sS;      // img_stats: K = U, half of the S columns per pass
 
-  for (int t = 0; t <= H; ++t) {
+  for (int t = a.t0; t < a.t1; ++t) {
     const long mrow = (long)t * N + gg;         // this thread's row in the [M, ..] / [H*N, ..] buffers
     float* trow = a.traj + ((long)t * N) * W;
 
@@ -730,13 +732,14 @@ constexpr int IMAG_LDS = 16 * ZS * 4 + 16 * 3 * 1024 + 16 * HS * 4 + 16 * 256 * 
 //   39 gru planes  40 gamma  41 beta  42 z3  43 gstats
 //   44.. img_out l = 0..2: planes, gamma, beta, z, stats, out           (6 each -> 44..61)
 //   62 stats planes  63 stats bias  64 raw statistics  [65 optional: 32 x u64 time stamps]
-extern "C" int dd_imagine_rollout_fwd(int N, int H, int D, int U, int G, int C, int A, int actor_units,
-                                      float unimix, float lo, float hi, const void* const* p,
-                                      int n_ptrs, void* stream) {
+extern "C" int dd_imagine_rollout_fwd(int N, int H, int t0, int t1, int D, int U, int G, int C, int A,
+                                      int actor_units, float unimix, float lo, float hi,
+                                      const void* const* p, int n_ptrs, void* stream) {
   DD_REQUIRE(dd_imagine_rollout_supported(D, U, G, C, A, actor_units, 4, 3, 0), "dd_imagine_rollout_fwd: unsupported shape");
   DD_REQUIRE((n_ptrs == 65 || n_ptrs == 66) && N >= 1 && H >= 1, "dd_imagine_rollout_fwd: 65 pointers (+ optional time-stamp buffer)");
+  DD_REQUIRE(0 <= t0 && t0 < t1 && t1 <= H + 1, "dd_imagine_rollout_fwd: 0 <= t0 < t1 <= H + 1");
   ImagArgs a;
-  a.N = N; a.H = H; a.unimix = unimix; a.lo = lo; a.hi = hi;
+  a.N = N; a.H = H; a.t0 = t0; a.t1 = t1; a.unimix = unimix; a.lo = lo; a.hi = hi;
   a.traj = (float*)p[0]; a.u_img = (const float*)p[1]; a.eps = (const float*)p[2];
   auto layer = [&](int i) {
     LayerP L;

@@ -87,7 +87,7 @@ _SIGS = {
     'dd_tanh_bwd': [c_p, c_p, c_p, c_i, c_f, c_p],
     'dd_imag_wprep': [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     'dd_imagine_rollout_supported': [c_i] * 9,
-    'dd_imagine_rollout_fwd': [c_i] * 8 + [c_f] * 3 + [ctypes.POINTER(c_p), c_i, c_p],
+    'dd_imagine_rollout_fwd': [c_i] * 10 + [c_f] * 3 + [ctypes.POINTER(c_p), c_i, c_p],
     'dd_stream_create': [ctypes.POINTER(c_p)],
     'dd_stream_destroy': [c_p],
     'dd_graph_capture_begin': [c_p],
@@ -402,15 +402,24 @@ class HipOps:
     self._check(self.lib.dd_imag_wprep(W.data_ptr(), W.stride(0), K, n, col0, planes.data_ptr(),
                                        self.stream), 'dd_imag_wprep')
 
-  def imagine_rollout_fwd(self, N, H, D, U, G, C, A, actor_units, unimix, lo, hi, tensors):
+  def imagine_rollout_fwd(self, N, H, D, U, G, C, A, actor_units, unimix, lo, hi, tensors, t0=0, t1=None):
     """tensors: the 65 device tensors of dd_imagine_rollout_fwd, in header order."""
+    t1 = H + 1 if t1 is None else t1
     n = len(tensors)
     assert n in (65, 66)   # (66: + time-stamp buffer, tools/imag_time.py)
     for t in tensors:
       assert t.is_contiguous() or t.dim() == 2   # (kernel row slices: contiguous rows)
     arr = (c_p * n)(*[t.data_ptr() for t in tensors])
-    self._check(self.lib.dd_imagine_rollout_fwd(
-        N, H, D, U, G, C, A, actor_units, unimix, lo, hi, arr, n, self.stream),
+    # algorithmic work (SURVEY.md 8d: dense contractions, each once): per row, H + 1 policy
+    # evaluations and H img_steps; bytes: weights once, every activation buffer written once
+    S, F, AU = G * C, D + G * C, actor_units
+    actor = F * AU + 3 * AU * AU + AU * 2 * A
+    img = (S + A) * U + (D + U) * 3 * D + U * D + 2 * U * U + U * S
+    na, ni = t1 - t0, min(t1, H) - t0    # policy evaluations, img_steps of this launch
+    flops = 2.0 * N * (na * actor + ni * img)
+    nbytes = 4 * (actor + img) + 4 * N * (na * (F + A + 8 * AU + 2 * A) + ni * (2 * U + 3 * D + 6 * U + S))
+    self._check(self._traced(f'imagine N{N} H{H} B{nbytes}', flops, lambda: self.lib.dd_imagine_rollout_fwd(
+        N, H, t0, t1, D, U, G, C, A, actor_units, unimix, lo, hi, arr, n, self.stream)),
         'dd_imagine_rollout_fwd')
 
   # ---- categorical latent -----------------------------------------------------

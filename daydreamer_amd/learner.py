@@ -1086,7 +1086,18 @@ class Learner:
     ca = cfg['actor']
     lo, hi = ca['minstd'], ca['maxstd']
     if self.fused_imag:
-      self.imagine_rollout_fused()
+      # one persistent launch.  (hip.imag_split: two launches split at a head-chunk boundary, so
+      # that the overlapped head evaluation of phase_imagine works on the first half meanwhile -
+      # measured at configs[1]: no gain, 7.60 vs 7.48 ms for phase_imagine: the persistent launch
+      # holds 157 of the 256 CUs, the heads crawl on the rest and their second half still runs
+      # after the rollout.  Off by default.)
+      cut = (H + 1) // 2 // self.HEAD_CHUNK * self.HEAD_CHUNK
+      if on_state and 0 < cut <= H and self.cfg.get('hip', {}).get('imag_split', False):
+        self.imagine_rollout_fused(0, cut)     # states 0 .. cut complete
+        on_state(cut - 1)
+        self.imagine_rollout_fused(cut, H + 1, prep=False)
+      else:
+        self.imagine_rollout_fused()
       if on_state:
         on_state(H)
       return
@@ -1112,14 +1123,15 @@ class Learner:
         if on_state:
           on_state(t + 1)
 
-  def imagine_rollout_fused(self):
+  def imagine_rollout_fused(self, t0=0, t1=None, prep=True):
     """The H img_steps and H + 1 policy evaluations as one persistent launch
     (dd_imagine_rollout_fwd): same buffers as the launch sequence above, same values up to the
     summation order of the contractions (the one-hot stoch inputs are gathered, not multiplied)."""
     ops, b, cfg = self.ops, self.b, self.cfg
     ca = cfg['actor']
-    for W, planes, col0 in self.imag_planes.values():   # the weights changed in the optimizer steps
-      ops.imag_wprep(W, planes, col0)
+    if prep:
+      for W, planes, col0 in self.imag_planes.values():   # the weights changed in the optimizer steps
+        ops.imag_wprep(W, planes, col0)
     pl = self.imag_planes
     layers, outs = self.heads['actor']
     acts, oacts = self.acts_im['actor']
@@ -1137,7 +1149,7 @@ class Learner:
     if getattr(self, 'imag_stamps', None) is not None:   # measurement aid (tools/imag_time.py)
       t.append(self.imag_stamps)
     ops.imagine_rollout_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'],
-                            self.unimix, ca['minstd'], ca['maxstd'], t)
+                            self.unimix, ca['minstd'], ca['maxstd'], t, t0, t1)
 
   HEAD_CHUNK = 4  # time rows per chunk of the overlapped head evaluation
 

@@ -351,13 +351,16 @@ int dd_tanh_bwd(const float* x, const float* dy, float* dx, int n, float beta, v
  * dd_imag_wprep: W [K, n] fp32 -> columns col0.. of the fragment-major bf16 plane cache
  * [Npad/16][K/32][3][64 lanes][8] of a [K, Npad] operand (exact 3-way split).
  * dd_imagine_rollout_fwd: `ptrs` is a HOST array of n_ptrs = 65 device pointers, order documented
- * at the definition (csrc/imag.hip).  Shapes: dd_imagine_rollout_supported. */
+ * at the definition (csrc/imag.hip).  A launch runs the policy of steps t0 .. t1 - 1 and the
+ * img_steps of those below H from the state in traj[t0] (0 <= t0 < t1 <= H + 1: the whole rollout
+ * is t0 = 0, t1 = H + 1; a split lets the caller work on finished time rows meanwhile).
+ * Shapes: dd_imagine_rollout_supported. */
 int dd_imag_wprep(const float* W, long ld, int K, int n, int col0, void* planes, void* stream);
 int dd_imagine_rollout_supported(int D, int U, int G, int C, int A, int actor_units,
                                  int actor_layers, int prior_layers, int discrete);
-int dd_imagine_rollout_fwd(int N, int H, int D, int U, int G, int C, int A, int actor_units,
-                           float unimix, float lo, float hi, const void* const* ptrs,
-                           int n_ptrs, void* stream);
+int dd_imagine_rollout_fwd(int N, int H, int t0, int t1, int D, int U, int G, int C, int A,
+                           int actor_units, float unimix, float lo, float hi,
+                           const void* const* ptrs, int n_ptrs, void* stream);
 
 /* ---- launch runtime: process-owned streams and HIP-graph segments ------------------------
  * Role of the reference's concrete-function cache (tfagent.py:56-70, tf.function :60-64): the
