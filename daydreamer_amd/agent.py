@@ -741,7 +741,10 @@ class Agent:
         off = g.offset[p.name]
         out[f'opt/{gname}/m/{p.name}'] = g.m[off:off + p.size].cpu().numpy().copy().reshape(p.shape)
         out[f'opt/{gname}/v/{p.name}'] = g.v[off:off + p.size].cpu().numpy().copy().reshape(p.shape)
-      out[f'opt/{gname}/step'] = np.asarray(g.opt_state.cpu().numpy()[0], np.int64)
+      st = g.opt_state.cpu().numpy()
+      out[f'opt/{gname}/step'] = np.asarray(st[0], np.int64)
+      out[f'opt/{gname}/grad_scale'] = np.asarray(st[3], np.float32)      # tfutils.py:113-114 (Optimizer.variables)
+      out[f'opt/{gname}/good_steps'] = np.asarray(st[4], np.int64)
     out['state/wmkl_scale'] = L.wmkl_scale.cpu().numpy().copy()
     out['state/actent_scale'] = L.actent_scale.cpu().numpy().copy()
     for k, v in L.norm_state.items():
@@ -774,6 +777,9 @@ class Agent:
             buf[off:off + p.size].copy_(torch.as_tensor(np.asarray(arr)).reshape(-1))
       if f'opt/{gname}/step' in data:
         g.opt_state[0] = float(data[f'opt/{gname}/step'])
+      if f'opt/{gname}/grad_scale' in data:
+        g.opt_state[3] = float(data[f'opt/{gname}/grad_scale'])
+        g.opt_state[4] = float(data[f'opt/{gname}/good_steps'])
     if 'state/wmkl_scale' in data:
       L.wmkl_scale.copy_(torch.as_tensor(data['state/wmkl_scale']))
       L.actent_scale.copy_(torch.as_tensor(data['state/actent_scale']))

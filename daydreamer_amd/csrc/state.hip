@@ -225,11 +225,15 @@ k_sumsq_partial(const float* __restrict__ g, long n, double* __restrict__ partia
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// opt_state: [0]=step (as double), [1]=grad norm, [2]=finite flag
+// opt_state: [0]=step (as double), [1]=grad norm, [2]=finite flag, [3]=grad scale, [4]=good steps
 // (one wave: lane l adds partials l, l+64, ...; fixed butterfly order - a single thread
 // walking ~1000 partials took 68 us, three times per step)
+// mixed: the reduced-precision mode's loss-scale controller (reference tfutils.py:225-240,
+// `self._mixed`): an overflow (non-finite gradient) halves the scale and resets the good-step
+// count, 1000 good steps in a row double it, clipped to [1e-4, 1e4]; the update is skipped on
+// overflow (k_adam) and the step count does not advance (tfutils.py:255-260).
 __global__ void __launch_bounds__(64)
-k_norm_finalize(const double* __restrict__ partial, int P, double* __restrict__ st) {
+k_norm_finalize(const double* __restrict__ partial, int P, double* __restrict__ st, int mixed) {
   double s = 0.0;
   for (int i = threadIdx.x; i < P; i += 64) s += partial[i];
   s = wave_sum_d(s);
@@ -239,6 +243,15 @@ k_norm_finalize(const double* __restrict__ partial, int P, double* __restrict__ 
   bool fin = isfinite(norm);
   st[2] = fin ? 1.0 : 0.0;
   if (fin) st[0] += 1.0;  // tfutils.py:260 (step advances only when applied)
+  if (mixed) {
+    const double scale = st[3], good = st[4];
+    double ns, ng;
+    if (!fin) { ns = scale / 2.0; ng = 0.0; }
+    else if (good >= 1000.0) { ns = scale * 2.0; ng = 0.0; }
+    else { ns = scale; ng = good + 1.0; }
+    st[3] = fmin(fmax(ns, 1e-4), 1e4);
+    st[4] = ng;
+  }
 }
 
 // p *= (1 - wd*lr) for i < n_decay, then Adam with bias correction
@@ -419,12 +432,12 @@ extern "C" int dd_scalar_mul(float* dst, const float* a, const float* b, float c
 }
 
 extern "C" int dd_grad_norm(const float* g, long n, double* opt_state, double* ws, size_t ws_bytes,
-                            void* stream) {
+                            int mixed, void* stream) {
   int P = gsz(n, 256, 1024);
   DD_REQUIRE(ws && (size_t)P * sizeof(double) <= ws_bytes, "dd_grad_norm: workspace too small");
   k_sumsq_partial<<<P, 256, 0, (hipStream_t)stream>>>(g, n, ws);
   DD_CHECK_LAUNCH("dd_grad_norm");
-  k_norm_finalize<<<1, 64, 0, (hipStream_t)stream>>>(ws, P, opt_state);
+  k_norm_finalize<<<1, 64, 0, (hipStream_t)stream>>>(ws, P, opt_state, mixed);
   DD_CHECK_LAUNCH("dd_grad_norm(finalize)");
   return 0;
 }

@@ -71,7 +71,7 @@ _SIGS = {
     'dd_autoadapt_update': [c_p, c_p, c_i, c_d, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_p],
     'dd_normalize_update': [c_p, c_p, c_d, c_p, c_d, c_d, c_i, c_i, c_p, c_p],
     'dd_scalar_mul': [c_p, c_p, c_p, c_f, c_i, c_p],
-    'dd_grad_norm': [c_p, c_l, c_p, c_p, c_z, c_p],
+    'dd_grad_norm': [c_p, c_l, c_p, c_p, c_z, c_i, c_p],
     'dd_adam_step': [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
     'dd_fill': [c_p, c_l, c_f, c_p],
     'dd_reset_mask2': [c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_l, c_p],
@@ -628,10 +628,11 @@ class HipOps:
         out.data_ptr(), target.data_ptr(), loss.data_ptr(), out.numel(), thres, kind,
         out7.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_balance_stats')
 
-  def grad_norm(self, g, opt_state):
+  def grad_norm(self, g, opt_state, mixed=False):
+    assert opt_state.numel() >= 5
     self._check(self.lib.dd_grad_norm(
         g.data_ptr(), g.numel(), opt_state.data_ptr(), self.ws.data_ptr(),
-        self.ws_bytes, self.stream), 'dd_grad_norm')
+        self.ws_bytes, int(bool(mixed)), self.stream), 'dd_grad_norm')
 
   def adam_step(self, p, g, m, v, n_decay, opt_state, lr, wd, eps, b1, b2,
                 clip):

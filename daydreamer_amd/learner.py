@@ -69,7 +69,8 @@ class ParamGroup:
       self.gflat = torch.zeros(self.n, dtype=F32, device=device)
       self.m = torch.zeros(self.n, dtype=F32, device=device)
       self.v = torch.zeros(self.n, dtype=F32, device=device)
-      self.opt_state = torch.zeros(3, dtype=torch.float64, device=device)
+      # step, grad norm, finite flag, loss scale (1e4, tfutils.py:165), good steps
+      self.opt_state = torch.tensor([0.0, 0.0, 1.0, 1e4, 0.0], dtype=torch.float64, device=device)
     for p in order:
       off = self.offset[p.name]
       self.p[p.name] = self.flat[off:off + p.size].view(p.shape)
@@ -142,6 +143,11 @@ class Learner:
     self.side_stream_b = (graphs.stream(self.device, 'side_b')
                           if ops_b2 is not None and self.device.type == 'cuda' else None)
     self.dtype = dtype  # float32 in the product; tests may use float64
+    # the reduced-precision mode keeps the reference's mixed-precision optimizer contract
+    # (tfutils.py:164-167, 225-240, 246-260): loss-scale controller state, `*_grad_scale` /
+    # `*_grad_overflow` metrics, update skipped (not an exception) on a non-finite gradient.  bf16
+    # has fp32's exponent range, so the scale is tracked but never needs to be applied.
+    self.mixed = str(spec.cfg.get('hip', {}).get('precision', 'float32')) != 'float32'
     self.cfg = cfg = spec.cfg
     self.B, self.T = batch, length
     self.N = batch * length
@@ -923,7 +929,7 @@ class Learner:
     g = self.groups[name]
     c = self.cfg[cfgkey]
     self.allreduce(g.gflat)
-    self.ops.grad_norm(g.gflat, g.opt_state)
+    self.ops.grad_norm(g.gflat, g.opt_state, self.mixed)
     self.ops.adam_step(g.flat, g.gflat, g.m, g.v, g.n_decay, g.opt_state,
                        c['lr'], c['wd'], c['eps'], 0.9, 0.999, c['clip'])
 
@@ -1621,7 +1627,12 @@ class Learner:
       o = host[f'opt_{gname}']
       mets[f'{pre}{gname}_grad_norm'] = o[1]
       mets[f'{pre}{gname}_grad_steps'] = o[0]
-      if o[2] == 0.0:
+      if self.mixed:   # tfutils.py:231-232, 246-247: overflow is a metric, the norm reads NaN
+        mets[f'{pre}{gname}_grad_scale'] = o[3]
+        mets[f'{pre}{gname}_grad_overflow'] = 1.0 - o[2]
+        if o[2] == 0.0:
+          mets[f'{pre}{gname}_grad_norm'] = float('nan')
+      elif o[2] == 0.0:
         raise FloatingPointError(f'{gname}_norm is not finite')
     mets['extr_critic_loss'] = st['critic_loss']['mean']
     mets['extr_imag_reward_mean'] = st['imag_reward']['mean']

@@ -297,9 +297,12 @@ int dd_normalize_update(double* state, const double* sums, double count,
                         const float* in_scale_dev, double decay, double maxv, int impl,
                         int do_update, float* out_off_scale, void* stream);
 int dd_scalar_mul(float* dst, const float* a, const float* b, float c, int n, void* stream);
-/* opt_state = {step, grad_norm, finite}: tf.linalg.global_norm tfutils.py:243 */
+/* opt_state = {step, grad_norm, finite, grad_scale, good_steps} (5 doubles):
+ * tf.linalg.global_norm tfutils.py:243; the step advances only on a finite norm (:255-260).
+ * mixed != 0: also the loss-scale controller of the reduced-precision mode (tfutils.py:225-240:
+ * overflow halves the scale, 1000 good steps double it, clip [1e-4, 1e4]). */
 int dd_grad_norm(const float* g, long n, double* opt_state, double* ws, size_t ws_bytes,
-                 void* stream);
+                 int mixed, void* stream);
 /* clip + weight decay (first n_decay elements) + Adam, tfutils.py:244-283. */
 int dd_adam_step(float* p, const float* g, float* m, float* v, long n, long n_decay,
                  const double* opt_state, float lr, float wd, float eps, float b1,

@@ -603,13 +603,23 @@ class RefOps:
     vals = [loss * pos, loss * (1 - pos), pr * pos, (1 - pr) * (1 - pos), pos, target, m]
     out7.copy_(torch.stack([v.double().sum() for v in vals]))
 
-  def grad_norm(self, g, opt_state):
+  def grad_norm(self, g, opt_state, mixed=False):
     norm = math.sqrt(float((g.double() ** 2).sum()))
     opt_state[1] = norm
     fin = math.isfinite(norm)
     opt_state[2] = 1.0 if fin else 0.0
     if fin:
       opt_state[0] += 1.0
+    if mixed:  # loss-scale controller, tfutils.py:225-240
+      scale, good = float(opt_state[3]), float(opt_state[4])
+      if not fin:
+        scale, good = scale / 2, 0.0
+      elif good >= 1000:
+        scale, good = scale * 2, 0.0
+      else:
+        good += 1.0
+      opt_state[3] = min(max(scale, 1e-4), 1e4)
+      opt_state[4] = good
 
   def adam_step(self, p, g, m, v, n_decay, opt_state, lr, wd, eps, b1, b2,
                 clip):

@@ -472,13 +472,33 @@ def test_state_kernels(hip, ref):
   # optimizer
   n, nd = 100000, 60000
   p, g, m, v = rnd(n, seed=3), rnd(n, seed=4, scale=5.0), rnd(n, seed=5).abs() * 0.1, rnd(n, seed=6).abs() * 0.1
-  st = torch.tensor([3.0, 0.0, 0.0], dtype=torch.float64)
+  st = torch.tensor([3.0, 0.0, 0.0, 1e4, 7.0], dtype=torch.float64)
   def fn(ops, p, g, m, v, st):
     ops.grad_norm(g, st)
     ops.adam_step(p, g, m, v, nd, st, 1e-3, 1e-2, 1e-6, 0.9, 0.999, 100.0)
   res = both(hip, ref, fn, [p, g, m, v, st], [0, 2, 3, 4])
   for (a, b), nm in zip(res, ['p', 'm', 'v', 'state']):
     close(a, b, rtol=1e-5, what=f'adam {nm}')
+  # reduced-precision mode's loss-scale controller (tfutils.py:225-240): good step counts up,
+  # 1000 good steps double the scale (clipped at 1e4), an overflow halves it, resets the count,
+  # leaves the step number and the parameters alone
+  for st0, gbad, want in (([3.0, 0, 0, 1e3, 7.0], False, [4.0, 1.0, 1e3, 8.0]),
+                          ([3.0, 0, 0, 1e3, 1000.0], False, [4.0, 1.0, 2e3, 0.0]),
+                          ([3.0, 0, 0, 1e4, 1000.0], False, [4.0, 1.0, 1e4, 0.0]),
+                          ([3.0, 0, 0, 1e3, 500.0], True, [3.0, 0.0, 5e2, 0.0])):
+    st = torch.tensor(st0, dtype=torch.float64)
+    g2 = g.clone()
+    if gbad:
+      g2[777] = float('inf')
+    def fn2(ops, p, g2, m, v, st):
+      ops.grad_norm(g2, st, mixed=True)
+      ops.adam_step(p, g2, m, v, nd, st, 1e-3, 1e-2, 1e-6, 0.9, 0.999, 100.0)
+    res = both(hip, ref, fn2, [p, g2, m, v, st], [0, 4])
+    for a in res[1]:
+      got = a.cpu().numpy()
+      assert [got[0], got[2], got[3], got[4]] == want, (st0, got)
+    if gbad:
+      assert torch.equal(res[0][0].cpu(), p) and torch.equal(res[0][1].cpu(), p)
   # autoadapt + normalize
   scale, s2 = torch.tensor([1.0, 0.5, 0.02]), torch.tensor([30.0, 5.0, 10.0], dtype=torch.float64)
   res = both(hip, ref, lambda ops, scale, s2: ops.autoadapt_update(scale, s2, 10.0, 1.0, 0.1, 0.1, 1e-3, 1.0, True),

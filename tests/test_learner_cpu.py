@@ -143,6 +143,52 @@ def test_weight_decay_and_is_first_midsequence():
     assert helpers.rel_err(newp[name], v) < 1e-7, name
 
 
+def test_reduced_precision_mode_keeps_the_mixed_optimizer_contract():
+  """hip.precision: bfloat16 (the counterpart of the reference's tf.precision: float16):
+  `*_grad_scale` / `*_grad_overflow` metrics, the loss-scale controller state, and an update
+  that is skipped - not an exception - when a gradient is not finite (tfutils.py:164-167,
+  225-240, 246-260).  Host logic on the CPU restatement of the kernels."""
+  cfg = helpers.make_config(('a1', 'debug'), batch_size=3, replay_chunk=4, imag_horizon=2)
+  cfg = cfg.update({'hip.precision': 'bfloat16'})
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, image=0, vector=7, action=6)
+  L = learner_mod.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params)
+  assert L.mixed
+  L.upload(data)
+  L.train_step_device(use_carry=False)
+  mets = L.read_metrics()
+  for pre in ('model', 'extr_critic', 'actor'):
+    assert float(mets[f'{pre}_grad_scale']) == 1e4 and float(mets[f'{pre}_grad_overflow']) == 0.0
+    assert float(mets[f'{pre}_grad_steps']) == 1.0
+  assert float(L.groups['actor'].opt_state[4]) == 1.0          # good steps
+  # an overflowing actor gradient: no exception, the step is skipped, the scale halves
+  before = L.groups['actor'].flat.clone()
+  keep = L.opt_step
+  def poisoned(name, cfgkey):
+    if name == 'actor':
+      L.groups['actor'].gflat[5] = float('inf')
+    keep(name, cfgkey)
+  L.opt_step = poisoned
+  L.train_step_device(use_carry=True)
+  mets = L.read_metrics()
+  assert float(mets['actor_grad_overflow']) == 1.0 and np.isnan(float(mets['actor_grad_norm']))
+  assert float(mets['actor_grad_scale']) == 5e3 and float(mets['actor_grad_steps']) == 1.0
+  assert float(mets['model_grad_overflow']) == 0.0 and float(mets['model_grad_steps']) == 2.0
+  assert torch.equal(L.groups['actor'].flat, before)
+  # full precision: the same gradient raises (check_numerics, tfutils.py:249)
+  plain2 = dict(plain, hip=dict(plain.get('hip', {}), precision='float32'))
+  L2 = learner_mod.Learner(type(sp)(**{**sp.__dict__, 'cfg': plain2}), ref_ops.RefOps('cpu'), 'cpu', B, T, params=params)
+  L2.upload(data)
+  keep2 = L2.opt_step
+  def poisoned2(name, cfgkey):
+    if name == 'actor':
+      L2.groups['actor'].gflat[5] = float('inf')
+    keep2(name, cfgkey)
+  L2.opt_step = poisoned2
+  L2.train_step_device(use_carry=False)
+  with pytest.raises(FloatingPointError):
+    L2.read_metrics()
+
+
 def test_report_open_loop_grid():
   """Agent.report: loss metrics + the open-loop video grid layout of
   WorldModel.report (reference agent.py:276-281, tfutils.video_grid)."""
