@@ -100,9 +100,10 @@ __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
 // ---- weight stream -------------------------------------------------------------------------
 // This wave's NT column tiles against the A operand in LDS: k-steps of 32, six MFMAs per tile
 // and k-step, two k-steps of weight fragments in registers.  `wp`: the wave's first tile.
-template <int NT, int KS, bool PRE = false>
+// TKS: k-steps per tile in the plane cache (> KS when a launch phase covers part of K).
+template <int NT, int KS, bool PRE = false, int TKS = KS>
 struct Stream {
-  static constexpr int TILE_BYTES = KS * 3 * 1024;
+  static constexpr int TILE_BYTES = TKS * 3 * 1024;
   uint4 bq[2][NT][3];
   // `wp` is wave-uniform (scalar registers): scalar base + one 32-bit lane offset + immediates
   // (per-lane 64-bit addresses per tile would be hoisted out of the time loop and fill the
@@ -140,11 +141,13 @@ struct Stream {
     }
   }
   // (k-steps 0 and 1 already requested by prefetch(wp))
-  __device__ __forceinline__ void run(const char* wp, const char* abuf, f32x4 (&acc)[NT]) {
+  __device__ __forceinline__ void run(const char* wp, const char* abuf, f32x4 (&acc)[NT], bool zero = true) {
     static_assert(KS % 2 == 0, "k-steps in pairs");
     if (!PRE) { load(0, wp, 0); load(1, wp, 1); }
+    if (zero) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks += 2) {
       step(0, abuf, ks, acc);
@@ -669,6 +672,362 @@ k_imagine_rollout(ImagArgs a) {
   }
 }
 
+
+// ============================================================================================
+// Reverse pass: the data gradient of the imagined rollout (actor_grad 'backprop', reference
+// agent.py:355-356 - tape.gradient through WorldModel.imagine).  Given d score / d state_t through
+// the reward / cont / critic heads in dtraj[t][:, :F] (bulk launches before this one), step
+// t = H .. 1 pulls the gradient of state_t back through the draw's straight-through estimator
+// and RSSM.img_step (img_stats, img_out 2..0, GRU, img_in) to state_{t-1} and action_{t-1}:
+//   dxs   = stats_bwd(xs_{t-1}, dstoch_t)                 softmax + unimix, tfutils.py:376-381
+//   ddet += ln_bwd / W^T chain of img_out 2..0 from dxs @ W_stats^T
+//   dz3, dh_direct = gru_bwd(ddet_t, z3_{t-1}, h_{t-1});  [dh | dx1] = dz3 @ W_gru^T
+//   dz1   = ln_bwd(img_in);  [dstoch_{t-1} | daction_{t-1}] += dz1 @ W_in^T
+// Same decomposition as the forward kernel: one workgroup per 16-row block, no grid
+// synchronisation, A operands built in LDS by the consumer, transposed weight planes streamed.
+// Writes what the per-layer launch sequence (learner._actor_backprop.scan_step) leaves behind:
+// dtraj[t][:, :D] = the total gradient of deter_t, dtraj[t-1][:, D:] += the step's contribution.
+
+struct LayerB {            // backward view of a Linear + LayerNorm + ELU layer
+  const char* planes;      // W^T as fragment-major planes [K_fwd/16 tiles][N_fwd/32 k-steps]
+  const float* gamma;
+  const float* z;
+  const float* st;
+  const float* out;
+};
+
+struct ImagBwdArgs {
+  int N, H;
+  float unimix;
+  const float* traj;       // [H+1, N, F + A]
+  float* dtraj;            // [H+1, N, F + A]
+  const float* xs;         // [H*N, S] raw statistics
+  const char* stats_planes;  // W_stats^T: K = S, N = U
+  LayerB img_out[3];
+  const char* gru_planes;    // W_gru^T: K = 3D, N = D + U
+  const float* gru_gamma;
+  const float* gru_beta;
+  const float* z3;         // [H*N, 3D]
+  const float* gstats;     // [H*N, 2]
+  LayerB img_in;           // planes: W_in^T: K = U, N = S + A
+  unsigned long long* dbg;
+};
+
+// LayerNorm + ELU backward of this thread's chunks: dout rows in zb (columns col0 ..), z / out /
+// statistics of the forward pass from global (requested by load() BEFORE the contraction that
+// produces dout, so their latency hides behind it); dz -> A operand planes (k-steps ks0 ..).
+template <int NC>
+struct LnBwd {
+  float z[NC][8], o[NC][8], gm[NC][8];
+  float2 ms;
+  __device__ __forceinline__ void load(const LayerB& L, long grow) {
+    constexpr int NCOL = NC * 128;
+    const int q = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int k = (q + 16 * i) * 8;
+      ld8(L.z + grow * NCOL + k, z[i]);
+      ld8(L.out + grow * NCOL + k, o[i]);
+      ld8(L.gamma + k, gm[i]);
+    }
+    ms = *reinterpret_cast<const float2*>(L.st + grow * 2);
+  }
+  __device__ __forceinline__ void run(const float* zb, int col0, char* abuf, int ks0) {
+    constexpr int NCOL = NC * 128;
+    const int tid = threadIdx.x, row = tid >> 4, q = tid & 15;
+    const float mean = ms.x, rstd = ms.y;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      float d[8];
+      ld8(zb + row * ZS + col0 + (q + 16 * i) * 8, d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dy = d[j] * (o[i][j] > 0.f ? 1.f : o[i][j] + 1.f);
+        z[i][j] = (z[i][j] - mean) * rstd;          // x hat
+        gm[i][j] = dy * gm[i][j];                   // g
+        s1 += gm[i][j];
+        s2 += gm[i][j] * z[i][j];
+      }
+    }
+    s1 = row16_sum(s1) / (float)NCOL;
+    s2 = row16_sum(s2) / (float)NCOL;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      float dz[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dz[j] = rstd * (gm[i][j] - s1 - z[i][j] * s2);
+      put_operand(abuf, ks0, row, q, i, dz);
+    }
+  }
+};
+
+#define TSB(i) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && t == a.H - 1) a.dbg[i] = wall_clock64()
+
+template <int D, int U, int G, int C, int A>
+__global__ void __launch_bounds__(256, 1)
+k_imagine_reverse(ImagBwdArgs a) {
+  constexpr int S = G * C, F = D + S, W = F + A;
+  static_assert(D == 256 && U == 256 && C == 32 && G == 32 && A <= 16, "compiled shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* zb = reinterpret_cast<float*>(smem);                       // [16][ZS]
+  char* abuf = smem + 16 * ZS * 4;                                  // 16 k-steps x 3 planes x 1 KB
+  float* dhb = reinterpret_cast<float*>(abuf + 16 * 3 * 1024);      // [16][HS] gradient of deter carried to step t - 1
+  float* par = dhb + 16 * HS;                                       // GRU scale [3D], offset [3D]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = a.N, H = a.H;
+  const long row0 = (long)blockIdx.x * 16;
+  const int gr = tid >> 4, gq = tid & 15;
+  const long gg = min(row0 + gr, (long)N - 1);
+  const bool glive = row0 + gr < N;
+
+  for (int i = tid; i < 3 * D; i += 256) { par[i] = a.gru_gamma[i]; par[3 * D + i] = a.gru_beta[i]; }
+  for (int i = tid; i < 16 * HS; i += 256) dhb[i] = 0.f;
+  __syncthreads();
+
+  for (int t = H; t >= 1; --t) {
+    const long mrow = (long)(t - 1) * N + gg;          // this thread's row of step t - 1 in the [H*N, ..] buffers
+    float* dcur = a.dtraj + ((long)t * N) * W;
+    float* dprev = a.dtraj + ((long)(t - 1) * N) * W;
+    const float* tprev = a.traj + ((long)(t - 1) * N) * W;
+    TSB(0);
+    // ================= draw backward + img_stats^T: K = S in two halves of 16 groups
+    LnBwd<U / 128> lnb;
+    lnb.load(a.img_out[2], mrow);
+    f32x4 accs[4];
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      {
+        // item = (row r, group g): one thread, serial over the 32 classes
+        const int r = tid & 15, gl = tid >> 4, g = h * 16 + gl;
+        const long gw = min(row0 + r, (long)N - 1);
+        const float* xp = a.xs + ((long)(t - 1) * N + gw) * S + g * C;
+        const float* dp_ = dcur + gw * W + D + g * C;
+        float x[32], ds[32];
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(xp + c);
+          const float4 e = *reinterpret_cast<const float4*>(dp_ + c);
+          x[c] = q.x; x[c + 1] = q.y; x[c + 2] = q.z; x[c + 3] = q.w;
+          ds[c] = e.x; ds[c + 1] = e.y; ds[c + 2] = e.z; ds[c + 3] = e.w;
+        }
+        float m = x[0];
+#pragma unroll
+        for (int c = 1; c < 32; ++c) m = fmaxf(m, x[c]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { x[c] = fexp_(x[c] - m); sum += x[c]; }
+        const float inv = 1.f / sum;
+        // pm = (1 - unimix) p + unimix / C; the straight-through sample passes d pm = d stoch
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          x[c] *= inv;                                  // p
+          ds[c] *= (1.f - a.unimix);                    // dp
+          dot += ds[c] * x[c];
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+          float dx[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dx[j] = x[c8 * 8 + j] * (ds[c8 * 8 + j] - dot);
+          uint4 pl[3];
+          split8(dx, pl);
+          // class chunk c8 of group gl is fragment lane c8 * 16 + r of k-step gl
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(abuf + ((gl * 3 + p) * 64 + c8 * 16 + r) * 16) = pl[p];
+        }
+      }
+      __syncthreads();
+      Stream<4, 16, false, 32> sT;
+      sT.run(a.stats_planes + (long)(wave * 4) * (32 * 3072) + h * 16 * 3072, abuf, accs, h == 0);
+      __syncthreads();
+    }
+    tiles_to_z<4, false>(accs, zb, wave * 64, nullptr);
+    __syncthreads();
+    TSB(1);
+    // ================= img_out 2 .. 0: LayerNorm / ELU backward, W^T
+#pragma unroll 1
+    for (int l = 2; l >= 0; --l) {
+      lnb.run(zb, 0, abuf, 0);
+      __syncthreads();
+      if (l > 0) lnb.load(a.img_out[l - 1], mrow);      // the next layer's activations travel during the contraction
+      Stream<4, 8> sO;
+      f32x4 acc[4];
+      sO.run(a.img_out[l].planes + (long)(wave * 4) * Stream<4, 8>::TILE_BYTES, abuf, acc);
+      tiles_to_z<4, false>(acc, zb, wave * 64, nullptr);
+      __syncthreads();
+    }
+    TSB(2);
+    // ================= GRU backward
+    {
+      constexpr int NC = 3 * D / 128, ND = D / 128;
+      float v[NC][8], dy[NC][8];   // (the normalised z3 is recomputed from v where needed: a third array spills)
+#pragma unroll
+      for (int i = 0; i < NC; ++i) ld8(a.z3 + mrow * (3 * D) + (gq + 16 * i) * 8, v[i]);
+      const float2 ms = *reinterpret_cast<const float2*>(a.gstats + mrow * 2);
+      const float mean = ms.x, rstd = ms.y;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int d = (gq + 16 * i) * 8;
+        float hp[8], dd[8], carry[8], rec[8], dhd[8];
+        ld8(tprev + gg * W + d, hp);
+        ld8(dcur + gg * W + d, dd);
+        ld8(dhb + gr * HS + d, carry);
+        ld8(zb + gr * ZS + d, rec);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dd[j] = (dd[j] + carry[j]) + rec[j];     // total gradient of deter_t
+        if (glive) st8(dcur + gg * W + d, dd);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xr = (v[i][j] - mean) * rstd, xc = (v[i + ND][j] - mean) * rstd, xu = (v[i + 2 * ND][j] - mean) * rstd;
+          const float yr = xr * par[d + j] + par[3 * D + d + j];
+          const float yc = xc * par[D + d + j] + par[4 * D + d + j];
+          const float yu = xu * par[2 * D + d + j] + par[5 * D + d + j];
+          const float r = sigmoidf_(yr);
+          const float cand = tanhf(r * yc);
+          const float u = sigmoidf_(yu - 1.f);
+          const float du = dd[j] * (cand - hp[j]);
+          const float dc = dd[j] * u;
+          dhd[j] = dd[j] * (1.f - u);
+          const float dpre = dc * (1.f - cand * cand);
+          const float dyc = dpre * r, dyr = dpre * yc * r * (1.f - r), dyu = du * u * (1.f - u);
+          dy[i][j] = dyr * par[d + j]; dy[i + ND][j] = dyc * par[D + d + j]; dy[i + 2 * ND][j] = dyu * par[2 * D + d + j];
+          s1 += dy[i][j] + dy[i + ND][j] + dy[i + 2 * ND][j];
+          s2 += dy[i][j] * xr + dy[i + ND][j] * xc + dy[i + 2 * ND][j] * xu;
+        }
+        st8(dhb + gr * HS + d, dhd);          // direct path (1 - update) * dh'; the W^T part is added below
+      }
+      s1 = row16_sum(s1) / (float)(3 * D);
+      s2 = row16_sum(s2) / (float)(3 * D);
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dy[i][j] = rstd * (dy[i][j] - s1 - (v[i][j] - mean) * rstd * s2);   // dz3
+      // [dh | dx1] = dz3 @ W_gru^T, K = 3D in two parts (the operand buffer holds 16 k-steps)
+      __syncthreads();                     // zb (rec) and abuf free
+#pragma unroll
+      for (int i = 0; i < 4; ++i) put_operand(abuf, 0, gr, gq, i, dy[i]);
+      __syncthreads();
+      lnb.load(a.img_in, mrow);            // img_in's activations travel during the contraction
+      // (two groups of 4 tiles per wave: 8 tiles' weight fragments at once do not fit the registers
+      // next to the second part of dz3)
+      f32x4 acc0[4], acc1[4];
+      const char* wg = a.gru_planes + (long)(wave * 8) * (24 * 3072);
+      {
+        Stream<4, 16, false, 24> sG;
+        sG.run(wg, abuf, acc0, true);
+        sG.run(wg + (long)4 * (24 * 3072), abuf, acc1, true);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 4; i < NC; ++i) put_operand(abuf, -16, gr, gq, i, dy[i]);
+      __syncthreads();
+      {
+        Stream<4, 8, false, 24> sG2;
+        sG2.run(wg + 16 * 3072, abuf, acc0, false);
+        sG2.run(wg + (long)4 * (24 * 3072) + 16 * 3072, abuf, acc1, false);
+      }
+      tiles_to_z<4, false>(acc0, zb, wave * 128, nullptr);
+      tiles_to_z<4, false>(acc1, zb, wave * 128 + 64, nullptr);
+    }
+    __syncthreads();
+    TSB(3);
+    // ================= dh carry, img_in backward
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) {
+      const int d = (gq + 16 * i) * 8;
+      float x[8], y[8];
+      ld8(dhb + gr * HS + d, x);
+      ld8(zb + gr * ZS + d, y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] += y[j];
+      st8(dhb + gr * HS + d, x);
+    }
+    lnb.run(zb, D, abuf, 0);
+    __syncthreads();
+    TSB(4);
+    // [dstoch_{t-1} | daction_{t-1}] += dz1 @ W_in^T : S columns in two passes of 8 tiles per wave
+#pragma unroll 1
+    for (int ps_ = 0; ps_ < S / 512; ++ps_) {
+      Stream<8, 8> sI;
+      f32x4 acc[8];
+      sI.run(a.img_in.planes + (long)(ps_ * 32 + wave * 8) * Stream<8, 8>::TILE_BYTES, abuf, acc);
+      // through the z buffer: the accumulation into dtraj[t - 1] is a row-wise pass of 32-byte
+      // accesses, all loads in flight together (4-byte read-modify-writes straight from the tile
+      // layout serialise one memory latency per element)
+      __syncthreads();          // zb readers of the previous pass / of ln_bwd are done
+      tiles_to_z<8, false>(acc, zb, wave * 128, nullptr);
+      __syncthreads();
+      if (glive) {
+        float o[4][8], d[4][8];
+        float* dst = dprev + gg * W + D + ps_ * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ld8(dst + (gq + 16 * i) * 8, o[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ld8(zb + gr * ZS + (gq + 16 * i) * 8, d[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[i][j] += d[i][j];
+          st8(dst + (gq + 16 * i) * 8, o[i]);
+        }
+      }
+    }
+    if (wave == 0) {   // the action columns: one tile (tile S / 16 of the cache)
+      uint4 bq[8][3];
+      const char* wp = a.img_in.planes + (long)(S / 16) * Stream<8, 8>::TILE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[ks][p] = *reinterpret_cast<const uint4*>(wp + (ks * 3 + p) * 1024 + (unsigned)lane * 16u);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 av[3], b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          av[p] = *reinterpret_cast<const bf16x8*>(abuf + ((ks * 3 + p) * 64 + lane) * 16);
+          b[p] = __builtin_bit_cast(bf16x8, bq[ks][p]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[0], acc, 0, 0, 0);
+      }
+      const int col = lane & 15;
+      if (col < A) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long rw = row0 + (lane >> 4) * 4 + r;
+          if (rw < N) dprev[rw * W + F + col] += acc[r];
+        }
+      }
+    }
+    __syncthreads();   // the next step reads dtraj[t - 1] (written above) and reuses abuf / zb
+    TSB(5);
+  }
+  // the gradient of the start states' deter (nothing consumes it; written for the launch
+  // sequence's dtraj[0], which it leaves complete)
+  if (glive) {
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) {
+      const int d = (gq + 16 * i) * 8;
+      float x[8], y[8];
+      ld8(a.dtraj + gg * W + d, x);
+      ld8(dhb + gr * HS + d, y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] += y[j];
+      st8(a.dtraj + gg * W + d, x);
+    }
+  }
+}
+
 // W [K, n] fp32 (row stride ld) -> fragment-major bf16 planes of an [K, Npad] operand, columns
 // col0 .. col0 + n (other columns of the destination are left untouched: zero-initialised pads).
 __global__ void k_imag_wprep(const float* __restrict__ W, long ld, int K, int n, int col0,
@@ -694,6 +1053,91 @@ __global__ void k_imag_wprep(const float* __restrict__ W, long ld, int K, int n,
 }
 
 }  // namespace
+
+namespace {
+// The same for the transposed operand: W stored [n, K] (row stride ld), B[k][col] = W[col][k].
+__global__ void k_imag_wprep_t(const float* __restrict__ W, long ld, int K, int n, char* __restrict__ planes) {
+  const int KS = K / 32;
+  const long total = (long)((n + 15) / 16) * KS * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long tk = i >> 6;
+    const int ks = (int)(tk % KS), tile = (int)(tk / KS);
+    const int col = tile * 16 + (lane & 15);
+    const int k0 = ks * 32 + (lane >> 4) * 8;
+    float v[8];
+    if (col < n) ld8(W + (long)col * ld + k0, v);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    uint4 pl[3];
+    split8(v, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<uint4*>(planes + (((long)tile * KS + ks) * 3 + p) * 1024 + lane * 16) = pl[p];
+  }
+}
+
+}  // namespace
+
+extern "C" int dd_imag_wprep_t(const float* W, long ld, int K, int n, void* planes, void* stream) {
+  DD_REQUIRE(K % 32 == 0 && n >= 1 && ld % 4 == 0, "dd_imag_wprep_t: K multiple of 32, ld multiple of 4");
+  const long total = (long)((n + 15) / 16) * (K / 32) * 64;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  k_imag_wprep_t<<<blocks, 256, 0, (hipStream_t)stream>>>(W, ld, K, n, (char*)planes);
+  DD_CHECK_LAUNCH("dd_imag_wprep_t");
+  return 0;
+}
+
+namespace {
+constexpr int IMAG_BWD_LDS = 16 * ZS * 4 + 16 * 3 * 1024 + 16 * HS * 4 + 6 * 256 * 4;
+}
+
+// ptrs (device pointers, in this order):
+//   0 traj  1 dtraj  2 raw statistics  3 img_stats^T planes
+//   4.. img_out l = 0..2: W^T planes, gamma, z, stats, out               (5 each -> 4..18)
+//   19 gru^T planes  20 gru gamma  21 gru beta  22 z3  23 gstats
+//   24 img_in^T planes  25 gamma  26 z  27 stats  28 out   [29 optional: 8 x u64 time stamps]
+extern "C" int dd_imagine_rollout_bwd(int N, int H, int D, int U, int G, int C, int A, float unimix,
+                                      const void* const* p, int n_ptrs, void* stream) {
+  DD_REQUIRE(dd_imagine_rollout_supported(D, U, G, C, A, 512, 4, 3, 0), "dd_imagine_rollout_bwd: unsupported shape");
+  DD_REQUIRE((n_ptrs == 29 || n_ptrs == 30) && N >= 1 && H >= 1, "dd_imagine_rollout_bwd: 29 pointers");
+  ImagBwdArgs a;
+  a.N = N; a.H = H; a.unimix = unimix;
+  a.traj = (const float*)p[0]; a.dtraj = (float*)p[1]; a.xs = (const float*)p[2];
+  a.stats_planes = (const char*)p[3];
+  for (int l = 0; l < 3; ++l) {
+    a.img_out[l].planes = (const char*)p[4 + 5 * l]; a.img_out[l].gamma = (const float*)p[5 + 5 * l];
+    a.img_out[l].z = (const float*)p[6 + 5 * l]; a.img_out[l].st = (const float*)p[7 + 5 * l];
+    a.img_out[l].out = (const float*)p[8 + 5 * l];
+  }
+  a.gru_planes = (const char*)p[19]; a.gru_gamma = (const float*)p[20]; a.gru_beta = (const float*)p[21];
+  a.z3 = (const float*)p[22]; a.gstats = (const float*)p[23];
+  a.img_in.planes = (const char*)p[24]; a.img_in.gamma = (const float*)p[25]; a.img_in.z = (const float*)p[26];
+  a.img_in.st = (const float*)p[27]; a.img_in.out = (const float*)p[28];
+  a.dbg = n_ptrs == 30 ? (unsigned long long*)p[29] : nullptr;
+  const int blocks = (N + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  bool launched = false;
+#define XB(d, u, g, c, a_)                                                                       \
+  if (!launched && D == d && U == u && G == g && C == c && A == a_) {                            \
+    static bool attr = false;                                                                    \
+    if (!attr) {                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)k_imagine_reverse<d, u, g, c, a_>,         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, IMAG_BWD_LDS); \
+      if (e != hipSuccess) { dd_set_error("dd_imagine_rollout_bwd(attr)", e); return (int)e; }   \
+      attr = true;                                                                               \
+    }                                                                                            \
+    k_imagine_reverse<d, u, g, c, a_><<<blocks, 256, IMAG_BWD_LDS, st>>>(a);                     \
+    launched = true;                                                                             \
+  }
+  XB(256, 256, 32, 32, 16) XB(256, 256, 32, 32, 6)
+#undef XB
+  DD_CHECK_LAUNCH("dd_imagine_rollout_bwd");
+  return 0;
+}
 
 extern "C" int dd_imag_wprep(const float* W, long ld, int K, int n, int col0, void* planes, void* stream) {
   DD_REQUIRE(K % 32 == 0 && n >= 1 && col0 >= 0, "dd_imag_wprep: K multiple of 32");

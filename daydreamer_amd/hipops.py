@@ -87,6 +87,8 @@ _SIGS = {
     'dd_tanh_bwd': [c_p, c_p, c_p, c_i, c_f, c_p],
     'dd_imag_wprep': [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     'dd_imagine_rollout_supported': [c_i] * 9,
+    'dd_imag_wprep_t': [c_p, c_l, c_i, c_i, c_p, c_p],
+    'dd_imagine_rollout_bwd': [c_i] * 7 + [c_f] + [ctypes.POINTER(c_p), c_i, c_p],
     'dd_imagine_rollout_fwd': [c_i] * 10 + [c_f] * 3 + [ctypes.POINTER(c_p), c_i, c_p],
     'dd_stream_create': [ctypes.POINTER(c_p)],
     'dd_stream_destroy': [c_p],
@@ -401,6 +403,26 @@ class HipOps:
     assert W.stride(1) == 1 and planes.dtype == torch.int16
     self._check(self.lib.dd_imag_wprep(W.data_ptr(), W.stride(0), K, n, col0, planes.data_ptr(),
                                        self.stream), 'dd_imag_wprep')
+
+  def imag_wprep_t(self, W, planes):
+    """Transposed weight cache of the fused reverse rollout: W [n, K] fp32 -> fragment-major bf16
+    planes of the operand B[k][col] = W[col][k]  ([ceil(n/16), K/32, 3, 64, 8])."""
+    n, K = W.shape
+    assert W.stride(1) == 1 and planes.dtype == torch.int16
+    self._check(self.lib.dd_imag_wprep_t(W.data_ptr(), W.stride(0), K, n, planes.data_ptr(),
+                                         self.stream), 'dd_imag_wprep_t')
+
+  def imagine_rollout_bwd(self, N, H, D, U, G, C, A, unimix, tensors):
+    """tensors: the 29 (+ optional time-stamp buffer) device tensors of dd_imagine_rollout_bwd."""
+    n = len(tensors)
+    assert n in (29, 30)
+    arr = (c_p * n)(*[t.data_ptr() for t in tensors])
+    S = G * C
+    img = (S + A) * U + (D + U) * 3 * D + U * D + 2 * U * U + U * S
+    flops = 2.0 * N * H * img
+    nbytes = 4 * img + 4 * N * H * ((D + S) + S + 3 * D + 8 * U + D + S + A)
+    self._check(self._traced(f'imagine_bwd N{N} H{H} B{nbytes}', flops, lambda: self.lib.dd_imagine_rollout_bwd(
+        N, H, D, U, G, C, A, unimix, arr, n, self.stream)), 'dd_imagine_rollout_bwd')
 
   def imagine_rollout_fwd(self, N, H, D, U, G, C, A, actor_units, unimix, lo, hi, tensors, t0=0, t1=None):
     """tensors: the 65 device tensors of dd_imagine_rollout_fwd, in header order."""

@@ -426,6 +426,7 @@ class Learner:
         'critic_target': self._head_acts('critic_target', M)}
     # fused imagination rollout (csrc/imag.hip): fragment-major bf16 weight planes
     ca = self.cfg['actor']
+    self.fused_imag_bwd = False
     self.fused_imag = (bool(self.cfg.get('hip', {}).get('fused_imag', True)) and
                        self.dtype == torch.float32 and hasattr(self.ops, 'imagine_rollout_fwd') and H >= 1 and
                        self.ops.imagine_rollout_supported(D, U, G, self.C, A, ca['units'], ca['layers'],
@@ -444,6 +445,16 @@ class Learner:
       for i in range(self.n_prior):
         pl[f'img_out{i}'] = (self.P[f'img_out_{i}'].W, i16(D if i == 0 else U, U), 0)
       pl['stats'] = (self.P['img_stats'].W, i16(U, S), 0)
+      # transposed caches of the reverse pass (dd_imag_wprep_t: W [n, K] -> operand [K, n])
+      self.fused_imag_bwd = (bool(self.cfg.get('hip', {}).get('fused_imag_bwd', True)) and
+                             hasattr(self.ops, 'imagine_rollout_bwd'))
+      plt = self.imag_planes_t = {}
+      plt['stats'] = (self.P['img_stats'].W, i16(S, U))            # [U, S] -> K = S, n = U
+      for i in range(self.n_prior):
+        Wl = self.P[f'img_out_{i}'].W
+        plt[f'img_out{i}'] = (Wl, i16(Wl.shape[1], Wl.shape[0]))
+      plt['gru'] = (self.P['gru'].W, i16(3 * D, D + U))             # [D+U, 3D] -> K = 3D, n = D+U
+      plt['img_in'] = (self.P['img_in'].W, i16(U, S + A))           # [S+A, U] -> K = U, n = S+A
     for k in ('value', 'cont', 'weight', 'value2', 'ent_row'):
       b['i_' + k] = z(M)
     for k in ('reward', 'ret', 'ret2', 'diff', 'crit_loss', 'actor_loss',
@@ -1157,6 +1168,24 @@ class Learner:
     ops.imagine_rollout_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'],
                             self.unimix, ca['minstd'], ca['maxstd'], t, t0, t1)
 
+  def imagine_reverse_fused(self):
+    """Steps t = H .. 1 of the reverse imagination scan (stats / img_out / GRU / img_in backward)
+    as one persistent launch: same dtraj as the launch sequence of _actor_backprop.scan_step."""
+    ops, b, P = self.ops, self.b, self.P
+    for W, planes in self.imag_planes_t.values():
+      ops.imag_wprep_t(W, planes)
+    plt = self.imag_planes_t
+    t = [b['traj'], b['dtraj'], self.ai_img_stats.z, plt['stats'][1]]
+    for i in range(self.n_prior):
+      a = self.ai_img_out[i]
+      t += [plt[f'img_out{i}'][1], P[f'img_out_{i}'].gamma, a.z, a.stats, a.out]
+    t += [plt['gru'][1], P['gru_h'].gamma, P['gru_h'].beta, b['iz3'], b['igstats']]
+    ai = self.ai_img_in
+    t += [plt['img_in'][1], P['img_in'].gamma, ai.z, ai.stats, ai.out]
+    if getattr(self, 'imag_stamps_b', None) is not None:   # measurement aid (tools/imag_time.py)
+      t.append(self.imag_stamps_b)
+    ops.imagine_rollout_bwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, self.unimix, t)
+
   HEAD_CHUNK = 4  # time rows per chunk of the overlapped head evaluation
 
   def phase_imagine(self):
@@ -1369,7 +1398,11 @@ class Learner:
                     dtraj[t - 1][:, D:], 1.0, self.P['img_in'])
       ops.reset_mask_bwd(b['idh'], zr, dtraj[t - 1][:, :D])
     side = self.side_stream_b
-    if self.ops_b2 is None or not self._in_b:
+    if self.fused_imag_bwd:
+      # the reverse scan as one persistent launch (dd_imagine_rollout_bwd) after the bulk heads
+      heads_bwd(0, H + 1)
+      self.imagine_reverse_fused()
+    elif self.ops_b2 is None or not self._in_b:
       heads_bwd(0, H + 1)
       for t in reversed(range(1, H + 1)):
         scan_step(t)

@@ -359,6 +359,16 @@ int dd_tanh_bwd(const float* x, const float* dy, float* dx, int n, float beta, v
  * is t0 = 0, t1 = H + 1; a split lets the caller work on finished time rows meanwhile).
  * Shapes: dd_imagine_rollout_supported. */
 int dd_imag_wprep(const float* W, long ld, int K, int n, int col0, void* planes, void* stream);
+/* Reverse pass (actor_grad 'backprop', agent.py:355-356: the data gradient of the score through
+ * the imagined world model): from d score / d state_t in dtraj[t][:, :F] (heads, bulk launches)
+ * steps t = H .. 1 of {draw straight-through + img_stats, img_out 2..0, GRU, img_in} backward in
+ * one persistent launch; leaves dtraj[t][:, :D] = total gradient of deter_t and adds the step's
+ * contribution to dtraj[t-1][:, D:] (stoch | action), as the per-layer launch sequence does.
+ * dd_imag_wprep_t: the transposed operand, W stored [n, K] -> planes of B[k][col] = W[col][k].
+ * `ptrs`: HOST array of 29 device pointers, order at the definition (csrc/imag.hip). */
+int dd_imag_wprep_t(const float* W, long ld, int K, int n, void* planes, void* stream);
+int dd_imagine_rollout_bwd(int N, int H, int D, int U, int G, int C, int A, float unimix,
+                           const void* const* ptrs, int n_ptrs, void* stream);
 int dd_imagine_rollout_supported(int D, int U, int G, int C, int A, int actor_units,
                                  int actor_layers, int prior_layers, int discrete);
 int dd_imagine_rollout_fwd(int N, int H, int t0, int t1, int D, int U, int G, int C, int A,

@@ -261,6 +261,45 @@ def test_fused_imagination_rollout_equals_launch_sequence(hip):
     torch.cuda.empty_cache()
 
 
+def test_fused_imagination_reverse_equals_launch_sequence(hip):
+  """csrc/imag.hip k_imagine_reverse: the data gradient of the imagined rollout (steps H .. 1 of
+  draw / img_stats / img_out / GRU / img_in backward) as ONE persistent launch against the
+  per-layer launch sequence, inside a whole train step with the same (fused) forward rollout:
+  the gradient of every imagined state and action (dtraj) and the actor's parameter gradients
+  must agree to float reassociation."""
+  for (B, T, H, adim) in ((50, 50, 15, 16), (21, 7, 5, 16), (2, 3, 2, 6)):
+    cfg = helpers.make_config(('a1_vision',), batch_size=B, replay_chunk=T, imag_horizon=H)
+    plain, sp, shapes, params, data, _, _ = helpers.make_problem(
+        cfg, image=64, vector=16, action=adim, terminals=0.02, smooth=True)
+    Ls = []
+    for fused in (True, False):
+      plain2 = dict(plain, hip=dict(plain.get('hip', {}), fused_imag_bwd=fused))
+      sp2 = type(sp)(**{**sp.__dict__, 'cfg': plain2})
+      L = learner_mod.Learner(sp2, hip, 'cuda:0', B, T, params=params, noise_seed=7)
+      assert L.fused_imag and L.fused_imag_bwd == fused
+      L.upload(data)
+      L.train_step_device(use_carry=False)
+      torch.cuda.synchronize()
+      Ls.append(L)
+    A, Bq = Ls
+    assert torch.equal(A.b['traj'], Bq.b['traj'])             # same forward
+    def cmp(x, y, what, tol):
+      x, y = x.double(), y.double()
+      err = float((x - y).abs().max() / (y.abs().max() + 1e-30))
+      assert err < tol, (what, err)
+    F, D = A.F, A.D
+    da, db = A.b['dtraj'], Bq.b['dtraj']
+    cmp(da[:, :, F:], db[:, :, F:], 'd action', 2e-5)
+    cmp(da[:, :, :D], db[:, :, :D], 'd deter', 2e-5)
+    cmp(da[:, :, D:F], db[:, :, D:F], 'd stoch', 2e-5)
+    ga, gb = A.export_grads(), Bq.export_grads()
+    for name in ga:
+      if name.startswith('actor/'):
+        assert helpers.rel_err(ga[name], gb[name]) < 5e-5, name
+    del Ls, A, Bq
+    torch.cuda.empty_cache()
+
+
 def test_fused_reverse_scan_equals_launch_sequence(hip):
   """csrc/scan.hip k_observe_scan_bwd: the data gradient of the T obs_steps as ONE persistent
   launch against the per-layer launch sequence, on the same forward state and the same incoming

@@ -41,3 +41,16 @@ for i, n in enumerate(names[1:], 1):
     print(f'{n:22s} {(ts[i] - prev) / 100.0:8.2f} us')
     prev = ts[i]
 print(f'step total {(ts[25] - ts[0]) / 100.0:.2f} us')
+
+# ---- reverse pass
+L.imag_stamps_b = torch.zeros(8, dtype=torch.int64, device='cuda:0')
+for rep in range(3):
+  e0.record()
+  L.imagine_reverse_fused()
+  e1.record()
+  torch.cuda.synchronize()
+  print(f'reverse launch (incl. weight prep) {e0.elapsed_time(e1):.3f} ms')
+ts = L.imag_stamps_b.cpu().numpy()
+for i, n in enumerate(['draw bwd + stats^T', 'img_out 2..0', 'gru', 'dh + img_in ln', 'img_in^T'], 1):
+  print(f'{n:22s} {(ts[i] - ts[i - 1]) / 100.0:8.2f} us')
+print(f'reverse step total {(ts[5] - ts[0]) / 100.0:.2f} us')
