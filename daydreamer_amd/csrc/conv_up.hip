@@ -31,6 +31,11 @@ __global__ void k_col2im_s2(const float* __restrict__ cols, const float* __restr
 
 }  // namespace
 
+// conv_image.hip: the image-side layer (few output channels) as one parity-form contraction
+int dd_convT_image_fwd(const float* small, const float* w, const float* bias, float* big,
+                       int n_img, int hs, int ws_, int Cs, int hb, int wb, int Cb, int k,
+                       float* wsp, size_t ws_bytes, hipStream_t st);
+
 extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* bias, float* big,
                                int n_img, int hs, int ws_, int Cs, int hb, int wb, int Cb, int k,
                                float* wsp, size_t ws_bytes, void* stream) {
@@ -95,6 +100,11 @@ extern "C" int dd_conv2d_s2_up(const float* small, const float* w, const float* 
       }
       return 0;
     }
+  }
+  static const int image_kernel = getenv("DD_UP_IMAGE") ? atoi(getenv("DD_UP_IMAGE")) : 1;
+  if (image_kernel && Cb <= 8 && gemm_mode() == 6) {
+    const int rc = dd_convT_image_fwd(small, w, bias, big, n_img, hs, ws_, Cs, hb, wb, Cb, k, wsp, ws_bytes, st);
+    if (rc != 1) return rc;   // (1: geometry not covered)
   }
   const int kkc = k * k * Cb;
   const size_t per_img = (size_t)hs * ws_ * kkc * sizeof(float);
