@@ -32,7 +32,7 @@ import bench
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res and res["FETCH_SIZE"]["k_mfma_gemm"][0]:
     nf, vf = res["FETCH_SIZE"]["k_mfma_gemm"]; nw, vw = res["WRITE_SIZE"]["k_mfma_gemm"]
     rec = dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_bench.sh) around "
-               "`python bench.py --steps 3 --warmup 3 --no-cpu-baseline`; FETCH_SIZE doubled (gfx950 counts 128-B "
+               "python bench.py --steps 3 --warmup 3 --no-cpu-baseline; FETCH_SIZE doubled (gfx950 counts 128-B "
                "requests at 64 B); counters are L2-miss side (Infinity-Cache hits included)",
                kernel="k_mfma_gemm_s3<*>", dispatches=nf, fetch_kib_per_launch_reported=round(vf / nf, 2),
                write_kib_per_launch=round(vw / nw, 2),
