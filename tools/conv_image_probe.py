@@ -21,3 +21,24 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 gb = (small.numel() + big.numel()) * 4 / 1e9
 print(f'DD_IMG_DBG={os.environ.get("DD_IMG_DBG", "0")} DD_UP_IMAGE={os.environ.get("DD_UP_IMAGE", "1")}: {ms * 1e3:.1f} us  ({gb / ms:.2f} TB/s algorithmic)')
+
+# ---- image-side filter gradients (decoder last layer k6, encoder first layer k4 on the uint8 image)
+def timeit(fn, reps=10):
+  for _ in range(3):
+    fn()
+  torch.cuda.synchronize()
+  e0.record()
+  for _ in range(reps):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / reps
+dw6 = torch.zeros(6, 6, 3, 64, device='cuda')
+dz = torch.randn(n, 64, 64, 3, device='cuda')
+ms = timeit(lambda: ops.conv_wgrad(dz, small, dw6, 6))
+print(f'conv_wgrad 64x3,30x64 k6: {ms * 1e3:.1f} us')
+img = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, device='cuda')
+s31 = torch.randn(n, 31, 31, 64, device='cuda')
+dw4 = torch.zeros(4, 4, 3, 64, device='cuda')
+ms = timeit(lambda: ops.conv_wgrad(img, s31, dw4, 4, 1.0 / 255.0))
+print(f'conv_wgrad u8 64x3,31x64 k4: {ms * 1e3:.1f} us')
