@@ -1099,8 +1099,19 @@ extern "C" int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* p
   return 0;
 }
 
+// The grid barrier needs all NWG workgroups resident at once (one per CU): on a device (or a
+// compute partition, e.g. CPX mode: 32 CUs) with fewer CUs the persistent kernels would spin
+// into their timeout, so such a device reports "unsupported" and the caller keeps the per-layer
+// launch sequence.  Without a visible device (build / CPU tests) the shape alone decides.
+static bool scan_device_ok() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+  return cus >= NWG;
+}
+
 extern "C" int dd_observe_scan_bwd_supported(int B, int D, int U, int G, int C) {
-  return B >= 1 && B <= 64 && D == 256 && U == 256 && G == 32 && C == 32;
+  return B >= 1 && B <= 64 && D == 256 && U == 256 && G == 32 && C == 32 && scan_device_ok();
 }
 
 extern "C" int dd_observe_scan_bwd(
@@ -1147,7 +1158,7 @@ extern "C" int dd_scan_wprep(const float* W, long ld, int K, int N, int Kp, void
 #define DD_SCAN_SHAPES(X) X(256, 256, 32, 32, 16) X(256, 256, 32, 32, 6) X(512, 512, 32, 32, 6)
 
 extern "C" int dd_observe_scan_supported(int B, int D, int U, int G, int C, int A) {
-  if (B < 1 || B > 64) return 0;
+  if (B < 1 || B > 64 || !scan_device_ok()) return 0;
 #define X(d, u, g, c, a_) if (D == d && U == u && G == g && C == c && A == a_) return 1;
   DD_SCAN_SHAPES(X)
 #undef X

@@ -144,7 +144,9 @@ int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
  * img_in kernel itself [S+A, U] (the one-hot stoch part of that layer is a gather of its rows);
  * idx_ws: (B*T + B + 1) * G ints of scratch (drawn classes per row, of the carry, of the
  * initial state).
- * dd_observe_scan_supported: B <= 64, D and U multiples of 32, classes in {16, 32, 64}. */
+ * dd_observe_scan_supported: the compiled shapes (B <= 64; deter = units = 256 or 512, 32 x 32
+ * latents, the action widths of the BASELINE configs) on a device with at least 64 CUs (the grid
+ * barrier needs every workgroup resident: a smaller compute partition keeps the launch sequence). */
 int dd_observe_scan_supported(int B, int D, int U, int G, int C, int A);
 int dd_scan_wprep(const float* W, long ld, int K, int N, int Kp, void* planes, void* stream);
 int dd_observe_scan_fwd(
