@@ -31,11 +31,14 @@ def main():
   batches = [synthetic.make_batch(obs, act, 6, 8, seed=s, smooth_images=True, terminals=0.1)
              for s in range(3)]
   res = {}
+  # DD_DP_TUNE=1: enough pipelined calls for the stream-pair measurement (12 pairs x 3 steps) to
+  # finish inside the run; every rank must then run the pair rank 0 chose
+  steps = 45 if os.environ.get('DD_DP_TUNE') == '1' else 6
   for mode in (False, True):
     ag = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': mode}))
     assert ag.world == world and ag.rank == rank and ag.ops.name == 'hip'
     state = None
-    for i in range(6):
+    for i in range(steps):
       batch = batches[i % 3]
       if i >= 3:  # rank-sharded minibatches, as a sharded Agent.dataset yields them
         per = 6 // world
@@ -43,6 +46,14 @@ def main():
       _, state, m = ag.train(batch, state)
     last = ag.flush()
     res[mode] = (ag.save(), last if mode else m)
+  if os.environ.get('DD_DP_TUNE') == '1':
+    best = agent_mod.Pipeline.BEST
+    assert len(best) == 1, best
+    pick = torch.tensor(list(best.values())[0], dtype=torch.int64, device='cuda:0')
+    picks = [torch.zeros_like(pick) for _ in range(world)]
+    dist.all_gather(picks, pick)
+    assert all(torch.equal(p, picks[0]) for p in picks), picks
+    print(f'rank {rank}: stream pair {tuple(int(x) for x in pick)} on every rank', flush=True)
   a, b = res[False][0], res[True][0]
   bad = [k for k in a if not np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True)]
   ma, mb = res[False][1], res[True][1]

@@ -32,9 +32,9 @@ def free_port():
   return p
 
 
-def launch(tmp_path, backend):
+def launch(tmp_path, backend, tune=False):
   env = dict(os.environ, DD_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0',
-             DD_PIPE_TUNE='0')
+             DD_PIPE_TUNE='1' if tune else '0', DD_DP_TUNE='1' if tune else '0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
          '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
          str(ROOT / 'tests' / 'dp_gpu_worker.py'), str(tmp_path)]
@@ -87,3 +87,14 @@ def test_two_ranks_on_hip_kernels_rccl(hip, tmp_path):
                 'one GPU per rank')
   assert r.returncode == 0, r.stdout[-3000:]
   compare(tmp_path)
+
+
+def test_two_ranks_pick_the_same_stream_pair(hip, tmp_path):
+  """The pipeline's stream-pair measurement under data parallelism: every rank measures in
+  lock-step and all adopt rank 0's choice (different pairs per rank would skew the ranks at
+  every collective); parameters stay bit-identical to the sequential schedule through the
+  pair switches (each pair has its own captured graphs)."""
+  r = launch(tmp_path, 'gloo', tune=True)
+  print(r.stdout[-3000:])
+  assert r.returncode == 0, r.stdout[-3000:]
+  assert 'stream pair' in r.stdout
