@@ -1,12 +1,22 @@
 // Stride-2 VALID convolution as an implicit GEMM (encoder forward, decoder backward-data).
 #include "gemm_core.h"
 
+// conv_image.hip: the image-side layer (few `big` channels), rows split once into LDS planes
+int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const float* bias, float* small,
+                       int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, float in_scale,
+                       float* wsp, size_t ws_bytes, hipStream_t st);
+
 extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const float* bias,
                                  float* small, int n_img, int hb, int wb, int Cb,
                                  int hs, int ws_, int Cs, int k, float in_scale,
                                  float* wsp, size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_down: geometry");
+  static const int image_kernel = getenv("DD_DOWN_IMAGE") ? atoi(getenv("DD_DOWN_IMAGE")) : 1;
+  if (image_kernel && Cb <= 4 && gemm_mode() == 6) {
+    const int rc = dd_conv_image_down(big, big_is_u8, w, bias, small, n_img, hb, wb, Cb, hs, ws_, Cs, k, in_scale, wsp, ws_bytes, st);
+    if (rc != 1) return rc;   // (1: geometry not covered)
+  }
   const int M = n_img * hs * ws_, N = Cs, K = k * k * Cb;
   const int kwc = k * Cb;
   const int vb = aligned16(w) && (Cs % 4 == 0);

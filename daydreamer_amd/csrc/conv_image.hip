@@ -186,19 +186,24 @@ k_convT_image(const float* __restrict__ small, const char* __restrict__ planes,
             for (int p = 0; p < 3; ++p)
               af[p] = *reinterpret_cast<const bf16x8*>(patch + p * PLANE + pix * PSTRIDE + kq * 16);
 #pragma unroll
+            // (tap weights as the ROW operand: the result tile is [parity x channel][block], a lane
+            // holds four consecutive outputs of one 2 x 2 block - neighbours in memory)
             for (int t = 0; t < NT; ++t) {
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[t][0], acc[m][t], 0, 0, 0);
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[t][2], acc[m][t], 0, 0, 0);
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[t][1], acc[m][t], 0, 0, 0);
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[t][0], acc[m][t], 0, 0, 0);
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[t][1], acc[m][t], 0, 0, 0);
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[t][0], acc[m][t], 0, 0, 0);
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[2], acc[m][t], 0, 0, 0);
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][2], af[0], acc[m][t], 0, 0, 0);
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][1], af[1], acc[m][t], 0, 0, 0);
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[1], acc[m][t], 0, 0, 0);
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][1], af[0], acc[m][t], 0, 0, 0);
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[0], acc[m][t], 0, 0, 0);
             }
           }
         }
     }
     if (c == NCH - 1) {
-      // epilogue of the tile: element (row (lane >> 4) * 4 + r, column lane & 15) of tile (m, t)
+      // epilogue of the tile: elements (rows (lane >> 4) * 4 + r = outputs n, column lane & 15 = block) of tile (m, t);
+      // output n = (py * 2 + px) * Cb + cb of block (i, j) lives at big[2i + py, 2j + px, cb]: the 2 * Cb outputs
+      // of a parity row are contiguous, and (Cb odd or even) pairs (n, n + 1) with n even never straddle rows
+      // when 2 * Cb is even - stored as 8-byte pairs where both are live
       const int tile = tile_lo + unit / NCH;
       const int tj = tile % tiles_j, ti = (tile / tiles_j) % tiles_i;
       const long img = tile / (tiles_j * tiles_i);
@@ -206,17 +211,23 @@ k_convT_image(const float* __restrict__ small, const char* __restrict__ planes,
       float* dst = big + img * (long)hb * wb * Cb;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int n = t * 16 + (lane & 15);
-        const int par = n / Cb, cb = n - par * Cb, py = par >> 1, px = par & 1;
-        const int y = 2 * i + py;
-        const bool ok = n < 4 * Cb && y < hb && !(dbg & 4);
-        const float bv = (ok && bias) ? bias[cb] : 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
+          const int j = j0 + m * 16 + (lane & 15);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = j0 + m * 16 + (lane >> 4) * 4 + r, x = 2 * j + px;
-            if (ok && x < wb) dst[((long)y * wb + x) * Cb + cb] = acc[m][t][r] + bv;
+          for (int r = 0; r < 4; r += 2) {
+            const int n = t * 16 + (lane >> 4) * 4 + r;            // even; n + 1 is in the same parity row (2 * Cb even)
+            const int py = n / (2 * Cb), w2 = n - py * 2 * Cb;      // w2 = px * Cb + cb, even
+            const int y = 2 * i + py;
+            const bool ok = n < 4 * Cb && y < hb && !(dbg & 4);
+            const int x0 = 2 * j;                                    // the block's first output column
+            if (ok && x0 * Cb + w2 + 1 < wb * Cb) {
+              const float b0 = bias ? bias[w2 % Cb] : 0.f, b1 = bias ? bias[(w2 + 1) % Cb] : 0.f;
+              *reinterpret_cast<float2*>(dst + ((long)y * wb + x0) * Cb + w2) =
+                  make_float2(acc[m][t][r] + b0, acc[m][t][r + 1] + b1);
+            } else if (ok && x0 * Cb + w2 < wb * Cb) {
+              dst[((long)y * wb + x0) * Cb + w2] = acc[m][t][r] + (bias ? bias[w2 % Cb] : 0.f);
+            }
           }
           acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -252,7 +263,7 @@ int dd_convT_image_fwd(const float* small, const float* w, const float* bias, fl
   const int T = k / 2, NT = (4 * Cb + 15) / 16, NCH = Cs / 32;
   if (k % 2 || T < 1 || T > 3 || Cs % 32 || NT > 2 || Cb < 1) return 1;
   if (!(NCH == 1 || NCH == 2) || (NT == 2 && T == 3 && NCH == 2)) return 1;   // (all tap weights resident in LDS)
-  if ((((uintptr_t)small | (uintptr_t)w) & 15) != 0) return 1;
+  if ((((uintptr_t)small | (uintptr_t)w) & 15) != 0 || ((uintptr_t)big & 7) != 0 || (wb * Cb) % 2) return 1;
   if ((long)hs * ws_ * Cs * 4 > (1L << 30)) return 1;      // (32-bit patch offsets inside an image)
   const size_t pbytes = (size_t)NT * T * T * NCH * 3 * 1024;
   if (!wsp || ws_bytes < pbytes) return 1;
@@ -282,5 +293,225 @@ int dd_convT_image_fwd(const float* small, const float* w, const float* bias, fl
 #undef PICK
 #undef LAUNCH
   DD_CHECK_LAUNCH("dd_conv2d_s2_up(image)");
+  return 0;
+}
+
+namespace {
+// ============================================================================================
+// Image-side stride-2 VALID convolution: small[n,i,j,co] = in_scale * sum_{ky,kx,cb}
+// big[n,2i+ky,2j+kx,cb] * W[ky,kx,cb,co] (+ bias) for a `big` tensor with a handful of channels:
+// the encoder's first layer on the uint8 image (nets.py:291-305, Conv2D :547, `/255` of
+// agent.py:129-130 fused) and the data gradient of the decoder's image layer.
+//
+// As a contraction K = k*k*Cb is tiny (48 / 108) and its rows are strided 4-byte (or 1-byte)
+// gathers; the generic implicit GEMM ran these two call sites at 45-65 TFLOP/s (1.4-2 TB/s of their
+// ~0.65 GB).  Here a workgroup owns 4 output rows x 32 output columns of one image: the k + 6
+// image rows it needs are split ONCE into three bf16 planes in LDS (14 KB); K is laid out as
+// k row segments of OPK octets (k*Cb values + zero-weight padding), so an A fragment is 8
+// consecutive values of one image row (four 4-byte LDS reads per plane: the octet starts at an
+// arbitrary 4-byte offset); the filter is a pre-split fragment-major plane cache resident in LDS.
+// Persistent workgroups, the next tile's rows requested while the current one multiplies.
+constexpr int DI = 4, DJ = 32;          // output rows x columns per workgroup tile
+
+// B[(ky, slot)][co] = W[ky, kx, cb, co] for slot = kx*Cb + cb < k*Cb, else 0; K padded to k-steps of 32.
+__global__ void k_conv_image_down_wprep(const float* __restrict__ w, int k, int Cb, int Cs, int OPK, int KS,
+                                        char* __restrict__ planes) {
+  const int NT = Cs / 16;
+  const long total = (long)NT * KS * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long tk = i >> 6;
+    const int ks = (int)(tk % KS), tile = (int)(tk / KS);
+    const int co = tile * 16 + (lane & 15);
+    const int o = ks * 4 + (lane >> 4), ky = o / OPK, oc = o - ky * OPK;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int slot = oc * 8 + j;
+      v[j] = (ky < k && slot < k * Cb) ? w[((long)ky * k * Cb + slot) * Cs + co] : 0.f;
+    }
+    uint4 pl[3];
+    split8(v, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<uint4*>(planes + (((long)tile * KS + ks) * 3 + p) * 1024 + lane * 16) = pl[p];
+  }
+}
+
+template <int KS, int NT, typename TB>
+__global__ void __launch_bounds__(256, 2)
+k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, const float* __restrict__ bias,
+                  float* __restrict__ small, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, int OPK,
+                  float in_scale, int tiles_j, int tiles_i, int n_tiles) {
+  constexpr int EPV = sizeof(TB) == 1 ? 16 : 4;        // elements per 16-byte vector
+  constexpr int RMAX = 12, RSMAX = 264;                // staged rows (k + 6 <= 12), row stride (elements, wb*Cb + 8 <= 264): 19 KB
+  __shared__ __attribute__((aligned(16))) unsigned short patch[3][RMAX * RSMAX];
+  __shared__ __attribute__((aligned(16))) char bl[NT * KS * 3 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int it = tid; it < NT * KS * 3 * 64; it += 256)
+    *reinterpret_cast<uint4*>(bl + (long)it * 16) = *reinterpret_cast<const uint4*>(planes + (long)it * 16);
+  const int rowlen = wb * Cb, RS = rowlen + 8, nrows = k + 2 * (DI - 1);
+  const int vec_per_row = (rowlen + EPV - 1) / EPV, nvec = nrows * vec_per_row;
+  constexpr int NV = 3;                                 // 16-byte vectors of a tile's rows per thread (<= 768 vectors)
+  const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const int tile_lo = blockIdx.x * per, tile_hi = min(n_tiles, tile_lo + per);
+  uint4 pre[NV];
+  auto request = [&](int tile) {
+    const int ti = (tile / tiles_j) % tiles_i;
+    const long img = tile / (tiles_j * tiles_i);
+    const TB* base = big + (img * hb + 2 * ti * DI) * (long)rowlen;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int id = tid + 256 * v;
+      const int r = id / vec_per_row, c = (id - r * vec_per_row) * EPV;
+      const bool ok = id < nvec && 2 * ti * DI + r < hb;
+      pre[v] = ok ? *reinterpret_cast<const uint4*>(base + (long)r * rowlen + c) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (tile_lo < tile_hi) request(tile_lo);
+  __syncthreads();
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    // ---- stage this tile's image rows: split once, three planes
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int id = tid + 256 * v;
+      if (id < nvec) {
+        const int r = id / vec_per_row, c = (id - r * vec_per_row) * EPV;
+        float f[EPV];
+        if constexpr (sizeof(TB) == 1) {
+          const unsigned w4[4] = {pre[v].x, pre[v].y, pre[v].z, pre[v].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f[4 * q] = (float)(w4[q] & 255u); f[4 * q + 1] = (float)((w4[q] >> 8) & 255u);
+            f[4 * q + 2] = (float)((w4[q] >> 16) & 255u); f[4 * q + 3] = (float)(w4[q] >> 24);
+          }
+        } else {
+          f[0] = __uint_as_float(pre[v].x); f[1] = __uint_as_float(pre[v].y);
+          f[2] = __uint_as_float(pre[v].z); f[3] = __uint_as_float(pre[v].w);
+        }
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+          unsigned h0, m0, l0, h1, m1, l1;
+          split3(f[e], h0, m0, l0);
+          split3(f[e + 1], h1, m1, l1);
+          const int o = r * RS + c + e;
+          *reinterpret_cast<unsigned*>(&patch[0][o]) = pack_hi(h0, h1);
+          *reinterpret_cast<unsigned*>(&patch[1][o]) = pack_hi(m0, m1);
+          *reinterpret_cast<unsigned*>(&patch[2][o]) = pack_hi(l0, l1);
+        }
+      }
+    }
+    // (the 8 pad elements behind a row are read by the last octet of the last pixels: finite
+    // garbage times zero weights; they are zeroed once so that no NaN pattern can sit there)
+    if (tile == tile_lo) {
+      for (int it = tid; it < nrows * 8; it += 256) {
+        const int r = it >> 3, e = it & 7;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) patch[p][r * RS + rowlen + e] = 0;
+      }
+    }
+    __syncthreads();
+    if (tile + 1 < tile_hi) request(tile + 1);
+    const int tj = tile % tiles_j, ti = (tile / tiles_j) % tiles_i;
+    const long img = tile / (tiles_j * tiles_i);
+    const int i = ti * DI + wave;                       // this wave's output row
+    // ---- MFMAs: this wave's two M tiles (16 output columns each) x NT column tiles
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const int o = s_ * 4 + q;
+      int ky = o / OPK;
+      const int oc = o - ky * OPK;
+      ky = min(ky, k - 1);                              // (padding octets: zero weights, any valid address)
+      bf16x8 bf[NT][3];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bf[t][p] = *reinterpret_cast<const bf16x8*>(bl + ((t * KS + s_) * 3 + p) * 1024 + lane * 16);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int j = min(tj * DJ + m * 16 + r16, ws_ - 1);
+        const int e0 = (2 * wave + ky) * RS + 2 * j * Cb + oc * 8;      // even element index (RS, Cb*2j, oc*8 even)
+        bf16x8 af[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned* src = reinterpret_cast<const unsigned*>(&patch[p][e0]);
+          af[p] = __builtin_bit_cast(bf16x8, make_uint4(src[0], src[1], src[2], src[3]));
+        }
+#pragma unroll
+        // (filter fragment as the ROW operand: the result tile is [channel][pixel], so a lane ends
+        // up with four consecutive channels of one pixel = one 16-byte store)
+        for (int t = 0; t < NT; ++t) {
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[2], acc[m][t], 0, 0, 0);
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][2], af[0], acc[m][t], 0, 0, 0);
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][1], af[1], acc[m][t], 0, 0, 0);
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[1], acc[m][t], 0, 0, 0);
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][1], af[0], acc[m][t], 0, 0, 0);
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[0], acc[m][t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue: elements (rows (lane >> 4) * 4 + r = channels, column lane & 15 = output column) of tile (m, t)
+    if (i < hs) {
+      float* dst = small + ((img * hs + i) * (long)ws_) * Cs;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int co = t * 16 + (lane >> 4) * 4;
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int j = tj * DJ + m * 16 + (lane & 15);
+          if (j < ws_)
+            *reinterpret_cast<float4*>(dst + (long)j * Cs + co) =
+                make_float4(in_scale * acc[m][t][0] + bv.x, in_scale * acc[m][t][1] + bv.y,
+                            in_scale * acc[m][t][2] + bv.z, in_scale * acc[m][t][3] + bv.w);
+        }
+      }
+    }
+    __syncthreads();     // the patch is free for the next tile
+  }
+}
+
+}  // namespace
+
+// Returns 1 when the geometry is not covered (the caller then takes the generic path).
+int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const float* bias, float* small,
+                       int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, float in_scale,
+                       float* wsp, size_t ws_bytes, hipStream_t st) {
+  const int OPK = (k * Cb + 7) / 8, KS = (k * OPK + 3) / 4, NT = Cs / 16;
+  const int epv = big_is_u8 ? 16 : 4, rowlen = wb * Cb;
+  if (Cb < 1 || Cb > 4 || Cs != 64 || k < 2 || k + 2 * (DI - 1) > 12 || rowlen + 8 > 264) return 1;
+  if (!(KS == 2 || KS == 3 || KS == 5) || rowlen % epv || (rowlen % 2) || ((uintptr_t)big & 15) || ((uintptr_t)w & 3)) return 1;
+  if (((uintptr_t)small & 15) || (bias && ((uintptr_t)bias & 15))) return 1;
+  if ((k + 2 * (DI - 1)) * ((rowlen + epv - 1) / epv) > 768) return 1;
+  if (2 * (ws_ - 1) * Cb + OPK * 8 > rowlen + 8) return 1;          // the last octet stays inside the padded row
+  const size_t pbytes = (size_t)NT * KS * 3 * 1024;
+  if (!wsp || ws_bytes < pbytes) return 1;
+  char* planes = reinterpret_cast<char*>(wsp);
+  const long total = (long)NT * KS * 64;
+  k_conv_image_down_wprep<<<(int)((total + 255) / 256), 256, 0, st>>>(w, k, Cb, Cs, OPK, KS, planes);
+  DD_CHECK_LAUNCH("dd_conv2d_s2_down(image wprep)");
+  const int tj = (ws_ + DJ - 1) / DJ, ti = (hs + DI - 1) / DI;
+  const long nt_ = (long)tj * ti * n_img;
+  if (nt_ > (1 << 30)) return 1;
+  const int n_tiles = (int)nt_;
+  const int grid = n_tiles < 512 ? n_tiles : 512;
+#define LD(KS_)                                                                                        \
+  if (KS == KS_) {                                                                                     \
+    if (big_is_u8) k_conv_image_down<KS_, 4, unsigned char><<<grid, 256, 0, st>>>(                     \
+        (const unsigned char*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles); \
+    else k_conv_image_down<KS_, 4, float><<<grid, 256, 0, st>>>(                                       \
+        (const float*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles); \
+  }
+  LD(2) LD(3) LD(5)
+#undef LD
+  DD_CHECK_LAUNCH("dd_conv2d_s2_down(image)");
   return 0;
 }

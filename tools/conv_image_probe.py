@@ -42,3 +42,13 @@ s31 = torch.randn(n, 31, 31, 64, device='cuda')
 dw4 = torch.zeros(4, 4, 3, 64, device='cuda')
 ms = timeit(lambda: ops.conv_wgrad(img, s31, dw4, 4, 1.0 / 255.0))
 print(f'conv_wgrad u8 64x3,31x64 k4: {ms * 1e3:.1f} us')
+# ---- image-side conv_down: decoder image layer's data gradient (k6) and encoder first layer (k4, uint8)
+w6 = torch.randn(6, 6, 3, 64, device='cuda') * 0.1
+d30 = torch.empty(n, 30, 30, 64, device='cuda')
+ms = timeit(lambda: ops.conv_down(dz, w6, None, d30, 6))
+print(f'DD_DOWN_IMAGE={os.environ.get("DD_DOWN_IMAGE", "1")} conv_down 64x3->30x64 k6: {ms * 1e3:.1f} us')
+w4 = torch.randn(4, 4, 3, 64, device='cuda') * 0.1
+b4 = torch.randn(64, device='cuda')
+z31 = torch.empty(n, 31, 31, 64, device='cuda')
+ms = timeit(lambda: ops.conv_down(img, w4, b4, z31, 4, 1.0 / 255.0))
+print(f'DD_DOWN_IMAGE={os.environ.get("DD_DOWN_IMAGE", "1")} conv_down u8 64x3->31x64 k4: {ms * 1e3:.1f} us')
