@@ -54,3 +54,18 @@ def test_persistent_scan_shape_queries():
   assert fwd(25, 512, 512, 32, 32, 6) == 1 and bwd(25, 512, 512, 32, 32) == 0       # xarm / ur5: forward only
   assert fwd(32, 4096, 256, 64, 64, 16) == 0 and bwd(32, 4096, 256, 64, 64) == 0    # a1_scaled: launch sequence
   assert fwd(16, 128, 128, 8, 32, 6) == 0
+
+
+def test_fused_imagination_shape_queries():
+  """dd_imagine_rollout_supported is host logic (no launch): the learner keeps the per-layer
+  launch sequence wherever it says no.  (deter, units, groups, classes, action dims, actor
+  units, actor layers, prior layers, discrete)"""
+  lib = ctypes.CDLL(str(ROOT / 'daydreamer_amd' / 'libdaydreamer_hip.so'))
+  q = lib.dd_imagine_rollout_supported
+  assert q(256, 256, 32, 32, 16, 512, 4, 3, 0) == 1      # configs[1]
+  assert q(256, 256, 32, 32, 6, 512, 4, 3, 0) == 1       # configs[0]
+  assert q(256, 256, 32, 32, 16, 512, 4, 3, 1) == 0      # one-hot actions: REINFORCE path
+  assert q(512, 512, 32, 32, 6, 512, 4, 3, 1) == 0       # xarm / ur5
+  assert q(4096, 256, 64, 64, 16, 512, 4, 3, 0) == 0     # a1_scaled
+  assert q(256, 256, 32, 32, 16, 512, 2, 3, 0) == 0      # debug block: 2 actor layers
+  assert q(256, 256, 32, 32, 16, 256, 4, 3, 0) == 0
