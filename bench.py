@@ -123,6 +123,9 @@ def main():
   ap.add_argument('--length', type=int, default=0, help='override the config sequence length')
   ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cnn', choices=('simple', 'resnet'), default='simple',
+                  help='image encoder / decoder family (reference encoder.cnn / decoder.cnn); the BASELINE '
+                       'configs use simple')
   ap.add_argument('--precision', choices=('float32', 'bfloat16'), default='float32',
                   help='hip.precision; bfloat16 is the opt-in reduced-precision mode (not the parity mode)')
   ap.add_argument('--pipeline', type=int, default=1,
@@ -154,6 +157,8 @@ def main():
 
   cfg = make_config(args.config).update({'hip.pipeline': bool(args.pipeline),
                                          'hip.precision': args.precision})
+  if args.cnn != 'simple':
+    cfg = cfg.update({'encoder.cnn': args.cnn, 'decoder.cnn': args.cnn})
   if args.batch:
     cfg = cfg.update({'batch_size': args.batch})
   if args.length:
@@ -323,7 +328,8 @@ def main():
         dtype='f32' if args.precision == 'float32' else 'bf16 inputs, f32 accumulate (opt-in reduced precision)',
         data='synthetic',
         config=dict(
-            workload=(f'{args.config} (BASELINE.json configs): batch {Bg} ({B} per GPU) x seq {T} x '
+            workload=(f'{args.config}{" with cnn: " + args.cnn if args.cnn != "simple" else ""} '
+                      f'(BASELINE.json configs): batch {Bg} ({B} per GPU) x seq {T} x '
                       f'horizon {H}; Agent.train with host minibatch in (PCIe upload timed), all three '
                       'optimizers stepped, numpy metrics out'),
             global_batch=Bg, per_gpu_batch=B, seq_len=T, horizon=H, parallelism=f'dp{world}',

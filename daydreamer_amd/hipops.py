@@ -33,6 +33,11 @@ _SIGS = {
     'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
     'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
+    'dd_conv2d_same': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_z, c_p],
+    'dd_conv2d_same_bwd_data': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
+    'dd_conv2d_same_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_z, c_p],
+    'dd_pool2': [c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
+    'dd_repeat2': [c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
     'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_i, c_f, c_p, c_p],
     'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p, c_i, c_f, c_p],
     'dd_ln_bwd_parts': [c_i, c_i],
@@ -274,6 +279,52 @@ class HipOps:
         big.data_ptr(), int(big.dtype == torch.uint8), small.data_ptr(),
         dw.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale, beta,
         self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_s2_wgrad')
+
+  # stride-1 SAME convolutions + 2x2 pooling / repetition (residual encoder / decoder)
+
+  def conv_same(self, x, w, bias, y, k, in_scale=1.0, alpha=1.0, beta=0.0):
+    n, h, wd, cin = x.shape
+    cout = y.shape[3]
+    assert tuple(y.shape) == (n, h, wd, cout) and x.is_contiguous() and y.is_contiguous()
+    assert tuple(w.shape) == (k, k, cin, cout) and w.is_contiguous()
+    fl = 2.0 * n * h * wd * k * k * cin * cout
+    self._check(self._traced(f'conv_same n{n} {h}x{cin}->{cout} k{k} B{x.numel() * x.element_size() + 4 * (w.numel() + y.numel())}', fl, lambda: self.lib.dd_conv2d_same(
+        x.data_ptr(), int(x.dtype == torch.uint8), w.data_ptr(),
+        bias.data_ptr() if bias is not None else None, y.data_ptr(), n, h, wd, cin, cout, k,
+        in_scale, alpha, beta, self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_same')
+
+  def conv_same_bwd(self, dy, w, dx, k, alpha=1.0, beta=0.0):
+    n, h, wd, cout = dy.shape
+    cin = dx.shape[3]
+    assert tuple(dx.shape) == (n, h, wd, cin) and dx.is_contiguous() and dy.is_contiguous()
+    assert tuple(w.shape) == (k, k, cin, cout) and w.is_contiguous()
+    fl = 2.0 * n * h * wd * k * k * cin * cout
+    self._check(self._traced(f'conv_same_bwd n{n} {h}x{cout}->{cin} k{k} B{4 * (dy.numel() + w.numel() + dx.numel())}', fl, lambda: self.lib.dd_conv2d_same_bwd_data(
+        dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, h, wd, cin, cout, k, alpha, beta,
+        self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_same_bwd_data')
+
+  def conv_same_wgrad(self, x, dy, dw, k, in_scale=1.0, alpha=1.0, beta=0.0):
+    n, h, wd, cin = x.shape
+    cout = dy.shape[3]
+    assert tuple(dy.shape) == (n, h, wd, cout) and x.is_contiguous() and dy.is_contiguous()
+    assert tuple(dw.shape) == (k, k, cin, cout) and dw.is_contiguous()
+    fl = 2.0 * n * h * wd * k * k * cin * cout
+    self._check(self._traced(f'conv_same_wgrad n{n} {h}x{cin},{cout} k{k} B{x.numel() * x.element_size() + 4 * (dy.numel() + dw.numel())}', fl, lambda: self.lib.dd_conv2d_same_wgrad(
+        x.data_ptr(), int(x.dtype == torch.uint8), dy.data_ptr(), dw.data_ptr(), n, h, wd, cin,
+        cout, k, in_scale, alpha, beta, self.ws.data_ptr(), self.ws_bytes, self.stream)),
+        'dd_conv2d_same_wgrad')
+
+  def pool2(self, x, y, scale=0.25):
+    n, ho, wo, c = y.shape
+    assert tuple(x.shape) == (n, 2 * ho, 2 * wo, c) and x.is_contiguous() and y.is_contiguous()
+    self._check(self.lib.dd_pool2(x.data_ptr(), y.data_ptr(), n, ho, wo, c, scale, self.stream),
+                'dd_pool2')
+
+  def repeat2(self, x, y, scale=1.0, beta=0.0):
+    n, hi, wi, c = x.shape
+    assert tuple(y.shape) == (n, 2 * hi, 2 * wi, c) and x.is_contiguous() and y.is_contiguous()
+    self._check(self.lib.dd_repeat2(x.data_ptr(), y.data_ptr(), n, hi, wi, c, scale, beta,
+                                    self.stream), 'dd_repeat2')
 
   # ---- LayerNorm / GRU -------------------------------------------------------
 

@@ -248,9 +248,12 @@ class Learner:
     P['obs_out_h'] = Lin(m, 'rssm/obs_out', True, rows=(0, D))
     e0 = D
     self.cnn_feat = 0
-    if s.enc_convs:
-      last = s.enc_convs[-1]
-      self.cnn_feat = last.h_small * last.h_small * last.c_small
+    if s.enc_convs or s.enc_res:
+      if s.enc_res:   # the residual encoder ends in Linear(1024) (reference nets.py:348)
+        self.cnn_feat = s.enc_res.units
+      else:
+        last = s.enc_convs[-1]
+        self.cnn_feat = last.h_small * last.h_small * last.c_small
       P['obs_out_cnn'] = Lin(m, 'rssm/obs_out', True, rows=(e0, e0 + self.cnn_feat))
       e0 += self.cnn_feat
     if s.enc_mlp_keys:
@@ -326,6 +329,7 @@ class Learner:
           out=z(N, cl.h_small, cl.h_small, cl.c_small),
           stats=z(rows, 2), dz=z(N, cl.h_small, cl.h_small, cl.c_small),
           dout=z(N, cl.h_small, cl.h_small, cl.c_small)))
+    self.enc_res = self._res_buffers(s.enc_res, True) if s.enc_res else None
     self.enc_mlp_act = [Act(self, N, self.P[f'enc/mlp/dense{i}'].units, True)
                         for i in range(self.cfg['encoder']['mlp_layers']
                                        if s.enc_mlp_keys else 0)]
@@ -399,6 +403,7 @@ class Learner:
       if cl.norm:
         d.update(out=z(*shp), stats=z(N * cl.h_big * cl.h_big, 2), dout=z(*shp))
       self.dec_act.append(d)
+    self.dec_res = self._res_buffers(s.dec_res, False) if s.dec_res else None
     if s.dec_convs:
       b['loss_image'] = {k: z(N) for k in s.dec_cnn_keys}
       c0 = s.dec_convs[0]
@@ -465,6 +470,41 @@ class Learner:
     self.zero_rows = z(max(N, B))
 
   # ----------------------------------------------------------- small helpers
+
+  def _res_buffers(self, net, encoder):
+    """Activations of a residual encoder / decoder (spec.ResNet).  Per block: `a1` = act(LN(x))
+    and its statistics, `za` = first convolution, `a2` = act(LN(za)), `o` = block output, `dx` =
+    gradient at the block input (the next-lower block's output gradient).  Per stage: `do` =
+    gradient at the last block's output; encoder `x` = pooled stage input, decoder `up` = the
+    stage output repeated 2x.  t1 / t2 / t3: gradient scratch shared by all blocks."""
+    z, N = self.zeros, self.N
+    R = dict(stages=[], do=[], x=[], up=[])
+    maxd = maxc = 0
+    for blocks in net.stages:
+      acts = []
+      for blk in blocks:
+        sc, sd = (N, blk.h, blk.h, blk.cin), (N, blk.h, blk.h, blk.depth)
+        rows = N * blk.h * blk.h
+        acts.append(dict(a1=z(*sc), st_a=z(rows, 2), za=z(*sd), a2=z(*sd), st_b=z(rows, 2),
+                         o=z(*sd), dx=z(*sc)))
+        maxd, maxc = max(maxd, rows * blk.depth), max(maxc, rows * blk.cin)
+      R['stages'].append(acts)
+      first, last = blocks[0], blocks[-1]
+      R['do'].append(z(N, last.h, last.h, last.depth))
+      if encoder:
+        R['x'].append(z(N, first.h, first.h, first.cin))
+      else:
+        R['up'].append(z(N, 2 * last.h, 2 * last.h, last.depth))
+    R['t1'], R['t2'], R['t3'] = z(maxd), z(maxd), z(maxc)
+    R['bias01'] = z(max(blk.depth for blocks in net.stages for blk in blocks))
+    if encoder:
+      R['zin'] = z(N, net.hw, net.hw, net.depth)
+      R['dzin'] = z(N, net.hw, net.hw, net.depth)
+      R['emb'], R['demb'] = z(N, net.units), z(N, net.units)
+    else:
+      R['xin'] = z(N, net.feat_h, net.feat_h, net.feat_c)
+      R['dup'] = z(N, net.hw, net.hw, net.depth)
+    return R
 
   def stat(self, name, x, count=None):
     """Register / compute batch statistics of a vector into a metric slot."""
@@ -577,10 +617,135 @@ class Learner:
 
   # ----------------------------------------------------------------- encoder
 
+  # residual blocks (reference nets.py:351-358 / 384-391):
+  #   o = skip(x) + 0.1 * conv_b(act(LN(conv_a(act(LN(x))))))      (both convolutions 3x3 SAME
+  #   with bias, pre-activation nets.py:510-513; skip = 1x1 convolution without bias when the
+  #   channel count changes, else the identity)
+
+  def res_block_fwd(self, blk, a, x, R):
+    ops, m = self.ops, self.groups['model']
+    nm, C, Dp = blk.name, blk.cin, blk.depth
+    ops.ln_act_fwd(x.view(-1, C), m.p[f'{nm}a/norm/scale'], m.p[f'{nm}a/norm/bias'],
+                   a['a1'].view(-1, C), a['st_a'], True)
+    ops.conv_same(a['a1'], m.p[f'{nm}a/kernel'], m.p[f'{nm}a/bias'], a['za'], 3)
+    ops.ln_act_fwd(a['za'].view(-1, Dp), m.p[f'{nm}b/norm/scale'], m.p[f'{nm}b/norm/bias'],
+                   a['a2'].view(-1, Dp), a['st_b'], True)
+    # the skip path goes into `o` first; the second convolution accumulates 0.1 * (conv + bias)
+    # onto it in its epilogue (bias pre-scaled: the epilogue adds it unscaled)
+    if blk.skip:
+      ops.gemm(x.view(-1, C), m.p[f'{nm}s/kernel'].view(C, Dp), a['o'].view(-1, Dp))
+    else:
+      ops.copy2d(x.view(-1, C), a['o'].view(-1, Dp))
+    b01 = R['bias01'][:Dp]
+    ops.scalar_mul(b01, m.p[f'{nm}b/bias'], None, 0.1)
+    ops.conv_same(a['a2'], m.p[f'{nm}b/kernel'], b01, a['o'], 3, alpha=0.1, beta=1.0)
+
+  def res_block_bwd(self, blk, a, x, do, R):
+    """do: gradient at the block output; writes a['dx'] (gradient at x) and the block's
+    parameter gradients."""
+    ops, m = self.ops, self.groups['model']
+    nm, C, Dp = blk.name, blk.cin, blk.depth
+    nd, nc = do.numel(), x.numel()
+    t1, t2 = R['t1'][:nd].view(do.shape), R['t2'][:nd].view(do.shape)
+    t3 = R['t3'][:nc].view(x.shape)
+    gb = m.g[f'{nm}b/bias']
+    ops.col_sum(do.view(-1, Dp), gb)
+    ops.scalar_mul(gb, gb, None, 0.1)
+    ops.conv_same_wgrad(a['a2'], do, m.g[f'{nm}b/kernel'], 3, alpha=0.1)
+    ops.conv_same_bwd(do, m.p[f'{nm}b/kernel'], t2, 3, alpha=0.1)
+    ops.ln_act_bwd(t2.view(-1, Dp), a['za'].view(-1, Dp), a['a2'].view(-1, Dp), a['st_b'],
+                   m.p[f'{nm}b/norm/scale'], t1.view(-1, Dp), m.g[f'{nm}b/norm/scale'],
+                   m.g[f'{nm}b/norm/bias'], False, True, m.g[f'{nm}a/bias'])
+    ops.conv_same_wgrad(a['a1'], t1, m.g[f'{nm}a/kernel'], 3)
+    ops.conv_same_bwd(t1, m.p[f'{nm}a/kernel'], t3, 3)
+    ops.ln_act_bwd(t3.view(-1, C), x.view(-1, C), a['a1'].view(-1, C), a['st_a'],
+                   m.p[f'{nm}a/norm/scale'], a['dx'].view(-1, C), m.g[f'{nm}a/norm/scale'],
+                   m.g[f'{nm}a/norm/bias'], False, True, None)
+    if blk.skip:
+      ops.gemm(x.view(-1, C), do.view(-1, Dp), m.g[f'{nm}s/kernel'].view(C, Dp), ta=True)
+      ops.gemm(do.view(-1, Dp), m.p[f'{nm}s/kernel'].view(C, Dp), a['dx'].view(-1, C),
+               tb=True, beta=1.0)
+    else:
+      ops.axpy(do, 1.0, None, a['dx'])
+
+  def encoder_res_fwd(self):
+    """ImageEncoderResnet (reference nets.py:337-349); the image's `/255` (agent.py:129-130) is
+    fused into the 'in' convolution's loader."""
+    s, ops, b, N = self.spec, self.ops, self.b, self.N
+    m, net, R = self.groups['model'], self.spec.enc_res, self.enc_res
+    ops.conv_same(b['image'], m.p['enc/cnn/in/kernel'], m.p['enc/cnn/in/bias'], R['zin'], 3,
+                  1.0 / 255.0)
+    prev = R['zin']
+    for blocks, acts, xin in zip(net.stages, R['stages'], R['x']):
+      ops.pool2(prev, xin, 0.25)
+      x = xin
+      for blk, a in zip(blocks, acts):
+        self.res_block_fwd(blk, a, x, R)
+        x = a['o']
+      prev = x
+    ops.gemm(prev.view(N, -1), m.p['enc/cnn/out/kernel'], R['emb'], bias=m.p['enc/cnn/out/bias'])
+
+  def encoder_res_bwd(self):
+    """Consumes enc_res['demb'] (gradient of the 1024-wide embedding)."""
+    s, ops, b, N = self.spec, self.ops, self.b, self.N
+    m, net, R = self.groups['model'], self.spec.enc_res, self.enc_res
+    top = R['stages'][-1][-1]['o'].view(N, -1)
+    ops.gemm(top, R['demb'], m.g['enc/cnn/out/kernel'], ta=True)
+    ops.col_sum(R['demb'], m.g['enc/cnn/out/bias'])
+    ops.gemm(R['demb'], m.p['enc/cnn/out/kernel'], R['do'][-1].view(N, -1), tb=True)
+    for i in reversed(range(len(net.stages))):
+      blocks, acts, do = net.stages[i], R['stages'][i], R['do'][i]
+      for j in reversed(range(len(blocks))):
+        x = acts[j - 1]['o'] if j > 0 else R['x'][i]
+        self.res_block_bwd(blocks[j], acts[j], x, do, R)
+        do = acts[j]['dx']
+      # gradient of the 2x2 average pooling in front of the stage
+      ops.repeat2(do, R['do'][i - 1] if i > 0 else R['dzin'], 0.25)
+    C = net.depth
+    ops.col_sum(R['dzin'].view(-1, C), m.g['enc/cnn/in/bias'])
+    ops.conv_same_wgrad(b['image'], R['dzin'], m.g['enc/cnn/in/kernel'], 3, 1.0 / 255.0)
+
+  def decoder_res_fwd(self, feat):
+    """ImageDecoderResnet (reference nets.py:370-382) up to the pre-sigmoid image."""
+    s, ops, N = self.spec, self.ops, self.N
+    m, net, R = self.groups['model'], self.spec.dec_res, self.dec_res
+    ops.gemm(feat, m.p['dec/cnn/in/kernel'], R['xin'].view(N, -1), bias=m.p['dec/cnn/in/bias'])
+    x = R['xin']
+    for blocks, acts, up in zip(net.stages, R['stages'], R['up']):
+      for blk, a in zip(blocks, acts):
+        self.res_block_fwd(blk, a, x, R)
+        x = a['o']
+      ops.repeat2(x, up, 1.0)
+      x = up
+    ops.conv_same(x, m.p['dec/cnn/out/kernel'], m.p['dec/cnn/out/bias'], self.dec_act[-1]['z'], 3)
+
+  def decoder_res_bwd(self, feat, dfeat, beta):
+    s, ops, N = self.spec, self.ops, self.N
+    m, net, R = self.groups['model'], self.spec.dec_res, self.dec_res
+    last, cl = self.dec_act[-1], s.dec_convs[-1]
+    self._image_bias_grad(ops, last, cl.c_big, cl)
+    ops.conv_same_wgrad(R['up'][-1], last['dz'], m.g['dec/cnn/out/kernel'], 3)
+    ops.conv_same_bwd(last['dz'], m.p['dec/cnn/out/kernel'], R['dup'], 3)
+    dup = R['dup']
+    for i in reversed(range(len(net.stages))):
+      blocks, acts, do = net.stages[i], R['stages'][i], R['do'][i]
+      ops.pool2(dup, do, 1.0)   # gradient of the 2x repetition
+      for j in reversed(range(len(blocks))):
+        x = acts[j - 1]['o'] if j > 0 else (R['up'][i - 1] if i > 0 else R['xin'])
+        self.res_block_bwd(blocks[j], acts[j], x, do, R)
+        do = acts[j]['dx']
+      dup = do
+    dxin = dup.view(N, -1)
+    ops.gemm(feat, dxin, m.g['dec/cnn/in/kernel'], ta=True)
+    ops.col_sum(dxin, m.g['dec/cnn/in/bias'])
+    ops.gemm(dxin, m.p['dec/cnn/in/kernel'], dfeat, tb=True, beta=beta)
+
   def encoder_fwd(self):
     s, ops, b = self.spec, self.ops, self.b
     m = self.groups['model']
     x = b.get('image')
+    if s.enc_res:
+      self.encoder_res_fwd()
     for i, (cl, a) in enumerate(zip(s.enc_convs, self.enc_act)):
       ops.conv_down(x, m.p[f'{cl.name}/kernel'], m.p[f'{cl.name}/bias'], a['z'],
                     cl.k, 1.0 / 255.0 if i == 0 else 1.0)
@@ -595,8 +760,9 @@ class Learner:
     # hoisted embed part of obs_out: written straight into its pre-LN buffer
     zo = self.a_obs_out.z
     first = True
-    if s.enc_convs:
-      ops.gemm(self.enc_act[-1]['out'].view(self.N, -1), self.P['obs_out_cnn'].W, zo)
+    if s.enc_convs or s.enc_res:
+      top = self.enc_res['emb'] if s.enc_res else self.enc_act[-1]['out'].view(self.N, -1)
+      ops.gemm(top, self.P['obs_out_cnn'].W, zo)
       first = False
     if s.enc_mlp_keys:
       ops.gemm(self.enc_mlp_act[-1].out, self.P['obs_out_mlp'].W, zo,
@@ -615,6 +781,11 @@ class Learner:
       ops.gemm(dzo, P.W, top.dout, tb=True)
       layers = [self.P[f'enc/mlp/dense{i}'] for i in range(len(self.enc_mlp_act))]
       self.mlp_bwd(layers, self.enc_mlp_act, b['vec_in'])
+    if s.enc_res:
+      P, R = self.P['obs_out_cnn'], self.enc_res
+      ops.gemm(R['emb'], dzo, P.dW, ta=True)
+      ops.gemm(dzo, P.W, R['demb'], tb=True)
+      self.encoder_res_bwd()
     if s.enc_convs:
       P = self.P['obs_out_cnn']
       top = self.enc_act[-1]
@@ -641,7 +812,9 @@ class Learner:
     s, ops, b = self.spec, self.ops, self.b
     m = self.groups['model']
     N = self.N
-    if s.dec_convs:
+    if s.dec_res:
+      self.decoder_res_fwd(feat)
+    elif s.dec_convs:
       c0, a0 = s.dec_convs[0], self.dec_act[0]
       kk = c0.k * c0.k
       bt = b['bias_tiled'].view(kk, c0.c_big)
@@ -659,6 +832,7 @@ class Learner:
                          m.p[f'{cl.name}/norm/bias'], a['out'].view(-1, C),
                          a['stats'], True)
           x = a['out']
+    if s.dec_convs:
       last = self.dec_act[-1]
       c0 = 0
       for key, shp in s.dec_cnn_keys.items():
@@ -683,7 +857,9 @@ class Learner:
       self.head_bwd('dec_mlp', self.acts_wm['dec_mlp'], feat, None, dfeat, beta,
                     defer=defer)
       beta = 1.0
-    if s.dec_convs:
+    if s.dec_res:
+      self.decoder_res_bwd(feat, dfeat, beta)
+    elif s.dec_convs:
       for i in reversed(range(len(s.dec_convs))):
         cl, a = s.dec_convs[i], self.dec_act[i]
         C = cl.c_big

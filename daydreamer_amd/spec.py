@@ -7,7 +7,14 @@ Shapes and initialisers follow the reference's lazily-built modules
 transposed Conv2D includes it (nets.py:523-525); biases zero, LayerNorm
 scale one / bias zero (nets.py:595-596); `initial_deter` zero (nets.py:58-60).
 Linear has a bias only without LayerNorm (nets.py:563); Conv2D always has one
-(nets.py:548-553).
+(nets.py:548-553) unless built with bias=False (the 1x1 skip convolutions of the residual
+blocks, nets.py:354, 387).
+
+`cnn: resnet` (ImageEncoderResnet / ImageDecoderResnet, nets.py:330-391): stride-1 SAME 3x3
+convolutions with pre-activation (LayerNorm over the INPUT channels, then the activation, then
+the convolution: nets.py:510-513), residual blocks `skip + 0.1 * x`, 2x2 average pooling between
+encoder stages, 2x repetition between decoder stages, a Linear(1024) on the 4x4 encoder output
+and a Linear(16 * depth) in front of the decoder.
 """
 
 import re
@@ -42,6 +49,31 @@ class ConvLayer:
 
 
 @dataclass
+class ResBlock:
+  """One residual block (reference nets.py:351-358 / 384-391) on h x h pixels."""
+  name: str      # parameter prefix: <name>a, <name>b (3x3, pre-activation), <name>s (1x1 skip)
+  h: int
+  cin: int
+  depth: int
+
+  @property
+  def skip(self):
+    return self.cin != self.depth
+
+
+@dataclass
+class ResNet:
+  prefix: str            # 'enc/cnn' | 'dec/cnn'
+  hw: int                # image side
+  cimg: int              # image channels
+  depth: int             # channels after 'in' (encoder) / in front of 'out' (decoder)
+  stages: list = field(default_factory=list)   # per stage: list of ResBlock
+  feat_h: int = 4        # side of the flattened end (4 x 4)
+  feat_c: int = 0        # channels at the 4 x 4 end
+  units: int = 0         # encoder: width of the 'out' Linear; decoder: width of the 'in' Linear
+
+
+@dataclass
 class ModelSpec:
   cfg: dict
   obs_shapes: dict
@@ -61,6 +93,8 @@ class ModelSpec:
   dec_mlp_keys: dict = field(default_factory=dict)
   enc_convs: list = field(default_factory=list)
   dec_convs: list = field(default_factory=list)
+  enc_res: ResNet = None   # cnn: resnet
+  dec_res: ResNet = None
   image_hw: int = 0
   image_c: int = 0
   params: list = field(default_factory=list)
@@ -110,11 +144,35 @@ def build_spec(cfg, obs_shapes, act_dim, act_discrete=False):
       fan_in = units
     return fan_in
 
+  def conv_same(name, k, cin, cout, bias=True, preact=False):
+    # Conv2D, not transposed: the limit ignores the kernel area (nets.py:541-543); with
+    # preact the LayerNorm acts on the INPUT (cin channels), nets.py:510-513
+    add(f'{name}/kernel', (k, k, cin, cout), 'model', 'uniform',
+        float(np.sqrt(3.0 / np.mean([cin, cout]))))
+    if bias:
+      add(f'{name}/bias', (cout,), 'model', 'zeros')
+    if preact:
+      add(f'{name}/norm/scale', (cin,), 'model', 'ones')
+      add(f'{name}/norm/bias', (cin,), 'model', 'zeros')
+
+  def res_block(name, h, cin, depth):
+    blk = ResBlock(name, h, cin, depth)
+    if blk.skip:
+      conv_same(f'{name}s', 1, cin, depth, bias=False)
+    conv_same(f'{name}a', 3, cin, depth, preact=True)
+    conv_same(f'{name}b', 3, depth, depth, preact=True)
+    return blk
+
+  def res_stage_count(hw):
+    n = int(np.log2(hw)) - 2   # nets.py:339, 372
+    assert n >= 1 and 2 ** (n + 2) == hw, ('resnet needs a power-of-two image side >= 8', hw)
+    return n
+
   shapes = {k: tuple(v) for k, v in obs_shapes.items()
             if not k.startswith('log_')}
   # ---- encoder (reference nets.py:186-232, 291-305)
   enc = cfg['encoder']
-  assert enc['cnn'] == 'simple' and enc['norm'] == 'layer'
+  assert enc['cnn'] in ('simple', 'resnet') and enc['norm'] == 'layer' and enc['act'] == 'elu'
   es = {k: v for k, v in shapes.items() if k not in ('is_first', 'is_last')}
   s.enc_cnn_keys = [k for k, v in es.items()
                     if re.match(enc['cnn_keys'], k) and len(v) == 3]
@@ -127,7 +185,23 @@ def build_spec(cfg, obs_shapes, act_dim, act_discrete=False):
     s.image_hw = es[s.enc_cnn_keys[0]][0]
     s.image_c = sum(es[k][2] for k in s.enc_cnn_keys)
     h, cin, depth = s.image_hw, s.image_c, enc['cnn_depth']
-    for i, k in enumerate(enc['cnn_kernels']):
+    if enc['cnn'] == 'resnet':   # nets.py:330-358
+      net = ResNet('enc/cnn', h, cin, depth)
+      conv_same('enc/cnn/in', 3, cin, depth)
+      c = depth
+      for i in range(res_stage_count(h)):
+        h //= 2   # avg_pool in front of the stage's blocks
+        blocks = []
+        for j in range(enc['cnn_blocks']):
+          blocks.append(res_block(f'enc/cnn/s{i}b{j}', h, c, depth))
+          c = depth
+        net.stages.append(blocks)
+        depth *= 2
+      net.feat_h, net.feat_c, net.units = h, c, 1024
+      dense_bias('enc/cnn/out', h * h * c, 1024, 'model')
+      s.enc_res = net
+      s.embed += 1024
+    for i, k in enumerate(enc['cnn_kernels'] if enc['cnn'] == 'simple' else ()):
       ho = (h - k) // 2 + 1
       name = f'enc/cnn/conv{i}'
       add(f'{name}/kernel', (k, k, cin, depth), 'model', 'uniform',
@@ -137,7 +211,8 @@ def build_spec(cfg, obs_shapes, act_dim, act_discrete=False):
       add(f'{name}/norm/bias', (depth,), 'model', 'zeros')
       s.enc_convs.append(ConvLayer(name, k, depth, cin, ho, h, True))
       h, cin, depth = ho, depth, depth * 2
-    s.embed += h * h * cin
+    if enc['cnn'] == 'simple':
+      s.embed += h * h * cin
   if s.enc_mlp_keys:
     s.enc_mlp_in = sum(int(np.prod(es[k])) if es[k] else 1
                        for k in s.enc_mlp_keys)
@@ -157,7 +232,8 @@ def build_spec(cfg, obs_shapes, act_dim, act_discrete=False):
   dense_bias('rssm/obs_stats', s.units, s.stoch, 'model')
   # ---- decoder (reference nets.py:235-327)
   dec = cfg['decoder']
-  assert dec['cnn'] == 'simple' and dec['image_dist'] == 'mse'
+  assert dec['cnn'] in ('simple', 'resnet') and dec['image_dist'] == 'mse'
+  assert dec['norm'] == 'layer' and dec['act'] == 'elu'
   assert list(dec['inputs']) == ['deter', 'stoch']
   ds = {k: v for k, v in shapes.items()
         if k not in ('is_first', 'is_last', 'is_terminal', 'reward')}
@@ -165,7 +241,30 @@ def build_spec(cfg, obs_shapes, act_dim, act_discrete=False):
                     if re.match(dec['cnn_keys'], k) and len(v) == 3}
   s.dec_mlp_keys = {k: v for k, v in ds.items()
                     if re.match(dec['mlp_keys'], k) and len(v) == 1}
-  if s.dec_cnn_keys:
+  if s.dec_cnn_keys and dec['cnn'] == 'resnet':   # nets.py:361-391
+    cimg = sum(v[2] for v in s.dec_cnn_keys.values())
+    hw = list(s.dec_cnn_keys.values())[0][0]
+    assert all(v[0] == hw and v[1] == hw for v in s.dec_cnn_keys.values())
+    n = res_stage_count(hw)
+    depth = 2 ** n * dec['cnn_depth']
+    net = ResNet('dec/cnn', hw, cimg, 0, feat_h=4, feat_c=depth, units=16 * depth)
+    dense_bias('dec/cnn/in', s.feat, 16 * depth, 'model')
+    h, c = 4, depth
+    for i in range(n):
+      blocks = []
+      for j in range(dec['cnn_blocks']):
+        blocks.append(res_block(f'dec/cnn/s{i}b{j}', h, c, depth))
+        c = depth
+      net.stages.append(blocks)
+      h *= 2    # repeated 2x after the stage's blocks
+      depth //= 2
+    net.depth = c
+    conv_same('dec/cnn/out', 3, c, cimg)
+    s.dec_res = net
+    # the image layer in the terms of the stride-2 decoder's bookkeeping (its z / dz buffers,
+    # the image loss and the bias-gradient fold are shared)
+    s.dec_convs.append(ConvLayer('dec/cnn/out', 3, c, cimg, hw, hw, False))
+  elif s.dec_cnn_keys:
     kernels = list(dec['cnn_kernels'])
     cimg = sum(v[2] for v in s.dec_cnn_keys.values())
     depth = dec['cnn_depth'] * 2 ** (len(kernels) - 2)

@@ -82,6 +82,34 @@ int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float
                        int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
                        float in_scale, float beta, float* ws, size_t ws_bytes, void* stream);
 
+/* Stride-1 SAME convolutions (odd k; NHWC, filter [k,k,Cin,Cout]) of the residual encoder /
+ * decoder: ImageEncoderResnet nets.py:330-358, ImageDecoderResnet nets.py:361-391, through
+ * Conv2D's defaults stride 1 / pad 'same' (nets.py:497-499, tf.nn.conv2d nets.py:547).
+ *   dd_conv2d_same          y  = alpha*conv(x, w) + bias[Cout] + beta*y   (x may be uint8, scaled
+ *                                by in_scale: the image layer 'in' with the `/255` fused)
+ *   dd_conv2d_same_bwd_data dx = alpha*conv(dy, rot180(w)^T) + beta*dx    (input gradient; the
+ *                                rotated filter is written to the head of ws: ws_bytes must
+ *                                cover k*k*Cin*Cout floats rounded up to 256 bytes)
+ *   dd_conv2d_same_wgrad    dw = alpha*sum_pixels x (x) dy + beta*dw      (filter gradient)
+ * A tap outside the image contributes an exact zero. */
+int dd_conv2d_same(const void* x, int x_is_u8, const float* w, const float* bias, float* y,
+                   int n_img, int h, int wd, int Cin, int Cout, int k, float in_scale,
+                   float alpha, float beta, float* ws, size_t ws_bytes, void* stream);
+int dd_conv2d_same_bwd_data(const float* dy, const float* w, float* dx, int n_img, int h,
+                            int wd, int Cin, int Cout, int k, float alpha, float beta,
+                            float* ws, size_t ws_bytes, void* stream);
+int dd_conv2d_same_wgrad(const void* x, int x_is_u8, const float* dy, float* dw, int n_img,
+                         int h, int wd, int Cin, int Cout, int k, float in_scale,
+                         float alpha, float beta, float* ws, size_t ws_bytes, void* stream);
+/* y[n,i,j,c] = scale * (sum of the 2x2 block of x) with y of ho x wo pixels, x of 2ho x 2wo:
+ * tf.nn.avg_pool(x, 2, 2, 'SAME') nets.py:343 (scale 0.25) and the gradient of dd_repeat2 (1). */
+int dd_pool2(const float* x, float* y, long n_img, int ho, int wo, int C, float scale,
+             void* stream);
+/* y[n,2i+a,2j+b,c] = scale * x[n,i,j,c] + beta*y with x of hi x wi pixels:
+ * tf.repeat(tf.repeat(x, 2, 1), 2, 2) nets.py:378 (scale 1) and the gradient of avg_pool (0.25). */
+int dd_repeat2(const float* x, float* y, long n_img, int hi, int wi, int C, float scale,
+               float beta, void* stream);
+
 /* ---- LayerNorm(+ELU), GRU cell -------------------------------------------- */
 
 /* out = act(LN(z)*gamma+beta), eps 1e-3, population variance; act 0 none,

@@ -329,6 +329,60 @@ def conv2d(p, name, x, transp, act='none', norm='none'):
   return get_act(act)(y)
 
 
+def conv2d_same(p, name, x, act='none', norm='none', preact=False, bias=True):
+  """nets.py:495-554 with Conv2D's defaults stride 1, pad 'same' (odd kernel: (k-1)/2 zeros on
+  every side).  preact (:510-513): norm and activation act on the INPUT, then the layer."""
+  if preact:
+    if norm != 'none':
+      x = layer_norm(x, p[f'{name}/norm/scale'], p[f'{name}/norm/bias'])
+    x = get_act(act)(x)
+  k = p[f'{name}/kernel']
+  y = F.conv2d(x.permute(0, 3, 1, 2), k.permute(3, 2, 0, 1), padding=k.shape[0] // 2)
+  y = y.permute(0, 2, 3, 1)
+  if bias:
+    y = y + p[f'{name}/bias']
+  if not preact:
+    if norm != 'none':
+      y = layer_norm(y, p[f'{name}/norm/scale'], p[f'{name}/norm/bias'])
+    y = get_act(act)(y)
+  return y
+
+
+def res_block(p, name, depth, x, **kw):  # nets.py:351-358, 384-391
+  skip = x
+  if skip.shape[-1] != depth:
+    skip = conv2d_same(p, f'{name}s', skip, bias=False)
+  x = conv2d_same(p, f'{name}a', x, preact=True, **kw)
+  x = conv2d_same(p, f'{name}b', x, preact=True, **kw)
+  return skip + 0.1 * x
+
+
+def encoder_resnet(p, name, image, depth, blocks, **kw):  # nets.py:337-349
+  stages = int(np.log2(image.shape[-2])) - 2
+  x = conv2d_same(p, f'{name}/in', image)
+  for i in range(stages):
+    # tf.nn.avg_pool(x, [2, 2], [2, 2], 'SAME') on even sides: plain 2x2 means
+    x = F.avg_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    for j in range(blocks):
+      x = res_block(p, f'{name}/s{i}b{j}', depth, x, **kw)
+    depth *= 2
+  x = x.reshape(x.shape[0], -1)
+  return linear(p, f'{name}/out', x)
+
+
+def decoder_resnet(p, name, feat, shape, depth, blocks, **kw):  # nets.py:370-382
+  stages = int(np.log2(shape[0])) - 2
+  depth = 2 ** stages * depth
+  x = linear(p, f'{name}/in', feat)
+  x = x.reshape(-1, 4, 4, depth)
+  for i in range(stages):
+    for j in range(blocks):
+      x = res_block(p, f'{name}/s{i}b{j}', depth, x, **kw)
+    x = x.repeat_interleave(2, 1).repeat_interleave(2, 2)  # tf.repeat(tf.repeat(x, 2, 1), 2, 2)
+    depth //= 2
+  return torch.sigmoid(conv2d_same(p, f'{name}/out', x))
+
+
 def mlp_trunk(p, name, x, layers, act, norm):  # nets.py:408-414
   for i in range(layers):
     x = linear(p, f'{name}/dense{i}', x, act, norm)
@@ -509,8 +563,11 @@ class RefAgent:
     if self.enc_cnn:
       x = torch.cat([data[k].reshape((-1,) + data[k].shape[len(lead):])
                      for k in self.enc_cnn], -1)
-      for i, _ in enumerate(enc['cnn_kernels']):
-        x = conv2d(self.p, f'enc/cnn/conv{i}', x, False, **kw)
+      if enc['cnn'] == 'resnet':  # nets.py:206-207
+        x = encoder_resnet(self.p, 'enc/cnn', x, enc['cnn_depth'], enc['cnn_blocks'], **kw)
+      else:
+        for i, _ in enumerate(enc['cnn_kernels']):
+          x = conv2d(self.p, f'enc/cnn/conv{i}', x, False, **kw)
       outs.append(x.reshape(x.shape[0], -1))
     if self.enc_mlp:
       xs = []
@@ -530,11 +587,16 @@ class RefAgent:
     lead = feat.shape[:-1]
     flat = feat.reshape(-1, feat.shape[-1])
     means = {}
-    if self.dec_cnn:
+    if self.dec_cnn and dec['cnn'] == 'resnet':  # nets.py:255-256
+      shapes = list(self.dec_cnn.values())
+      merged = tuple(shapes[0][:-1]) + (sum(v[-1] for v in shapes),)
+      x = decoder_resnet(self.p, 'dec/cnn', flat, merged, dec['cnn_depth'], dec['cnn_blocks'], **kw)
+    elif self.dec_cnn:
       x = flat.reshape(-1, 1, 1, flat.shape[-1])
       for i, _ in enumerate(dec['cnn_kernels'][:-1]):
         x = conv2d(self.p, f'dec/cnn/conv{i}', x, True, **kw)
       x = torch.sigmoid(conv2d(self.p, 'dec/cnn/out', x, True))
+    if self.dec_cnn:
       x = x.reshape(lead + x.shape[1:])
       chans = [v[-1] for v in self.dec_cnn.values()]
       for k, m in zip(self.dec_cnn, torch.split(x, chans, -1)):

@@ -186,6 +186,48 @@ class RefOps:
         g[ky, kx] = torch.einsum('nhwb,nhws->bs', patch, small)
     dw.copy_(g + beta * dw if beta != 0.0 else g)
 
+  # stride-1 SAME convolutions (odd k) + 2x2 pooling / repetition: include/daydreamer_hip.h
+  # dd_conv2d_same*, dd_pool2, dd_repeat2 (reference nets.py:330-391)
+
+  def conv_same(self, x, w, bias, y, k, in_scale=1.0, alpha=1.0, beta=0.0):
+    xx = self._big(x, in_scale, w.dtype).permute(0, 3, 1, 2)
+    r = alpha * F.conv2d(xx, w.permute(3, 2, 0, 1), padding=k // 2).permute(0, 2, 3, 1)
+    if bias is not None:
+      r = r + bias
+    y.copy_(r + beta * y if beta != 0.0 else r)
+
+  def conv_same_bwd(self, dy, w, dx, k, alpha=1.0, beta=0.0):
+    # dx[n,y,x,ci] = sum_{ky,kx,co} dy[n, y-ky+p, x-kx+p, co] * w[ky,kx,ci,co]
+    n, h, wd, cout = dy.shape
+    p = k // 2
+    dyp = F.pad(dy, (0, 0, p, p, p, p))
+    r = torch.zeros_like(dx)
+    for ky in range(k):
+      for kx in range(k):
+        sl = dyp[:, 2 * p - ky:2 * p - ky + h, 2 * p - kx:2 * p - kx + wd, :]
+        r += torch.einsum('nhwo,io->nhwi', sl, w[ky, kx])
+    r = alpha * r
+    dx.copy_(r + beta * dx if beta != 0.0 else r)
+
+  def conv_same_wgrad(self, x, dy, dw, k, in_scale=1.0, alpha=1.0, beta=0.0):
+    xx = self._big(x, in_scale, dy.dtype)
+    n, h, wd, cin = xx.shape
+    p = k // 2
+    xp = F.pad(xx, (0, 0, p, p, p, p))
+    g = torch.zeros_like(dw)
+    for ky in range(k):
+      for kx in range(k):
+        g[ky, kx] = torch.einsum('nhwi,nhwo->io', xp[:, ky:ky + h, kx:kx + wd, :], dy)
+    g = alpha * g
+    dw.copy_(g + beta * dw if beta != 0.0 else g)
+
+  def pool2(self, x, y, scale=0.25):
+    y.copy_(((x[:, 0::2, 0::2] + x[:, 0::2, 1::2]) + (x[:, 1::2, 0::2] + x[:, 1::2, 1::2])) * scale)
+
+  def repeat2(self, x, y, scale=1.0, beta=0.0):
+    r = (x * scale).repeat_interleave(2, 1).repeat_interleave(2, 2)
+    y.copy_(r + beta * y if beta != 0.0 else r)
+
   # ---- LayerNorm / GRU ----------------------------------------------------------
 
   def ln_act_fwd(self, z, gamma, beta, out, stats, act=True, pre=None):

@@ -181,6 +181,89 @@ def test_conv_wgrad(hip, ref, n, hb, Cb, hs, Cs, k, u8):
     close(g, c, what=f'conv_wgrad beta{beta}')
 
 
+# stride-1 SAME convolutions of the residual encoder / decoder: (n, h, Cin, Cout, k, u8)
+SAME = [
+    (3, 8, 16, 32, 3, False), (2, 16, 32, 32, 3, False), (5, 4, 64, 128, 3, False),
+    (2, 32, 3, 16, 3, True), (2, 32, 16, 3, 3, False), (3, 7, 5, 6, 3, False),
+    (2, 9, 8, 12, 1, False), (1, 64, 64, 64, 3, False), (40, 4, 256, 256, 3, False),
+    (2, 6, 4, 8, 5, False)]
+
+
+@pytest.mark.parametrize('n,h,Cin,Cout,k,u8', SAME)
+def test_conv_same(hip, ref, n, h, Cin, Cout, k, u8):
+  if u8:
+    x = torch.randint(0, 256, (n, h, h, Cin), dtype=torch.uint8,
+                      generator=torch.Generator().manual_seed(1))
+  else:
+    x = rnd(n, h, h, Cin, seed=1)
+  w, bias, y = rnd(k, k, Cin, Cout, seed=2, scale=0.1), rnd(Cout, seed=3), rnd(n, h, h, Cout, seed=4)
+  sc = 1.0 / 255.0 if u8 else 1.0
+  for alpha, beta, bs in ((1.0, 0.0, True), (0.1, 1.0, True), (1.0, 0.0, False)):
+    def fn(ops, x, w, bias, y):
+      ops.conv_same(x, w, bias if bs else None, y, k, sc, alpha, beta)
+    (g, c), = both(hip, ref, fn, [x, w, bias, y], [3])
+    close(g, c, what=f'conv_same alpha{alpha} beta{beta} bias{bs}')
+
+
+@pytest.mark.parametrize('n,h,Cin,Cout,k,u8', SAME)
+def test_conv_same_bwd(hip, ref, n, h, Cin, Cout, k, u8):
+  dy, w, dx = rnd(n, h, h, Cout, seed=1), rnd(k, k, Cin, Cout, seed=2, scale=0.1), rnd(n, h, h, Cin, seed=3)
+  for alpha, beta in ((1.0, 0.0), (0.1, 1.0)):
+    def fn(ops, dy, w, dx):
+      ops.conv_same_bwd(dy, w, dx, k, alpha, beta)
+    (g, c), = both(hip, ref, fn, [dy, w, dx], [2])
+    close(g, c, what=f'conv_same_bwd alpha{alpha} beta{beta}')
+
+
+@pytest.mark.parametrize('n,h,Cin,Cout,k,u8', SAME)
+def test_conv_same_wgrad(hip, ref, n, h, Cin, Cout, k, u8):
+  if u8:
+    x = torch.randint(0, 256, (n, h, h, Cin), dtype=torch.uint8,
+                      generator=torch.Generator().manual_seed(1))
+  else:
+    x = rnd(n, h, h, Cin, seed=1)
+  dy, dw = rnd(n, h, h, Cout, seed=2), rnd(k, k, Cin, Cout, seed=3)
+  sc = 1.0 / 255.0 if u8 else 1.0
+  for alpha, beta in ((1.0, 0.0), (0.1, 1.0)):
+    def fn(ops, x, dy, dw):
+      ops.conv_same_wgrad(x, dy, dw, k, sc, alpha, beta)
+    (g, c), = both(hip, ref, fn, [x, dy, dw], [2])
+    close(g, c, what=f'conv_same_wgrad alpha{alpha} beta{beta}')
+
+
+def test_conv_same_adjoint_large(hip):
+  """Size-independent property at a full-size residual layer (2500 images would be 32x32x64 ->
+  64; here 256 images): <conv(x), y> == <x, conv_bwd(y)> and <conv(x), y> == <w, wgrad(x, y)>."""
+  n, h, Cin, Cout, k = 256, 32, 64, 64, 3
+  x = rnd(n, h, h, Cin, seed=1).cuda()
+  y = rnd(n, h, h, Cout, seed=2).cuda()
+  w = rnd(k, k, Cin, Cout, seed=3, scale=0.1).cuda()
+  cx, cty, dw = torch.empty_like(y), torch.empty_like(x), torch.empty_like(w)
+  hip.conv_same(x, w, None, cx, k)
+  hip.conv_same_bwd(y, w, cty, k)
+  hip.conv_same_wgrad(x, y, dw, k)
+  torch.cuda.synchronize()
+  a = float((cx.double() * y.double()).sum())
+  b = float((x.double() * cty.double()).sum())
+  c = float((w.double() * dw.double()).sum())
+  assert abs(a - b) <= 1e-5 * abs(a) and abs(a - c) <= 1e-5 * abs(a), (a, b, c)
+
+
+@pytest.mark.parametrize('n,h,C', [(3, 4, 16), (2, 16, 64), (5, 2, 3), (1, 32, 128), (7, 8, 6)])
+def test_pool2_repeat2(hip, ref, n, h, C):
+  x, y = rnd(n, 2 * h, 2 * h, C, seed=1), rnd(n, h, h, C, seed=2)
+  for scale in (0.25, 1.0):
+    def fn(ops, x, y):
+      ops.pool2(x, y, scale)
+    (g, c), = both(hip, ref, fn, [x, y], [1])
+    close(g, c, rtol=1e-6, what=f'pool2 scale{scale}')
+  for scale, beta in ((1.0, 0.0), (0.25, 0.0), (0.25, 1.0)):
+    def fn(ops, y, x):
+      ops.repeat2(y, x, scale, beta)
+    (g, c), = both(hip, ref, fn, [y, x], [1])
+    close(g, c, rtol=1e-6, what=f'repeat2 scale{scale} beta{beta}')
+
+
 def test_conv_adjoint_large(hip):
   """Size-independent property at full C2 layer size: <down(x), y> == <x, up(y)>
   (the transposed conv is the exact adjoint of the conv)."""

@@ -67,6 +67,22 @@ def test_learner_matches_oracle_vision():
   run_pair(cfg, steps=2, image=64, vector=5, action=3, terminals=0.15)
 
 
+def test_learner_matches_oracle_resnet():
+  """`cnn: resnet` (reference nets.py:330-391): residual encoder and decoder, hand-derived
+  backward against the oracle's autograd: every gradient, every updated parameter."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=2, replay_chunk=3, imag_horizon=2)
+  cfg = cfg.update({'encoder.cnn': 'resnet', 'decoder.cnn': 'resnet', 'encoder.cnn_depth': 4,
+                    'decoder.cnn_depth': 4, 'encoder.cnn_blocks': 2, 'decoder.cnn_blocks': 2})
+  out = run_pair(cfg, steps=2, image=32, vector=5, action=3, terminals=0.15)
+  L = out[0][0]
+  names = {p.name for p in L.spec.params}
+  # stage 1 of either net changes the channel count in its first block only: one 1x1 skip each
+  assert 'enc/cnn/s1b0s/kernel' in names and 'enc/cnn/s1b1s/kernel' not in names
+  assert 'enc/cnn/s0b0s/kernel' not in names and 'dec/cnn/s0b0s/kernel' not in names
+  assert 'dec/cnn/s1b0s/kernel' in names and 'dec/cnn/in/bias' in names
+  assert L.spec.embed == 1024 + 512
+
+
 def test_learner_deferred_weight_grads():
   """Same check with the weight-gradient contractions queued for the side
   launch context (the GPU runs them on a second stream)."""

@@ -130,6 +130,28 @@ def test_e2e_multicam_128(hip):
   run(hip, cfg, 1, image=128, cameras=2, vector=5, action=3, terminals=0.1)
 
 
+def test_e2e_resnet(hip):
+  """`encoder.cnn: resnet` / `decoder.cnn: resnet` (reference nets.py:330-391): stride-1 SAME
+  3x3 convolutions with pre-activation, residual blocks, 2x2 pooling / 2x repetition, on a
+  64x64 image (four stages each way) against the oracle: losses, every gradient, every
+  updated parameter, two steps."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=3, replay_chunk=4, imag_horizon=3)
+  cfg = cfg.update({'encoder.cnn': 'resnet', 'decoder.cnn': 'resnet', 'encoder.cnn_depth': 8,
+                    'decoder.cnn_depth': 8})
+  L = run(hip, cfg, 2, image=64, vector=5, action=3, terminals=0.1)
+  assert len(L.spec.enc_res.stages) == 4 and L.spec.dec_res.feat_c == 128
+
+
+def test_e2e_resnet_multicam_128(hip):
+  """BASELINE configs[3] geometry through the residual nets - the reference's own way to a
+  128x128 image (five stages each way), two cameras on the channel axis."""
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=2, replay_chunk=3, imag_horizon=2)
+  cfg = cfg.update({'encoder.cnn': 'resnet', 'decoder.cnn': 'resnet', 'encoder.cnn_depth': 4,
+                    'decoder.cnn_depth': 4, 'encoder.cnn_blocks': 1, 'decoder.cnn_blocks': 1})
+  L = run(hip, cfg, 1, image=128, cameras=2, vector=5, action=3, terminals=0.1)
+  assert len(L.spec.enc_res.stages) == 5 and L.spec.image_c == 6
+
+
 def test_fused_observe_scan_equals_launch_sequence(hip):
   """csrc/scan.hip: RSSM.observe forward as ONE persistent launch (grid barriers between the
   four layers of a step) against the per-layer launch sequence on the same inputs, at the full
