@@ -15,6 +15,10 @@ documentation (dreamer_ref.py header).  Two of them are pinned here without PyTo
     the straight-through estimator of the categorical draw (tfutils.py:376-381), which by
     construction is NOT the derivative of the sampled value, so finite differences cannot
     check them; their building blocks are autograd of plain torch ops.
+  * the residual nets (`cnn: resnet`, nets.py:330-391): tf.nn.conv2d with stride 1 and 'SAME'
+    (odd kernel: floor(k/2) zeros on every side - TF pads total k-1, the smaller half first,
+    equal halves for odd k), tf.nn.avg_pool 2x2 / stride 2 on even sides, tf.repeat on both
+    image axes, and one whole pre-activation residual block, as direct numpy loops.
 """
 
 import pathlib
@@ -90,6 +94,71 @@ def test_conv2d_transpose_matches_direct_loops_and_is_the_adjoint():
     lhs = (conv2d_loops(x, f) * y).sum()
     rhs = (x * up).sum()
     assert abs(lhs - rhs) < 1e-9 * max(1.0, abs(lhs))
+
+
+def conv2d_same_loops(x, f):
+  """tf.nn.conv2d, stride 1, 'SAME' (NHWC): output[b, i, j, k] = sum_{di, dj, q}
+  input[b, i + di - pt, j + dj - pl, q] * filter[di, dj, q, k] with the input zero outside the
+  image; TF: pad_total = k - 1, pad_top = pad_left = pad_total // 2."""
+  n, h, w, cin = x.shape
+  kh, kw, _, cout = f.shape
+  pt, pl = (kh - 1) // 2, (kw - 1) // 2
+  y = np.zeros((n, h, w, cout))
+  for b in range(n):
+    for i in range(h):
+      for j in range(w):
+        for di in range(kh):
+          for dj in range(kw):
+            si, sj = i + di - pt, j + dj - pl
+            if 0 <= si < h and 0 <= sj < w:
+              y[b, i, j] += x[b, si, sj] @ f[di, dj]
+  return y
+
+
+def _ln_elu(x, scale, bias):   # Norm nets.py:594-600 (eps 1e-3, population variance) + tf.nn.elu
+  m = x.mean(-1, keepdims=True)
+  v = ((x - m) ** 2).mean(-1, keepdims=True)
+  y = (x - m) / np.sqrt(v + 1e-3) * scale + bias
+  return np.where(y > 0, y, np.exp(np.minimum(y, 0)) - 1)
+
+
+def test_same_conv_pool_repeat_and_residual_block_match_direct_loops():
+  rng = np.random.RandomState(5)
+  t = lambda a: torch.tensor(a)
+  for (h, k, cin, cout) in ((5, 3, 3, 4), (4, 1, 4, 2), (6, 3, 2, 2)):
+    x, f, b = rng.randn(2, h, h, cin), rng.randn(k, k, cin, cout), rng.randn(cout)
+    p = {'c/kernel': t(f), 'c/bias': t(b)}
+    got = dreamer_ref.conv2d_same(p, 'c', t(x)).numpy()
+    assert np.abs(got - (conv2d_same_loops(x, f) + b)).max() < 1e-12
+  # one residual block with a 1x1 skip (nets.py:351-358): channels 3 -> 4 on 4x4 pixels
+  cin, d, h = 3, 4, 4
+  P = {'b/a/kernel': rng.randn(3, 3, cin, d), 'b/a/bias': rng.randn(d),
+       'b/a/norm/scale': rng.rand(cin) + 0.5, 'b/a/norm/bias': rng.randn(cin),
+       'b/b/kernel': rng.randn(3, 3, d, d), 'b/b/bias': rng.randn(d),
+       'b/b/norm/scale': rng.rand(d) + 0.5, 'b/b/norm/bias': rng.randn(d),
+       'b/s/kernel': rng.randn(1, 1, cin, d)}
+  P = {k.replace('b/a', 'ba').replace('b/b', 'bb').replace('b/s', 'bs'): v for k, v in P.items()}
+  x = rng.randn(2, h, h, cin)
+  skip = conv2d_same_loops(x, P['bs/kernel'])
+  y = conv2d_same_loops(_ln_elu(x, P['ba/norm/scale'], P['ba/norm/bias']), P['ba/kernel']) + P['ba/bias']
+  y = conv2d_same_loops(_ln_elu(y, P['bb/norm/scale'], P['bb/norm/bias']), P['bb/kernel']) + P['bb/bias']
+  want = skip + 0.1 * y
+  got = dreamer_ref.res_block({k: t(v) for k, v in P.items()}, 'b', d, t(x), act='elu', norm='layer').numpy()
+  assert np.abs(got - want).max() < 1e-11
+  # encoder / decoder plumbing: avg_pool 2x2 (even sides: no padding) and tf.repeat by 2 on both axes
+  img = rng.randn(2, 8, 8, 3)
+  pooled = np.zeros((2, 4, 4, 3))
+  rep = np.zeros((2, 16, 16, 3))
+  for i in range(4):
+    for j in range(4):
+      pooled[:, i, j] = img[:, 2 * i:2 * i + 2, 2 * j:2 * j + 2].mean((1, 2))
+  for i in range(16):
+    for j in range(16):
+      rep[:, i, j] = img[:, i // 2, j // 2]
+  import torch.nn.functional as F
+  tp = F.avg_pool2d(t(img).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).numpy()
+  tr = t(img).repeat_interleave(2, 1).repeat_interleave(2, 2).numpy()
+  assert np.abs(tp - pooled).max() < 1e-14 and np.array_equal(tr, rep)
 
 
 def _losses(params, which):
