@@ -892,7 +892,7 @@ struct PlaneS3 {
 #elif DD_OCC3 == 1
 #define DD_OCC(BM, BN, AKC, BKC) (((BM) == 128 && (BN) == 128 && (AKC) && (BKC)) ? 3 : 2)
 #else
-#define DD_OCC(BM, BN, AKC, BKC) 2
+#define DD_OCC(BM, BN, AKC, BKC) ((BM) >= 256 ? 1 : 2)
 #endif
 
 // Raised wave priority around the MFMA block of a k-step (s_setprio): the waves of the two
@@ -1175,7 +1175,7 @@ void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps,
     grid.x = (unsigned)(((tm + 7) & ~7) * tiles_n);
     tm |= TILES_STRIDED;
   }
-  if constexpr (!has_tile_ctx<AL>::value) {   // (tile-context loaders: split loop only, the caller checks the mode)
+  if constexpr (!has_tile_ctx<AL>::value && BM <= 128) {   // (tile-context loaders: split loop only, the caller checks the mode)
     if (gemm_mode() == 0) {
       k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
       return;
@@ -1311,6 +1311,9 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
       if (!strcmp(force, "128x128")) { TMS = 128; TNS = 128; }
       else if (!strcmp(force, "128x64")) { TMS = 128; TNS = 64; }
       else if (!strcmp(force, "64x64")) { TMS = 64; TNS = 64; }
+#ifdef DD_EXP_BIG
+      else if (!strcmp(force, "256x128") && gemm_mode() == 6 && M > 128 && N > 64) { TMS = 256; TNS = 128; }
+#endif
     }
   }
   const int tm = dd_ceil_div(M, TMS), tn = dd_ceil_div(N, TNS);
@@ -1320,6 +1323,11 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
   S = K > 0 ? dd_ceil_div(K, kps) : 1;
   EpiMat ep{C, ldc, bias, alpha, beta, M, N, S > 1 ? ws : nullptr};
   dim3 grid(tm * tn, 1, S);
+#ifdef DD_EXP_BIG
+  if (TMS == 256)
+    launch_tile<256, 128, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
+  else
+#endif
   if (TMS == 128 && TNS == 128)
     launch_tile<128, 128, AKC, BKC>(grid, st, al, bl, ep, K, kps, tm);
   else if (TMS == 128)

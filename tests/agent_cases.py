@@ -31,12 +31,21 @@ def spaces(discrete, image=64, vector=5, action=3):
   return obs, act
 
 
-def policy_parity(backend, discrete, tol, noise_amount=0.0):
+def with_cnn(cfg, cnn):
+  """cnn = 'resnet': the residual encoder / decoder (reference nets.py:330-391) at a small depth."""
+  if cnn == 'simple':
+    return cfg
+  return cfg.update({'encoder.cnn': cnn, 'decoder.cnn': cnn, 'encoder.cnn_depth': 4,
+                     'decoder.cnn_depth': 4, 'encoder.cnn_blocks': 1, 'decoder.cnn_blocks': 1})
+
+
+def policy_parity(backend, discrete, tol, noise_amount=0.0, cnn='simple'):
   """Three consecutive policy calls (initial state, carried state, reset by is_first) in the
   'train' and 'eval' modes against RefAgent.policy with the learner's own noise."""
   dreamer_ref.SAMPLE_TOL[0] = tol['sample']
   cfg = helpers.make_config(('a1_vision', 'debug'))
   cfg = cfg.update({'expl_noise': noise_amount, 'eval_noise': noise_amount / 2})
+  cfg = with_cnn(cfg, cnn)
   A = 4 if discrete else 3
   obs_space, act_space = spaces(discrete, action=A)
   ag = make_agent(cfg, obs_space, act_space, backend)
@@ -82,12 +91,13 @@ def policy_parity(backend, discrete, tol, noise_amount=0.0):
   return ag
 
 
-def report_parity(backend, discrete, tol, device_batch=False, cameras=1):
+def report_parity(backend, discrete, tol, device_batch=False, cameras=1, cnn='simple'):
   """Agent.report against RefAgent.report: world-model loss metrics, open-loop grids and the
   Greedy behaviour's imagined-rollout grids; nothing in the agent's state may change."""
   dreamer_ref.SAMPLE_TOL[0] = tol['sample']
   dreamer_ref.SAMPLE_STATS.update(draws=0, adopted=0)
   cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=7, replay_chunk=8, imag_horizon=3)
+  cfg = with_cnn(cfg, cnn)
   A = 4 if discrete else 3
   obs_space, act_space = spaces(discrete, action=A)
   for i in range(1, cameras):

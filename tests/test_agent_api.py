@@ -23,6 +23,13 @@ def test_report_matches_oracle(discrete):
   assert adopted == 0 and draws > 0
 
 
+def test_policy_and_report_match_oracle_resnet():
+  """The same two bodies with `cnn: resnet` (residual encoder in policy, decoder in report)."""
+  agent_cases.policy_parity(ref_ops.RefOps('cpu'), False, TOL, 0.0, cnn='resnet')
+  adopted, draws = agent_cases.report_parity(ref_ops.RefOps('cpu'), False, TOL, cnn='resnet')
+  assert adopted == 0 and draws > 0
+
+
 def test_load_before_first_train_keeps_controller_state():
   agent_cases.load_before_train_keeps_controller_state(ref_ops.RefOps('cpu'))
 

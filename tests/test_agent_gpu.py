@@ -26,5 +26,13 @@ def test_report_matches_oracle(hip, discrete, device_batch):
   assert adopted <= max(1, draws // 5000)
 
 
+def test_policy_and_report_match_oracle_resnet(hip):
+  """`cnn: resnet`: the residual encoder inside Agent.policy, the residual decoder inside
+  Agent.report (open-loop and imagined grids), device minibatch in."""
+  agent_cases.policy_parity(None, False, TOL, 0.3, cnn='resnet')
+  adopted, draws = agent_cases.report_parity(None, False, TOL, device_batch=True, cnn='resnet')
+  assert adopted <= max(1, draws // 5000)
+
+
 def test_load_before_first_train_keeps_controller_state(hip):
   agent_cases.load_before_train_keeps_controller_state(None)
