@@ -201,3 +201,46 @@ def test_oracle_gradients_match_finite_differences():
         vals.append(_losses(q, which)[0])
       fd = (vals[0] - vals[1]) / (2 * h)
       assert abs(fd - g[idx]) <= 1e-4 * abs(g[idx]) + 2e-7, (name, idx, fd, g[idx])
+
+
+def _resnet_problem():
+  import helpers
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=2, replay_chunk=3, imag_horizon=2)
+  cfg = cfg.update({'encoder.cnn': 'resnet', 'decoder.cnn': 'resnet', 'encoder.cnn_depth': 2,
+                    'decoder.cnn_depth': 2, 'encoder.cnn_blocks': 1, 'decoder.cnn_blocks': 1})
+  return helpers.make_problem(cfg, image=16, vector=5, action=3, terminals=0.2)
+
+
+def test_oracle_resnet_decoder_gradients_match_finite_differences():
+  """The residual decoder's restatement (dreamer_ref.decoder_resnet: Linear, pre-activation
+  blocks with and without the 1x1 skip, repetition, output convolution) against central
+  differences of model_loss, float64, on a 16x16 image (two stages)."""
+  plain, sp, shapes, params, data, B, T = _resnet_problem()
+  H = plain['imag_horizon']
+  params = {k: np.asarray(v, np.float64) for k, v in params.items()}
+  noise = mg.golden_noise(B, T, H, sp.groups, sp.act_dim, 1)
+
+  def loss(p):
+    ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, p, torch.float64)
+    ag.train(data, noise, None)
+    return float(ag.last['model_loss'].detach()), ag.last['grads']
+
+  _, grads = loss(params)
+  rng = np.random.RandomState(4)
+  h = 1e-5
+  for name in ('dec/cnn/in/kernel', 'dec/cnn/in/bias', 'dec/cnn/s0b0a/kernel', 'dec/cnn/s0b0a/norm/scale',
+               'dec/cnn/s0b0b/bias', 'dec/cnn/s1b0s/kernel', 'dec/cnn/s1b0b/kernel',
+               'dec/cnn/s1b0a/norm/bias', 'dec/cnn/out/kernel', 'dec/cnn/out/bias'):
+    assert name in params, (name, [k for k in params if k.startswith('dec/cnn')])
+    g = grads[name].numpy()
+    for i in (int(np.abs(g).argmax()), int(rng.randint(g.size))):
+      idx = np.unravel_index(i, g.shape)
+      vals = []
+      for sgn in (+1, -1):
+        q = dict(params)
+        w = params[name].copy()
+        w[idx] += sgn * h
+        q[name] = w
+        vals.append(loss(q)[0])
+      fd = (vals[0] - vals[1]) / (2 * h)
+      assert abs(fd - g[idx]) <= 1e-4 * abs(g[idx]) + 2e-7, (name, idx, fd, g[idx])
