@@ -1283,6 +1283,11 @@ int pick_split(long tiles, int K, long MN, size_t ws_bytes) {
   static const int kmin = getenv("DD_SPLIT_KMIN") ? atoi(getenv("DD_SPLIT_KMIN")) : 64;
   static const int target = getenv("DD_SPLIT_TARGET") ? atoi(getenv("DD_SPLIT_TARGET")) : 512;
   long s = (target + tiles - 1) / tiles;
+  // never more workgroups than the `target` slots (256 CUs x 2 resident workgroups): the few
+  // extra ones run as a second round after the first has finished - 18 tiles x 29 slabs = 522
+  // workgroups took 1.89 ms where 18 x 28 = 504 take one round (the k = 6 filter gradient)
+  static const int floor_split = getenv("DD_SPLIT_FLOOR") ? atoi(getenv("DD_SPLIT_FLOOR")) : 1;
+  if (floor_split && s > 1 && s * tiles > target) s = target / tiles;
   long maxs = K / kmin;
   if (s > maxs) s = maxs;
   while (s > 1 && (size_t)s * MN * sizeof(float) > ws_bytes) --s;
