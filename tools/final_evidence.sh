@@ -24,6 +24,8 @@ cd $GRAFT_REPO_ROOT
 (timeout 200 python tools/trace_shapes.py > gpurun_out/${tag}_contraction_call_sites.txt 2>&1)
 (timeout 200 python tools/imag_time.py > gpurun_out/${tag}_fused_imagination_times.txt 2>&1)
 (for d in 0 2 6 14; do DD_IMG_DBG=$d timeout 100 python tools/conv_image_probe.py 2>&1 | tail -1; done; DD_UP_IMAGE=0 timeout 100 python tools/conv_image_probe.py 2>&1 | tail -1) > gpurun_out/${tag}_image_layer_probe.txt
+(timeout 100 python tools/conv_same_time.py > gpurun_out/${tag}_conv_same_times.txt 2>&1)
+(timeout 200 python bench.py --cnn resnet --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_resnet.json 2>/dev/null)
 (timeout 120 python tools/graph_stress.py --iters 45 > gpurun_out/${tag}_graph_stress.log 2>&1)
 # the other BASELINE configs at their per-GPU shard (configs[2] 50 / 2 GPUs, [3] 64 / 4, [4] 256 / 8)
 (for c in "a1 --batch 16 --length 16" "xarm --batch 25 --length 50" "ur5_multicam --batch 16 --length 64" "a1_scaled --batch 32 --length 64"; do timeout 400 python bench.py --config $c --no-cpu-baseline 2>/dev/null | grep -a -o '{"metric.*'; done > gpurun_out/${tag}_bench_other_configs.jsonl)
