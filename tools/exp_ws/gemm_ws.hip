@@ -137,6 +137,120 @@ k_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
     }
 }
 
+// Persistent form: one workgroup per CU walks a contiguous range of tiles (column tiles of a row
+// tile back to back).  After the last k-tile of a tile the compute waves write its results while
+// the staging waves are already loading and staging the first k-tiles of the next one.
+template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int BK = 16, int ST = 2>
+__global__ void __launch_bounds__(512, 2)
+k_gemm_ws_p(AL al, BL bl, EP ep, int K, int tiles_m, int tiles_n, int per) {
+  constexpr int NPL = 3;
+  using LA = PlaneS3<BM, AKC, BK>;
+  using LB = PlaneS3<BN, BKC, BK>;
+  __shared__ __attribute__((aligned(16))) unsigned char As[2][NPL * LA::BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NPL * LB::BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool stager = wave >= 4;
+  const int rt = tid & 255, cw = wave & 3;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  const int wm0 = (cw >> 1) * WM, wn0 = (cw & 1) * WN;
+  constexpr int NA = LA::N, NB = LB::N;
+  const int ke = K, nk = (K + BK - 1) / BK;
+  const int ntiles = tiles_m * tiles_n;
+  const int tbeg = (int)blockIdx.x * per, tend = min(ntiles, tbeg + per);
+  float ra_[ST][NA][4], rb_[ST][NB][4];
+  const int lk = lane >> 5, lr = lane & 31;
+
+  for (int tile = tbeg; tile < tend; ++tile) {
+    const int tmi = tile / tiles_n, tni = tile - tmi * tiles_n;
+    const int m0 = tmi * BM, n0 = tni * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto gload = [&](int t, float (&ra)[NA][4], float (&rb)[NB][4]) {
+      const int k0 = t * BK;
+      if (k0 + BK <= ke) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); al.template load4<true>(m0 + r, k0 + k, ke, ra[u]); }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); bl.template load4<true>(n0 + r, k0 + k, ke, rb[u]); }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); al.template load4<false>(m0 + r, k0 + k, ke, ra[u]); }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); bl.template load4<false>(n0 + r, k0 + k, ke, rb[u]); }
+      }
+    };
+    auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); LA::template store<NPL>(As[buf], ra[u], r, k); }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); LB::template store<NPL>(Bs[buf], rb[u], r, k); }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 af[TM][NPL], bf[TN][NPL];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, ks, lane);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, ks, lane);
+        constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+      }
+    };
+
+    if (stager) {
+#pragma unroll
+      for (int s_ = 0; s_ < ST; ++s_)
+        if (s_ < nk) gload(s_, ra_[s_], rb_[s_]);
+      if (nk > 0) sstore(0, ra_[0], rb_[0]);
+      if (ST < nk) gload(ST, ra_[0], rb_[0]);
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < nk; t0 += ST) {
+#pragma unroll
+      for (int s_ = 0; s_ < ST; ++s_) {
+        const int t = t0 + s_;
+        if (t < nk) {
+          if (stager) {
+            if (t + 1 < nk) sstore((t + 1) & 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+            if (t + 1 + ST < nk) gload(t + 1 + ST, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+          } else {
+            compute(t & 1);
+          }
+          __syncthreads();
+        }
+      }
+    }
+    if (!stager) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int col = n0 + wn0 + b * 32 + lr;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            ep(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col, acc[a][b][r]);
+        }
+    }
+  }
+}
+
 template <bool AKC, bool BKC, class AL, class BL>
 int run_ws(AL al, BL bl, int M, int N, int K, float* C, long ldc, float* ws, size_t ws_bytes, hipStream_t st) {
   const int tm = dd_ceil_div(M, 128), tn = dd_ceil_div(N, 128);
@@ -154,6 +268,22 @@ int run_ws(AL al, BL bl, int M, int N, int K, float* C, long ldc, float* ws, siz
   int S = (int)s;
   int kps = ((dd_ceil_div(K, S) + 31) / 32) * 32;
   S = dd_ceil_div(K, kps);
+  static const int persist = getenv("DD_WS_PERSIST") ? atoi(getenv("DD_WS_PERSIST")) : 0;
+  if (persist && S == 1) {
+    static const int cus = getenv("DD_WS_CUS") ? atoi(getenv("DD_WS_CUS")) : 256;
+    const int nt = tm * tn, per = dd_ceil_div(nt, cus), G = dd_ceil_div(nt, per);
+    EpiMat ep{C, ldc, nullptr, 1.f, 0.f, M, N, nullptr};
+    static const int bkp = getenv("DD_WS_BK") ? atoi(getenv("DD_WS_BK")) : 16;
+    static const int stp = getenv("DD_WS_ST") ? atoi(getenv("DD_WS_ST")) : 2;   // k-tiles in flight in registers
+    if (bkp == 32)
+      k_gemm_ws_p<128, 128, AKC, BKC, AL, BL, EpiMat, 32><<<G, 512, 0, st>>>(al, bl, ep, K, tm, tn, per);
+    else if (stp == 4)
+      k_gemm_ws_p<128, 128, AKC, BKC, AL, BL, EpiMat, 16, 4><<<G, 512, 0, st>>>(al, bl, ep, K, tm, tn, per);
+    else
+      k_gemm_ws_p<128, 128, AKC, BKC, AL, BL, EpiMat, 16><<<G, 512, 0, st>>>(al, bl, ep, K, tm, tn, per);
+    DD_CHECK_LAUNCH("dd_gemm_ws(persistent)");
+    return 0;
+  }
   EpiMat ep{C, ldc, nullptr, 1.f, 0.f, M, N, S > 1 ? ws : nullptr};
   dim3 grid(tm * tn, 1, S);
   int tma = tm;
@@ -164,8 +294,12 @@ int run_ws(AL al, BL bl, int M, int N, int K, float* C, long ldc, float* ws, siz
   static const int bk = getenv("DD_WS_BK") ? atoi(getenv("DD_WS_BK")) : 16;
   if (occ == 2)
     k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 2, 16><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+  else if (bk == 32 && getenv("DD_WS_ST") && atoi(getenv("DD_WS_ST")) == 4)
+    k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 4><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
   else if (bk == 32)
     k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+  else if (getenv("DD_WS_ST") && atoi(getenv("DD_WS_ST")) == 4)
+    k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 16, 4><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
   else
     k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 16><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
   DD_CHECK_LAUNCH("dd_gemm_ws");
