@@ -20,7 +20,22 @@ int g_gemm_mode = 6;
 
 namespace {
 
-template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int OCC = 1, int BK = 16, int ST = 2>
+// (ablation) stage a float4 without the split arithmetic: the truncated high halves go to all three
+// planes - what a loader of PRE-SPLIT planes would cost the staging waves, timing only
+template <class PL>
+__device__ __forceinline__ void store_nosplit(unsigned char* base, const float (&v)[4], int r, int k, bool kc) {
+  const int o = kc ? (k >> 3) * PL::STR + r * 16 + (k & 4) * 2 : k * PL::STR + r * 2;
+  const uint2 w = make_uint2(pack_hi(__float_as_uint(v[0]), __float_as_uint(v[1])),
+                             pack_hi(__float_as_uint(v[2]), __float_as_uint(v[3])));
+  *reinterpret_cast<uint2*>(base + o) = w;
+  *reinterpret_cast<uint2*>(base + PL::BYTES + o) = w;
+  *reinterpret_cast<uint2*>(base + 2 * PL::BYTES + o) = w;
+}
+
+// ABL (timing only, wrong results): bit 0 = the staging waves do nothing inside the loop, bit 1 = the compute
+// waves read their fragments once and reuse them, bit 2 = no MFMAs (fragment reads kept alive),
+// bit 3 = the B operand staged without the split, bit 4 = the A operand staged without the split
+template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int OCC = 1, int BK = 16, int ST = 2, int ABL = 0>
 __global__ void __launch_bounds__(512, 2 * OCC)   // (HIP: second argument = waves per SIMD)
 k_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   constexpr int NPL = 3;
@@ -68,30 +83,52 @@ k_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   };
   auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
 #pragma unroll
-    for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); LA::template store<NPL>(As[buf], ra[u], r, k); }
+    for (int u = 0; u < NA; ++u) {
+      int r, k; LA::coord(rt, u, r, k);
+      if constexpr (ABL & 16) store_nosplit<LA>(As[buf], ra[u], r, k, AKC);
+      else LA::template store<NPL>(As[buf], ra[u], r, k);
+    }
 #pragma unroll
-    for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); LB::template store<NPL>(Bs[buf], rb[u], r, k); }
+    for (int u = 0; u < NB; ++u) {
+      int r, k; LB::coord(rt, u, r, k);
+      if constexpr (ABL & 8) store_nosplit<LB>(Bs[buf], rb[u], r, k, BKC);
+      else LB::template store<NPL>(Bs[buf], rb[u], r, k);
+    }
   };
+  bf16x8 af0[TM][NPL], bf0[TN][NPL];
   auto compute = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[TM][NPL], bf[TN][NPL];
+      if constexpr (ABL & 2) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, ks, lane);
+          for (int p = 0; p < NPL; ++p) af[a][p] = af0[a][p];
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, ks, lane);
+          for (int p = 0; p < NPL; ++p) bf[b][p] = bf0[b][p];
+      } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, ks, lane);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, ks, lane);
+      }
       constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TN; ++b) {
+            if constexpr (ABL & 4) acc[a][b][q] += (float)af[a][PA_[q]][0] + (float)bf[b][PB_[q]][0];
+            else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+          }
     }
   };
 
@@ -105,6 +142,16 @@ k_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
     if (ST < nk) gload(ST, ra_[0], rb_[0]);
   }
   __syncthreads();
+  if constexpr (ABL & 2) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) af0[a][p] = LA::frag(As[0] + p * LA::BYTES, wm0 + a * 32, 0, lane);
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) bf0[b][p] = LB::frag(Bs[0] + p * LB::BYTES, wn0 + b * 32, 0, lane);
+  }
   // iteration t: compute waves multiply buffer t & 1; stagers put tile t + 1 (register slot
   // (t + 1) % ST) into buffer (t + 1) & 1 - last read in iteration t - 1, before the barrier
   // that ended it - and then request tile t + 1 + ST into the slot just emptied
@@ -114,8 +161,10 @@ k_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       const int t = t0 + s_;
       if (t < nk) {
         if (stager) {
-          if (t + 1 < nk) sstore((t + 1) & 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
-          if (t + 1 + ST < nk) gload(t + 1 + ST, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+          if constexpr (!(ABL & 1)) {
+            if (t + 1 < nk) sstore((t + 1) & 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+            if (t + 1 + ST < nk) gload(t + 1 + ST, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+          }
         } else {
           compute(t & 1);
         }
@@ -294,6 +343,16 @@ int run_ws(AL al, BL bl, int M, int N, int K, float* C, long ldc, float* ws, siz
   static const int bk = getenv("DD_WS_BK") ? atoi(getenv("DD_WS_BK")) : 16;
   if (occ == 2)
     k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 2, 16><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+  else if (getenv("DD_WS_ABL")) {   // ablations of the BK = 32 loop (timing only)
+    const int abl = atoi(getenv("DD_WS_ABL"));
+    if (abl == 1) k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 2, 1><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else if (abl == 2) k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 2, 2><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else if (abl == 3) k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 2, 3><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else if (abl == 8) k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 2, 8><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else if (abl == 24) k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 2, 24><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else if (abl == 5) k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 2, 5><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 2, 4><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+  }
   else if (bk == 32 && getenv("DD_WS_ST") && atoi(getenv("DD_WS_ST")) == 4)
     k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 1, 32, 4><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
   else if (bk == 32)
