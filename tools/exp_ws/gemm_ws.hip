@@ -186,6 +186,114 @@ k_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
     }
 }
 
+// Role-separated form: each role runs its OWN loop (same number of barriers), so the register
+// allocator sees either the accumulators + fragments or the staging registers, never both - the
+// kernel fits 128 registers and two workgroups (two MFMA waves + two staging waves per SIMD) share a CU.
+// PRIO: 1 = the MFMA waves run at raised priority, 2 = the staging waves do
+template <int BM, int BN, bool AKC, bool BKC, class AL, class BL, class EP, int ST = 2, int PRIO = 0>
+__global__ void __launch_bounds__(512, 4)
+k_gemm_ws2(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
+  constexpr int BK = 16, NPL = 3;
+  using LA = PlaneS3<BM, AKC, BK>;
+  using LB = PlaneS3<BN, BKC, BK>;
+  __shared__ __attribute__((aligned(16))) unsigned char As[2][NPL * LA::BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NPL * LB::BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tmi, tni;
+  if (!tile_coords(tiles_m, tmi, tni)) return;
+  const int m0 = tmi * BM, n0 = tni * BN;
+  const int kb = blockIdx.z * kps;
+  const int ke = min(K, kb + kps);
+  const int nk = (ke - kb + BK - 1) / BK;
+  if (wave >= 4) {   // ---- staging waves
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(2);
+    const int rt = tid & 255;
+    constexpr int NA = LA::N, NB = LB::N;
+    float ra_[ST][NA][4], rb_[ST][NB][4];
+    auto gload = [&](int t, float (&ra)[NA][4], float (&rb)[NB][4]) {
+      const int k0 = kb + t * BK;
+      if (k0 + BK <= ke) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); al.template load4<true>(m0 + r, k0 + k, ke, ra[u]); }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); bl.template load4<true>(n0 + r, k0 + k, ke, rb[u]); }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); al.template load4<false>(m0 + r, k0 + k, ke, ra[u]); }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); bl.template load4<false>(n0 + r, k0 + k, ke, rb[u]); }
+      }
+    };
+    auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); LA::template store<NPL>(As[buf], ra[u], r, k); }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); LB::template store<NPL>(Bs[buf], rb[u], r, k); }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < ST; ++s_)
+      if (s_ < nk) gload(s_, ra_[s_], rb_[s_]);
+    if (nk > 0) sstore(0, ra_[0], rb_[0]);
+    if (ST < nk) gload(ST, ra_[0], rb_[0]);
+    __syncthreads();
+    for (int t0 = 0; t0 < nk; t0 += ST) {
+#pragma unroll
+      for (int s_ = 0; s_ < ST; ++s_) {
+        const int t = t0 + s_;
+        if (t < nk) {
+          if (t + 1 < nk) sstore((t + 1) & 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+          if (t + 1 + ST < nk) gload(t + 1 + ST, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+          __syncthreads();
+        }
+      }
+    }
+    return;
+  }
+  // ---- MFMA waves
+  if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(2);
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    bf16x8 af[TM][NPL], bf[TN][NPL];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, 0, lane);
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, 0, lane);
+    constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+    __syncthreads();
+  }
+  const int lk = lane >> 5, lr = lane & 31;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + wn0 + b * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ep(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col, acc[a][b][r]);
+    }
+}
+
 // Persistent form: one workgroup per CU walks a contiguous range of tiles (column tiles of a row
 // tile back to back).  After the last k-tile of a tile the compute waves write its results while
 // the staging waves are already loading and staging the first k-tiles of the next one.
@@ -341,7 +449,15 @@ int run_ws(AL al, BL bl, int M, int N, int K, float* C, long ldc, float* ws, siz
   // wave for two workgroups per CU (spills ~420 registers: kept only to be measured)
   static const int occ = getenv("DD_WS_OCC") ? atoi(getenv("DD_WS_OCC")) : 1;
   static const int bk = getenv("DD_WS_BK") ? atoi(getenv("DD_WS_BK")) : 16;
-  if (occ == 2)
+  if (getenv("DD_WS_ROLES") && atoi(getenv("DD_WS_ROLES")) == 1)   // role-separated loops, two workgroups per CU
+  {
+    const int v = getenv("DD_WS_V2") ? atoi(getenv("DD_WS_V2")) : 0;   // 1: MFMA waves prioritised, 2: staging waves, 3: four k-tiles in flight
+    if (v == 1) k_gemm_ws2<128, 128, AKC, BKC, AL, BL, EpiMat, 2, 1><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else if (v == 2) k_gemm_ws2<128, 128, AKC, BKC, AL, BL, EpiMat, 2, 2><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else if (v == 3) k_gemm_ws2<128, 128, AKC, BKC, AL, BL, EpiMat, 4, 0><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+    else k_gemm_ws2<128, 128, AKC, BKC, AL, BL, EpiMat><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
+  }
+  else if (occ == 2)
     k_gemm_ws<128, 128, AKC, BKC, AL, BL, EpiMat, 2, 16><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tma);
   else if (getenv("DD_WS_ABL")) {   // ablations of the BK = 32 loop (timing only)
     const int abl = atoi(getenv("DD_WS_ABL"));
