@@ -20,9 +20,17 @@ Scaling over N GPUs (one process per GPU, gradients + controller statistics summ
 On a box with fewer GPUs than ranks the ranks share devices and the collectives fall back to
 gloo on device tensors (a plumbing check, not a measurement; the JSON line says so).
 
+`value` is measured on the SHIPPED DEFAULT schedule (`hip.pipeline: false`: train() returns this
+call's metrics, the reference's contract); the opt-in two-stream pipeline of consecutive steps is
+reported next to it under `pipelined` (single GPU) or selected with --pipeline 1.
+
 One JSON line on rank 0 with `roofline` (dominant kernel family: the MFMA contraction kernels,
-timed live with HIP events on their launch streams) and `cpu_baseline` (the oracle restatement
-of the reference graph on the host cores, full workload batch).
+timed live with HIP events on their launch streams; `peak` is the roof of the instruction stream
+the kernels issue - the dense bf16 MFMA peak / 6 products per fp32 product - and the fp32-MFMA
+nominal figure is given beside it) and `cpu_baseline` (the oracle restatement of the reference
+graph on the host cores, full workload batch).  `roofline.traffic` is measured in this invocation
+(two rocprofv3 --pmc passes over a short child run) when rocprofv3 is on the box (--pmc auto),
+else it is the committed record of the same kernel sources and is labelled so.
 """
 
 import argparse
@@ -43,6 +51,10 @@ from daydreamer_amd import config as config_mod
 from daydreamer_amd import synthetic
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (measured 2382-2495)
+# the contraction kernels compute an fp32 product as six v_mfma_f32_32x32x16_bf16 products of the
+# exact 3-way bf16 split, so the roof of the instructions they issue is the bf16 peak / 6
+PEAK_SPLIT6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
 
 
 def kernel_sources_sha():
@@ -92,10 +104,62 @@ def cpu_baseline(cfg, name, batch, T, threads=16, reps=3):
     _, state, _ = ag.train(data, noise, state)
   dt = (time.perf_counter() - t0) / reps
   return dict(
-      value=batch * T * H / dt, unit='imagined_env_steps/s', cores=threads, kind='port',
+      value=batch * T * H / dt, unit='imagined_env_steps/s', cores=threads, threads=threads,
+      host_cores=os.cpu_count(), kind='port',
       sample=(f'oracle/dreamer_ref.py (reference graph as written, fp32, PyTorch-CPU, {threads} '
               f'threads) on the full workload batch {batch} x seq {T} x horizon {H}: '
               f'{reps} timed train steps after 1 warm-up, {dt:.2f} s/step'))
+
+
+def pmc_live(argv_tail, timeout=170):
+  """HBM traffic of the contraction kernels, measured now: two rocprofv3 --pmc passes (FETCH_SIZE
+  and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over a short
+  child run of this script.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes,
+  same guide, section HBM).  Returns the record dict or None (no rocprofv3, failure, timeout)."""
+  import collections
+  import csv
+  import glob
+  import re
+  import shutil
+  import tempfile
+  exe = shutil.which('rocprofv3')
+  if exe is None:
+    return None
+  per = {}
+  for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    out = tempfile.mkdtemp(prefix=f'dd_pmc_{counter}_', dir='/tmp')
+    cmd = [exe, '--pmc', counter, '--kernel-trace', '-d', out, '-o', 'b', '--output-format', 'csv', '--',
+           sys.executable, os.path.abspath(__file__), '--child', '--steps', '2', '--warmup', '3',
+           '--no-cpu-baseline', '--pmc', 'off'] + argv_tail
+    env = dict(os.environ, TMPDIR='/tmp', DD_PIPE_TUNE='0', PYTHONPATH=ROOT)
+    try:
+      subprocess.run(cmd, env=env, cwd='/tmp', timeout=timeout, check=True,
+                     stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+      files = glob.glob(os.path.join(out, '**', '*counter_collection*.csv'), recursive=True)
+      agg = collections.defaultdict(lambda: [0, 0.0])
+      for r in csv.DictReader(open(files[0])):
+        if r['Counter_Name'] != counter:
+          continue
+        name = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+        key = 'k_mfma_gemm' if 'k_mfma_gemm' in name else 'other'
+        agg[key][0] += 1
+        agg[key][1] += float(r['Counter_Value'])
+      per[counter] = agg['k_mfma_gemm']
+    except Exception as e:  # noqa: BLE001 - any failure falls back to the committed record
+      print(f'[bench] live PMC pass {counter} failed: {type(e).__name__}: {e}', file=sys.stderr)
+      return None
+    finally:
+      shutil.rmtree(out, ignore_errors=True)
+  (nf, vf), (nw, vw) = per['FETCH_SIZE'], per['WRITE_SIZE']
+  if not nf or not nw:
+    return None
+  return dict(
+      source=('measured in this invocation: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) '
+              'over a child run of bench.py (--steps 2 --warmup 3, default schedule); FETCH_SIZE doubled '
+              '(gfx950 counts 128-B requests at 64 B); L2-miss side, Infinity-Cache hits included'),
+      kernel='k_mfma_gemm_s3<*> + k_mfma_gemm_ws<*>', dispatches=nf,
+      fetch_kib_per_launch_reported=round(vf / nf, 2), write_kib_per_launch=round(vw / nw, 2),
+      bytes_per_launch=int(1024 * (2 * vf / nf + vw / nw)), kernel_sources_sha=kernel_sources_sha())
 
 
 def self_launch(args):
@@ -128,8 +192,13 @@ def main():
                        'configs use simple')
   ap.add_argument('--precision', choices=('float32', 'bfloat16'), default='float32',
                   help='hip.precision; bfloat16 is the opt-in reduced-precision mode (not the parity mode)')
-  ap.add_argument('--pipeline', type=int, default=1,
-                  help='hip.pipeline (opt-in two-stream pipeline of consecutive steps)')
+  ap.add_argument('--pipeline', type=int, default=0,
+                  help='hip.pipeline for the headline value (default 0 = the shipped default schedule; '
+                       'with 0 on one GPU the opt-in pipeline is measured too and reported under `pipelined`)')
+  ap.add_argument('--pmc', choices=('auto', 'on', 'off'), default='auto',
+                  help='HBM traffic of the contraction kernels: auto/on = two rocprofv3 --pmc passes over a '
+                       'short child run of this script (single GPU, rocprofv3 on PATH); off = committed record')
+  ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)  # the --pmc child run
   args = ap.parse_args()
 
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -154,6 +223,11 @@ def main():
       dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
     else:
       dist.init_process_group(backend)
+
+  if backend is not None or world > 1:
+    print(f'[bench rank {rank}/{world}] device cuda:{local} of {ndev} visible, backend '
+          f'{backend}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}',
+          file=sys.stderr, flush=True)
 
   cfg = make_config(args.config).update({'hip.pipeline': bool(args.pipeline),
                                          'hip.precision': args.precision})
@@ -214,6 +288,8 @@ def main():
   mets = agent.flush() or box['mets']
   ms = 1e3 * dt
   value = Bg * T * H / dt
+  if args.child:   # the --pmc child: the counters only need the kernels to have run
+    return
 
   # ---- the same with inputs already resident in HBM (no upload, metrics still read)
   def resident_call():
@@ -225,17 +301,31 @@ def main():
   n_extra = max(3, args.steps // 2)
   dt_res = timed(resident_call, n_extra)
 
-  # ---- the shipped default schedule (hip.pipeline off: train() returns this call's metrics)
-  dt_seq = None
-  if pipelined and world == 1:
-    seq = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': False}))
-    sbox = dict(state=None)
-    def seq_call():
-      _, sbox['state'], _ = seq.train(mine, sbox['state'])
+  # ---- the other schedule next to the headline one (single GPU): with the default headline
+  # (hip.pipeline off) the opt-in pipeline, with --pipeline 1 the shipped default
+  dt_other = None
+  if world == 1:
+    other = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': not pipelined}))
+    obox = dict(state=None)
+    def other_call():
+      _, obox['state'], _ = other.train(mine, obox['state'])
     for _ in range(3):
-      seq_call()
-    dt_seq = timed(seq_call, n_extra)
-    del seq
+      other_call()
+    if not pipelined:
+      obox['state'] = other.tune_pipeline(mine, obox['state'])
+    def timed_other(n):
+      barrier()
+      t0 = time.perf_counter()
+      for _ in range(n):
+        other_call()
+      other.flush()
+      barrier()
+      return (time.perf_counter() - t0) / n
+    dt_other = timed_other(args.steps if not pipelined else n_extra)
+    other.flush()
+    del other
+  dt_seq = dt_other if pipelined else None
+  dt_pipe = dt_other if not pipelined else None
 
   # ---- replay-inclusive: minibatches gathered in HBM from a DeviceReplay
   # (embodied.Replay API) -> Agent.train; no host copy of the batch
@@ -288,31 +378,49 @@ def main():
     step_flops = tot_f
     # algorithmic bytes (operands read once, result written once), from the labels
     alg_bytes = sum(int(lab.rsplit(' B', 1)[1]) for lab, _, _, _ in trace)
-    pmc = None
+    pmc, pmc_note = None, None
+    if rank == 0 and world == 1 and args.pmc != 'off' and args.config == 'a1_vision':
+      tail = []
+      if args.cnn != 'simple':
+        tail += ['--cnn', args.cnn]
+      if args.batch:
+        tail += ['--batch', str(args.batch)]
+      if args.length:
+        tail += ['--length', str(args.length)]
+      torch.cuda.synchronize()
+      pmc = pmc_live(tail)
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
-    pmc_note = None
-    if os.path.exists(pmc_path) and args.config == 'a1_vision':
+    if pmc is None and os.path.exists(pmc_path) and args.config == 'a1_vision':
       pmc = json.load(open(pmc_path))
       if pmc.get('kernel_sources_sha') != kernel_sources_sha():
-        pmc_note = ('profiles/pmc_hbm_traffic.json was measured on other kernel sources '
+        pmc_note = ('committed record profiles/pmc_hbm_traffic.json was measured on other kernel sources '
                     f'({pmc.get("kernel_sources_sha")}): not quoted')
         pmc = None
+      else:
+        pmc['source'] = 'committed record (profiles/pmc_hbm_traffic.json, same kernel sources): ' + pmc.get('source', '')
     ach = tot_f / tot_t / 1e12
+    kinds = {k: dict(launches=v[0], tflops=round(v[1] / v[2] / 1e12, 1), ms=round(1e3 * v[2], 3),
+                     frac=round(v[1] / v[2] / 1e12 / PEAK_SPLIT6_TFLOPS, 4)) for k, v in by.items()}
     roof = dict(
         bound='mfma',
-        kernel='k_mfma_gemm_s3<*> + k_imagine_rollout<*> (fp32 GEMM, implicit-GEMM conv and the fused imagination rollout on the bf16 matrix pipe: exact 3-way bf16 split, 6 products, fp32 accumulate; incl. split-K reduce)',
-        achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-        frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        kernel=('k_mfma_gemm_s3<*> / k_mfma_gemm_ws<*> + k_imagine_rollout<*> / k_imagine_reverse<*> (fp32 GEMM, '
+                'implicit-GEMM conv and the fused imagination rollout on the bf16 matrix pipe: exact 3-way bf16 '
+                'split, 6 products of v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate; incl. split-K reduce)'),
+        achieved=round(ach, 2), peak=round(PEAK_SPLIT6_TFLOPS, 1), unit='TFLOP/s',
+        frac=round(ach / PEAK_SPLIT6_TFLOPS, 4),
+        peak_note=('peak = dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 6 bf16 products per fp32 product: '
+                   'the roof of the instructions the kernels issue; achieved counts ALGORITHMIC fp32 flop (2*M*N*K)'),
+        fp32_mfma_nominal=dict(peak=PEAK_F32_MFMA_TFLOPS, frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                               note='v_mfma_f32_32x32x2_f32 dense peak: what a native-fp32 MFMA loop is bounded by '
+                                    '(kinds above 1.0 of it are possible on the bf16 pipe)'),
         traffic=None if pmc is None else pmc['bytes_per_launch'],
         traffic_source=pmc_note if pmc is None else pmc.get('source'),
+        traffic_dispatches=None if pmc is None else pmc.get('dispatches'),
         algorithmic_bytes_per_launch=round(alg_bytes / max(len(trace), 1)),
         launches_per_step=len(trace),
         avg_launch_us=round(1e6 * tot_t / max(len(trace), 1), 2),
         kernel_time_ms=round(1e3 * tot_t, 3),
-        split_bf16_roof=dict(peak=round(2382.0 / 6, 1), frac=round(ach / (2382.0 / 6), 4),
-                             note='bf16 MFMA peak / 6 products per fp32 product'),
-        by_kind={k: dict(launches=v[0], tflops=round(v[1] / v[2] / 1e12, 1),
-                         ms=round(1e3 * v[2], 3)) for k, v in by.items()})
+        by_kind=kinds)
 
   if rank == 0:
     base = None
@@ -339,10 +447,12 @@ def main():
                 backend='RCCL (nccl)' if backend == 'nccl' else backend, world_size=world,
                 ranks_share_devices=shared_devices),
             hip_graphs=plan.n_graphs,
-            pipeline=('on (opt-in hip.pipeline): behaviour phase of step k overlaps world-model phase '
+            schedule=('opt-in hip.pipeline: behaviour phase of step k overlaps world-model phase '
                       'of step k+1, bit-identical parameters, metrics returned one call late'
-                      if pipelined else 'off (default): train() returns this call\'s metrics')),
+                      if pipelined else 'shipped default (hip.pipeline off): train() returns this call\'s metrics')),
         resident=rate(dt_res),
+        pipelined=None if dt_pipe is None else dict(
+            **rate(dt_pipe), note='opt-in hip.pipeline: true - bit-identical parameters, metrics one call late'),
         sequential_default=rate(dt_seq),
         replay_inclusive=None if dt_replay is None else dict(
             **rate(dt_replay), note='DeviceReplay.sample_batch (dd_replay_gather from the HBM '

@@ -123,6 +123,8 @@ class Batcher:
         n += 1
         if done[i] is not None:
           self._wait(done[i])  # the copy out of this pinned set has finished
+          if self._stop.is_set():   # (_wait returned early: the copy may still read the set)
+            return
         if pinned is None:
           with graphs.API_LOCK:
             pinned = [{
@@ -158,9 +160,19 @@ class Batcher:
     return self
 
   def __next__(self):
-    if self._stop.is_set():
-      raise StopIteration
-    batch = self._queue.get()
+    # poll: close() from another thread / a finalizer, or a worker that left through a refused
+    # _put, must end the iteration instead of leaving the consumer blocked in get() forever
+    while True:
+      if self._stop.is_set():
+        raise StopIteration
+      try:
+        batch = self._queue.get(timeout=0.05)
+        break
+      except queue.Empty:
+        if not self._thread.is_alive() and self._queue.empty():
+          if self._error is not None:
+            raise self._error
+          raise StopIteration
     if batch is None:
       raise self._error
     if self._device is None:
@@ -283,6 +295,12 @@ class Pipeline:
       self.s1.synchronize()
       self.s2.synchronize()
       self._use_pair(a, b)
+    if self.tuned:
+      # the losing pairs' graphs (3 plans x 11 pairs) are not needed again: retire them (they are
+      # destroyed by a later capture, after a device-wide synchronize - graphs.py)
+      for key in [k for k in self.plans if k != (a, b)]:
+        for plan in self.plans.pop(key):
+          plan.release()
 
   def step(self):
     """Enqueue one step; returns the metrics of the previous pipelined step (None for

@@ -15,5 +15,5 @@ void dd_set_error_msg(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 
-extern "C" int dd_version(void) { return 1; }
+extern "C" int dd_version(void) { return DD_ABI_VERSION; }
 extern "C" const char* dd_last_error(void) { return g_err; }

@@ -1147,6 +1147,172 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       }
 }
 
+// Role-separated form of the split-bf16 loop for the 128x128 tile (round 3: tools/exp_ws,
+// profiles/r03_gemm_wave_specialised.txt; shipped in round 4 behind the per-launch selector
+// ws_selected below): 512 threads, waves 0-3 only read fragments and issue MFMAs, waves 4-7 only
+// load, split and store the next k-tile.  Each role runs its OWN loop with the same number of
+// barriers, so the register allocator never sees accumulators and staging registers alive
+// together (104 VGPRs: two 8-wave workgroups per CU = two MFMA waves + two staging waves per
+// SIMD, the matrix pipe of a SIMD always has a second wave to draw from while the first waits at
+// the barrier or for its fragments).  Same LDS image, same product order as
+// k_mfma_gemm_s3<128, 128, ..., 6>: results are bit-identical.
+template <bool AKC, bool BKC, class AL, class BL, class EP, int ST = 2>
+__global__ void __launch_bounds__(512, 4)
+k_mfma_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
+  constexpr int BM = 128, BN = 128, BK = 16, NPL = 3;
+  using LA = PlaneS3<BM, AKC, BK>;
+  using LB = PlaneS3<BN, BKC, BK>;
+  __shared__ __attribute__((aligned(16))) unsigned char As[2][NPL * LA::BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NPL * LB::BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tmi, tni;
+  if (!tile_coords(tiles_m, tmi, tni)) return;
+  constexpr bool TC = has_tile_ctx<AL>::value;
+  const auto cx = get_tile_ctx<BM>(al, tmi);
+  int m0 = tmi * BM;
+  const int n0 = tni * BN;
+  const int kb = blockIdx.z * kps;
+  int ke = min(K, kb + kps);
+  if constexpr (TC) { m0 = cx.row0; ke = cx.keff; }
+  const int nk = (ke - kb + BK - 1) / BK;
+  if (wave >= 4) {   // ---- staging waves
+    const int rt = tid & 255;
+    constexpr int NA = LA::N, NB = LB::N;
+    float ra_[ST][NA][4], rb_[ST][NB][4];
+    [[maybe_unused]] long abase[TC ? NA : 1], bbase[TC ? NB : 1];
+    if constexpr (TC) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); abase[u] = al.row_base(cx, m0 + r) + k; }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); bbase[u] = bl.row_base(cx, n0 + r) + k; }
+    }
+    auto gload = [&](int t, float (&ra)[NA][4], float (&rb)[NB][4]) {
+      const int k0 = kb + t * BK;
+      if constexpr (TC) {   // (the tile's contraction length is a whole number of k-tiles)
+        const float* pa = al.ptr() + al.k_off(cx, k0);
+        const float* pb = bl.ptr() + bl.k_off(cx, k0);
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+          const float4 q = *reinterpret_cast<const float4*>(pa + abase[u]);
+          ra[u][0] = q.x; ra[u][1] = q.y; ra[u][2] = q.z; ra[u][3] = q.w;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const float4 q = *reinterpret_cast<const float4*>(pb + bbase[u]);
+          rb[u][0] = q.x; rb[u][1] = q.y; rb[u][2] = q.z; rb[u][3] = q.w;
+        }
+      } else if (k0 + BK <= ke) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); al.template load4<true>(m0 + r, k0 + k, ke, ra[u]); }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); bl.template load4<true>(n0 + r, k0 + k, ke, rb[u]); }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); al.template load4<false>(m0 + r, k0 + k, ke, ra[u]); }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); bl.template load4<false>(n0 + r, k0 + k, ke, rb[u]); }
+      }
+    };
+    auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) { int r, k; LA::coord(rt, u, r, k); LA::template store<NPL>(As[buf], ra[u], r, k); }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { int r, k; LB::coord(rt, u, r, k); LB::template store<NPL>(Bs[buf], rb[u], r, k); }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < ST; ++s_)
+      if (s_ < nk) gload(s_, ra_[s_], rb_[s_]);
+    if (nk > 0) sstore(0, ra_[0], rb_[0]);
+    if (ST < nk) gload(ST, ra_[0], rb_[0]);
+    __syncthreads();
+    for (int t0 = 0; t0 < nk; t0 += ST) {
+#pragma unroll
+      for (int s_ = 0; s_ < ST; ++s_) {
+        const int t = t0 + s_;
+        if (t < nk) {
+          if (t + 1 < nk) sstore((t + 1) & 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+          if (t + 1 + ST < nk) gload(t + 1 + ST, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+          __syncthreads();
+        }
+      }
+    }
+    return;
+  }
+  // ---- MFMA waves (2 x 2 wave tiles of 64 x 64)
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    bf16x8 af[TM][NPL], bf[TN][NPL];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, 0, lane);
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, 0, lane);
+    constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA_[q]], bf[b][PB_[q]], acc[a][b], 0, 0, 0);
+    __syncthreads();
+  }
+  const int lk = lane >> 5, lr = lane & 31;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + wn0 + b * 32 + lr;
+      bool batched = false;
+      if constexpr (epi_reads_c<EP>::value) {
+        if (ep.wants_old()) {
+          batched = true;
+          float oldv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            oldv[r] = ep.read_old(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            ep.put(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col, acc[a][b][r], oldv[r]);
+        }
+      }
+      if (!batched) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if constexpr (TC) ep.putc(cx, m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col, acc[a][b][r]);
+          else ep(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, col, acc[a][b][r]);
+        }
+      }
+    }
+}
+
+// Which launches of the 128x128 tile take the role-separated loop.  Measured per shape class
+// (profiles/r03_gemm_wave_specialised.txt, profiles/r04_ws_selector.txt): it wins where the
+// contraction loop of a workgroup is long (>= DD_WS_KMIN elements per split-K slab: x1.1-1.33) and
+// loses on the K = 512 forms (x0.89-0.96), whose prologue / epilogue the product loop's two
+// independent 4-wave workgroups overlap better.  DD_WS=0 switches it off (A/B measurements);
+// tile-context (banded transposed-convolution) launches have their own threshold on the band's
+// longest contraction.
+inline bool ws_selected(int kps, bool tile_ctx) {
+  static const int on = getenv("DD_WS") ? atoi(getenv("DD_WS")) : 1;
+  static const int kmin = getenv("DD_WS_KMIN") ? atoi(getenv("DD_WS_KMIN")) : 1024;
+  static const int kmin_tc = getenv("DD_WS_KMIN_TC") ? atoi(getenv("DD_WS_KMIN_TC")) : 1024;
+  return on && kps >= (tile_ctx ? kmin_tc : kmin);
+}
+
 // 0 = native fp32 MFMA, 6 = split-bf16 with six products (fp32-level accuracy, default),
 // 1 = bf16 inputs (operands rounded to bf16, one product, fp32 accumulation): the opt-in
 //     reduced-precision mode `hip.precision: bfloat16`, the counterpart of the reference's
@@ -1203,6 +1369,12 @@ void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps,
 #endif
     k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false, DD_A2_64><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   } else {
+    if constexpr (BM == 128 && BN == 128) {
+      if (ws_selected(kps, has_tile_ctx<AL>::value)) {
+        k_mfma_gemm_ws<AKC, BKC, AL, BL, EP><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tm);
+        return;
+      }
+    }
     k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 2, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   }
 }

@@ -1093,6 +1093,26 @@ extern "C" int dd_imag_wprep_t(const float* W, long ld, int K, int n, void* plan
 
 namespace {
 constexpr int IMAG_BWD_LDS = 16 * ZS * 4 + 16 * 3 * 1024 + 16 * HS * 4 + 6 * 256 * 4;
+constexpr int IMAG_LDS = 16 * ZS * 4 + 16 * 3 * 1024 + 16 * HS * 4 + 16 * 256 * 4 + 16 * 32 * 4 + 256 * 4 + 256 * 4 + 16 * 32 * 4 +
+                         (8 * 512 + 6 * 256) * 4;
+int imag_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return dev;
+}
+// The fused kernels need ~157 KB of dynamic LDS per workgroup, which only a full gfx950 CU grants:
+// on a device (or partition) that cannot, the shape query answers "unsupported" and the caller
+// keeps the per-layer launch sequence (as scan.hip's scan_device_ok does for its CU count).
+// Without a visible device (build / CPU tests) the shape alone decides.
+bool imag_device_ok() {
+  int dev = 0, lds = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;
+  }
+  return lds >= (IMAG_LDS > IMAG_BWD_LDS ? IMAG_LDS : IMAG_BWD_LDS);
+}
 }
 
 // ptrs (device pointers, in this order):
@@ -1123,12 +1143,13 @@ extern "C" int dd_imagine_rollout_bwd(int N, int H, int D, int U, int G, int C, 
   bool launched = false;
 #define XB(d, u, g, c, a_)                                                                       \
   if (!launched && D == d && U == u && G == g && C == c && A == a_) {                            \
-    static bool attr = false;                                                                    \
-    if (!attr) {                                                                                 \
+    static unsigned long long attr = 0;   /* one bit per device: the attribute is per device */  \
+    const unsigned long long bit = 1ull << (imag_device() & 63);                                 \
+    if (!(attr & bit)) {                                                                         \
       hipError_t e = hipFuncSetAttribute((const void*)k_imagine_reverse<d, u, g, c, a_>,         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, IMAG_BWD_LDS); \
       if (e != hipSuccess) { dd_set_error("dd_imagine_rollout_bwd(attr)", e); return (int)e; }   \
-      attr = true;                                                                               \
+      attr |= bit;                                                                               \
     }                                                                                            \
     k_imagine_reverse<d, u, g, c, a_><<<blocks, 256, IMAG_BWD_LDS, st>>>(a);                     \
     launched = true;                                                                             \
@@ -1155,16 +1176,11 @@ extern "C" int dd_imag_wprep(const float* W, long ld, int K, int n, int col0, vo
 
 extern "C" int dd_imagine_rollout_supported(int D, int U, int G, int C, int A, int actor_units,
                                             int actor_layers, int prior_layers, int discrete) {
-  if (actor_layers != 4 || prior_layers != 3 || discrete) return 0;
+  if (actor_layers != 4 || prior_layers != 3 || discrete || !imag_device_ok()) return 0;
 #define X(d, u, g, c, a_, au) if (D == d && U == u && G == g && C == c && A == a_ && actor_units == au) return 1;
   DD_IMAG_SHAPES(X)
 #undef X
   return 0;
-}
-
-namespace {
-constexpr int IMAG_LDS = 16 * ZS * 4 + 16 * 3 * 1024 + 16 * HS * 4 + 16 * 256 * 4 + 16 * 32 * 4 + 256 * 4 + 256 * 4 + 16 * 32 * 4 +
-                         (8 * 512 + 6 * 256) * 4;
 }
 
 // ptrs (device pointers, in this order):
@@ -1208,12 +1224,13 @@ extern "C" int dd_imagine_rollout_fwd(int N, int H, int t0, int t1, int D, int U
   bool launched = false;
 #define X(d, u, g, c, a_, au)                                                                    \
   if (!launched && D == d && U == u && G == g && C == c && A == a_ && actor_units == au) {       \
-    static bool attr = false;                                                                    \
-    if (!attr) {                                                                                 \
+    static unsigned long long attr = 0;   /* one bit per device: the attribute is per device */  \
+    const unsigned long long bit = 1ull << (imag_device() & 63);                                 \
+    if (!(attr & bit)) {                                                                         \
       hipError_t e = hipFuncSetAttribute((const void*)k_imagine_rollout<d, u, g, c, a_, au>,     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, IMAG_LDS);  \
       if (e != hipSuccess) { dd_set_error("dd_imagine_rollout_fwd(attr)", e); return (int)e; }   \
-      attr = true;                                                                               \
+      attr |= bit;                                                                               \
     }                                                                                            \
     k_imagine_rollout<d, u, g, c, a_, au><<<blocks, 256, IMAG_LDS, st>>>(a);                     \
     launched = true;                                                                             \

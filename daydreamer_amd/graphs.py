@@ -14,15 +14,21 @@ Lifetime rules (the round-2 driver run died with SIGSEGV inside a graph replay):
     out handles of a 32-entry round-robin pool shared with everything else in the process
     (other agents, the prefetch thread, torch.distributed): a capturing stream could BE the
     stream another thread was issuing on, which invalidates or corrupts the capture.
-  * graph executables are owned by the library (`dd_graph_capture_end`) and registered here;
-    they are never destroyed while the process runs (dropping a plan only drops its Python
-    handles), so no executable can be freed under work that is still queued.
+  * graph executables are owned by the library (`dd_graph_capture_end`) and registered here.
+    Dropping a plan never destroys anything by itself (an executable must not be freed under
+    work that is still queued): the plan's executables are RETIRED, and retired executables are
+    destroyed (`dd_graph_destroy`) only at the next capture of the same device - under API_LOCK,
+    right after the device-wide synchronize every capture starts with, when nothing of the
+    process can be in flight or be launching - and only once at least RECLAIM_THRESHOLD of them
+    have piled up (a process that builds one agent never destroys anything; an agent-in-a-loop
+    sweep stays bounded).  DD_GRAPH_RECLAIM=<n> sets the threshold, 0 disables reclaiming.
   * every capture and graph launch happens under API_LOCK; the prefetch thread
     (agent.Batcher) takes the same lock around its own runtime calls, so no other host thread
     of this package is inside the HIP runtime while a capture or a launch is.
 """
 
 import ctypes
+import os
 import threading
 
 import torch
@@ -39,7 +45,10 @@ API_LOCK = threading.RLock()
 CHECK_CAPTURE_ALLOCS = False
 
 _STREAMS = {}   # (device index, role) -> torch.cuda.ExternalStream
-_EXECS = []     # every graph executable of the process (kept alive)
+_EXECS = set()  # every live graph executable of the process: (device index, handle)
+_RETIRED = []   # executables of dropped plans, destroyed by the next capture on their device
+RECLAIM_THRESHOLD = int(os.environ.get('DD_GRAPH_RECLAIM', 32))
+_DESTROYED = [0]
 
 
 def stream(device, role):
@@ -62,7 +71,41 @@ def stream(device, role):
 
 
 def n_live_graphs():
+  """Executables that are instantiated right now (owned by live plans + retired, not yet destroyed)."""
   return len(_EXECS)
+
+
+def n_destroyed_graphs():
+  return _DESTROYED[0]
+
+
+def _reclaim(lib, idx, force=False):
+  """Destroy the retired executables of device `idx`.  Caller holds API_LOCK and has just
+  synchronized the device."""
+  if not RECLAIM_THRESHOLD and not force:
+    return
+  mine = [e for e in _RETIRED if e[0] == idx]
+  if not force and len(mine) < RECLAIM_THRESHOLD:
+    return
+  for e in mine:
+    _RETIRED.remove(e)
+    _EXECS.discard(e)
+    with torch.cuda.device(idx):
+      rc = lib.dd_graph_destroy(ctypes.c_void_p(e[1]))
+    if rc != 0:
+      raise RuntimeError(f'dd_graph_destroy failed ({rc}): {lib.dd_last_error().decode()}')
+    _DESTROYED[0] += 1
+
+
+def reclaim(device=None):
+  """Synchronize and destroy every retired executable now (tests, long sweeps)."""
+  lib = hipops.load_library()
+  with API_LOCK:
+    for idx in sorted({e[0] for e in _RETIRED}):
+      if device is not None and torch.device(device).index not in (None, idx):
+        continue
+      torch.cuda.synchronize(idx)
+      _reclaim(lib, idx, force=True)
 
 
 class EagerPlan:
@@ -88,6 +131,21 @@ class GraphPlan:
     # all sequential plans of the process share one stream: they are issued by one thread, in
     # program order
     self.stream = stream(self.device, role)
+    self._idx = self.stream.device.index
+    self._owned = []
+
+  def release(self):
+    """Retire this plan's executables (destroyed by a later capture, see the module docstring);
+    the plan must not be replayed afterwards."""
+    owned, self._owned = self._owned, []
+    self.items = []
+    _RETIRED.extend(owned)   # (list.extend is atomic: __del__ may run on any thread)
+
+  def __del__(self):
+    try:
+      self.release()
+    except Exception:  # noqa: BLE001 - interpreter shutdown
+      pass
 
   def _check(self, rc, what):
     if rc != 0:
@@ -102,7 +160,8 @@ class GraphPlan:
                                               ctypes.byref(nodes)), 'dd_graph_capture_end')
     # (a segment between two adjacent cut points holds no kernels: exe is NULL, launch a no-op)
     if exe.value:
-      _EXECS.append(exe.value)
+      _EXECS.add((self._idx, exe.value))
+      self._owned.append((self._idx, exe.value))
     self.items.append(('graph', exe.value))
 
   def capture(self, fn):
@@ -110,6 +169,7 @@ class GraphPlan:
     cut(...) at host/collective points) without executing it."""
     with API_LOCK:
       torch.cuda.synchronize(self.device)
+      _reclaim(self.lib, self._idx)
       check = CHECK_CAPTURE_ALLOCS
       allocs = torch.cuda.memory_stats(self.device).get('allocation.all.allocated', 0) if check else 0
       self.stream.wait_stream(torch.cuda.current_stream(self.device))

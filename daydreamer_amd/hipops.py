@@ -105,6 +105,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
+ABI_VERSION = 3   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -123,6 +124,9 @@ def load_library():
     fn.restype = c_i
   lib.dd_version.restype = c_i
   lib.dd_last_error.restype = ctypes.c_char_p
+  if lib.dd_version() != ABI_VERSION:   # a stale build: signatures below may not match
+    raise RuntimeError(f'{_LIB_PATH} has ABI version {lib.dd_version()}, this binding needs '
+                       f'{ABI_VERSION}: rebuild it (make -C daydreamer_amd/csrc)')
   _lib = lib
   return lib
 

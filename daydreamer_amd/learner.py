@@ -143,11 +143,18 @@ class Learner:
     self.side_stream_b = (graphs.stream(self.device, 'side_b')
                           if ops_b2 is not None and self.device.type == 'cuda' else None)
     self.dtype = dtype  # float32 in the product; tests may use float64
-    # the reduced-precision mode keeps the reference's mixed-precision optimizer contract
-    # (tfutils.py:164-167, 225-240, 246-260): loss-scale controller state, `*_grad_scale` /
-    # `*_grad_overflow` metrics, update skipped (not an exception) on a non-finite gradient.  bf16
-    # has fp32's exponent range, so the scale is tracked but never needs to be applied.
-    self.mixed = str(spec.cfg.get('hip', {}).get('precision', 'float32')) != 'float32'
+    # Non-finite gradients.  The reference enables its loss-scale / skip-on-overflow controller only
+    # for COMPUTE_DTYPE == float16 (tfutils.py:164 `self._mixed`); in float32 AND bfloat16 it runs
+    # check_numerics on the norm and raises (tfutils.py:249).  bf16 has fp32's exponent range, so a
+    # non-finite gradient there is real divergence, not a scaling artefact: both precisions of this
+    # learner raise FloatingPointError.  `hip.loss_scale: true` opts into the float16 contract
+    # (tfutils.py:225-240, 246-260: `*_grad_scale` / `*_grad_overflow` metrics, update skipped
+    # instead of an exception, controller state saved / loaded) for callers that want a run to
+    # survive an isolated overflow.  The reported `*_grad_scale` is the value AFTER the controller
+    # update: the reference puts the tf.Variable itself into the metrics dict (tfutils.py:231),
+    # which tf.function reads when it converts its outputs - after the assign (automatic control
+    # dependencies order a resource read behind earlier writes).
+    self.mixed = bool(spec.cfg.get('hip', {}).get('loss_scale', False))
     self.cfg = cfg = spec.cfg
     self.B, self.T = batch, length
     self.N = batch * length

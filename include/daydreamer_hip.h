@@ -24,6 +24,10 @@
 extern "C" {
 #endif
 
+/* ABI version.  1: rounds 1-2.  2 (round 3): dd_grad_norm gained `int mixed` in front of
+ * `stream` and its opt_state grew from 3 to 5 doubles - a caller built against version 1 must
+ * not call it.  3 (round 4): the version was bumped for that change; no signature changed since. */
+#define DD_ABI_VERSION 3
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -327,7 +331,8 @@ int dd_normalize_update(double* state, const double* sums, double count,
                         const float* in_scale_dev, double decay, double maxv, int impl,
                         int do_update, float* out_off_scale, void* stream);
 int dd_scalar_mul(float* dst, const float* a, const float* b, float c, int n, void* stream);
-/* opt_state = {step, grad_norm, finite, grad_scale, good_steps} (5 doubles):
+/* opt_state = {step, grad_norm, finite, grad_scale, good_steps}: FIVE doubles, all written by
+ * every call (ABI version >= 2; version 1 had three and no `mixed` argument):
  * tf.linalg.global_norm tfutils.py:243; the step advances only on a finite norm (:255-260).
  * mixed != 0: also the loss-scale controller of the reduced-precision mode (tfutils.py:225-240:
  * overflow halves the scale, 1000 good steps double it, clip [1e-4, 1e4]). */

@@ -22,7 +22,8 @@ def test_library_exports_header_symbols():
   from daydreamer_amd import hipops
   assert set(hipops.EXPORTS) == declared, set(hipops.EXPORTS) ^ declared
   lib.dd_version.restype = ctypes.c_int
-  assert lib.dd_version() >= 1
+  header_version = int(re.search(r'#define DD_ABI_VERSION (\d+)', header).group(1))
+  assert lib.dd_version() == header_version == hipops.ABI_VERSION
 
 
 def test_product_fails_loudly_without_gpu():

@@ -50,10 +50,14 @@ def test_streams_are_process_owned(hip):
 @pytest.mark.parametrize('modes', [('seq', 'pipe'), ('batcher', 'seq', 'pipe')])
 def test_agents_created_and_dropped_in_a_loop(hip, modes):
   """x24 {build an agent, eager step, capture, replays, drop it, collect, empty the cache}:
-  graph executables of dropped agents stay registered (never freed under queued work), every
-  new agent captures and replays on the same process-owned streams."""
+  graph executables of dropped agents are retired, never freed under queued work, and destroyed
+  in batches by a later capture (after its device-wide synchronize), so the number of live
+  executables stays bounded; every new agent captures and replays on the same process-owned
+  streams."""
   from daydreamer_amd import graphs, synthetic
   before = graphs.n_live_graphs()
+  destroyed0 = graphs.n_destroyed_graphs()
+  peak = 0
   for it in range(24):
     mode = modes[it % len(modes)]
     B, T, H = 4 + 2 * (it % 2), 6 + 2 * (it % 3), 3 + it % 2
@@ -72,10 +76,19 @@ def test_agents_created_and_dropped_in_a_loop(hip, modes):
     assert ag._plan is not None and ag._plan.n_graphs >= 2
     del ag, state
     gc.collect()
+    peak = max(peak, graphs.n_live_graphs())
     if it % 3 == 2:
       torch.cuda.empty_cache()
   torch.cuda.synchronize()
-  assert graphs.n_live_graphs() > before   # nothing was destroyed
+  if graphs.RECLAIM_THRESHOLD:
+    # retired executables were destroyed along the way and the live set stayed bounded
+    assert graphs.n_destroyed_graphs() > destroyed0
+    assert peak - before <= graphs.RECLAIM_THRESHOLD + 128, (peak, before)
+    gc.collect()
+    graphs.reclaim()
+    assert graphs.n_live_graphs() <= before + 8, (graphs.n_live_graphs(), before)
+  else:
+    assert graphs.n_live_graphs() > before   # nothing was destroyed
 
 
 def test_capture_and_replay_next_to_foreign_stream_traffic(hip):

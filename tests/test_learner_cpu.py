@@ -159,13 +159,15 @@ def test_weight_decay_and_is_first_midsequence():
     assert helpers.rel_err(newp[name], v) < 1e-7, name
 
 
-def test_reduced_precision_mode_keeps_the_mixed_optimizer_contract():
-  """hip.precision: bfloat16 (the counterpart of the reference's tf.precision: float16):
-  `*_grad_scale` / `*_grad_overflow` metrics, the loss-scale controller state, and an update
-  that is skipped - not an exception - when a gradient is not finite (tfutils.py:164-167,
-  225-240, 246-260).  Host logic on the CPU restatement of the kernels."""
+def test_loss_scale_option_keeps_the_mixed_optimizer_contract():
+  """hip.loss_scale: true (the reference's float16 optimizer contract, tfutils.py:164-167,
+  225-240, 246-260): `*_grad_scale` / `*_grad_overflow` metrics, the loss-scale controller state,
+  and an update that is skipped - not an exception - when a gradient is not finite.  Without
+  the option BOTH precisions raise, as the reference does for float32 and bfloat16
+  (`self._mixed` is float16 only; check_numerics, tfutils.py:249).  Host logic on the CPU
+  restatement of the kernels."""
   cfg = helpers.make_config(('a1', 'debug'), batch_size=3, replay_chunk=4, imag_horizon=2)
-  cfg = cfg.update({'hip.precision': 'bfloat16'})
+  cfg = cfg.update({'hip.precision': 'bfloat16', 'hip.loss_scale': True})
   plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, image=0, vector=7, action=6)
   L = learner_mod.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params)
   assert L.mixed
@@ -190,19 +192,21 @@ def test_reduced_precision_mode_keeps_the_mixed_optimizer_contract():
   assert float(mets['actor_grad_scale']) == 5e3 and float(mets['actor_grad_steps']) == 1.0
   assert float(mets['model_grad_overflow']) == 0.0 and float(mets['model_grad_steps']) == 2.0
   assert torch.equal(L.groups['actor'].flat, before)
-  # full precision: the same gradient raises (check_numerics, tfutils.py:249)
-  plain2 = dict(plain, hip=dict(plain.get('hip', {}), precision='float32'))
-  L2 = learner_mod.Learner(type(sp)(**{**sp.__dict__, 'cfg': plain2}), ref_ops.RefOps('cpu'), 'cpu', B, T, params=params)
-  L2.upload(data)
-  keep2 = L2.opt_step
-  def poisoned2(name, cfgkey):
-    if name == 'actor':
-      L2.groups['actor'].gflat[5] = float('inf')
-    keep2(name, cfgkey)
-  L2.opt_step = poisoned2
-  L2.train_step_device(use_carry=False)
-  with pytest.raises(FloatingPointError):
-    L2.read_metrics()
+  # without the option the same gradient raises in both precisions (check_numerics, tfutils.py:249)
+  for prec in ('float32', 'bfloat16'):
+    plain2 = dict(plain, hip=dict(plain.get('hip', {}), precision=prec, loss_scale=False))
+    L2 = learner_mod.Learner(type(sp)(**{**sp.__dict__, 'cfg': plain2}), ref_ops.RefOps('cpu'), 'cpu', B, T, params=params)
+    assert not L2.mixed
+    L2.upload(data)
+    keep2 = L2.opt_step
+    def poisoned2(name, cfgkey, L2=L2, keep2=keep2):
+      if name == 'actor':
+        L2.groups['actor'].gflat[5] = float('inf')
+      keep2(name, cfgkey)
+    L2.opt_step = poisoned2
+    L2.train_step_device(use_carry=False)
+    with pytest.raises(FloatingPointError):
+      L2.read_metrics()
 
 
 def test_report_open_loop_grid():

@@ -20,5 +20,5 @@ for lab, f, e0, e1 in ops.trace:
   d = by.setdefault(lab, [0, 0.0, 0.0]); d[0] += 1; d[1] += f; d[2] += e0.elapsed_time(e1)
 tot = sum(v[2] for v in by.values())
 print('total traced ms', tot)
-for lab, v in sorted(by.items(), key=lambda kv: -kv[1][2])[:45]:
+for lab, v in sorted(by.items(), key=lambda kv: -kv[1][2])[:int(sys.argv[1]) if len(sys.argv) > 1 else 45]:
   print(f'{v[2]:8.3f} ms n={v[0]:4d} {v[1]/v[2]/1e9:7.1f} TF  avg {1e3*v[2]/v[0]:8.1f} us  {lab}')
