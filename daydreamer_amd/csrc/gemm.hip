@@ -19,6 +19,16 @@
 #include "gemm_core.h"
 
 int g_gemm_mode = -1;
+int g_ws_select[3] = {-1, 1024, 1024};
+
+extern "C" int dd_gemm_set_ws(int on, int kmin, int kmin_tc) {
+  ws_selected(0, false);   // (environment defaults first)
+  const int prev = g_ws_select[0];
+  g_ws_select[0] = on ? 1 : 0;
+  if (kmin > 0) g_ws_select[1] = kmin;
+  if (kmin_tc > 0) g_ws_select[2] = kmin_tc;
+  return prev;
+}
 
 extern "C" int dd_gemm_set_mode(int mode) {
   const int prev = gemm_mode();

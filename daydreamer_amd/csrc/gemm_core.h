@@ -12,6 +12,8 @@
 
 // arithmetic mode of the main loop (dd_gemm_set_mode), defined in gemm.hip
 extern int g_gemm_mode;
+// selector of the role-separated loop {on, kmin, kmin of tile-context launches} (dd_gemm_set_ws)
+extern int g_ws_select[3];
 
 namespace {
 
@@ -1299,18 +1301,25 @@ k_mfma_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
     }
 }
 
-// Which launches of the 128x128 tile take the role-separated loop.  Measured per shape class
-// (profiles/r03_gemm_wave_specialised.txt, profiles/r04_ws_selector.txt): it wins where the
-// contraction loop of a workgroup is long (>= DD_WS_KMIN elements per split-K slab: x1.1-1.33) and
-// loses on the K = 512 forms (x0.89-0.96), whose prologue / epilogue the product loop's two
-// independent 4-wave workgroups overlap better.  DD_WS=0 switches it off (A/B measurements);
-// tile-context (banded transposed-convolution) launches have their own threshold on the band's
-// longest contraction.
+// Which launches of the 128x128 tile take the role-separated loop: none by default.
+// Round 3 measured it x1.1-1.33 ahead on deep-K shapes in 13-launch timing loops; in steady state
+// (round 4, tools/r04/ws_steady.py, profiles/r04_ws_steady.txt: 120 back-to-back launches, last
+// 60 averaged) both loops run at the same rate on every shape of the step - 4096^3 717 vs 716 us,
+// 422500x128x2304 1487 vs 1503, 40000x512x1280 284 vs 295, 40000x512x512 128 vs 130 - and the
+// train step's per-call-site times do not move (profiles/r04_ws_selector.txt: 27.89 vs 27.67 ms).
+// The same record shows why: with ZERO operands the identical instruction stream runs 4096^3 in
+// 484 us instead of 717 (284 vs 191 TFLOP/s) - the loop is bound by the chip's power-limited
+// clock on real data (~1.55 vs ~2.3 GHz), not by its schedule, so a schedule that keeps the matrix
+// pipe busier is paid back in clock.  Kept as a selectable variant (dd_gemm_set_ws / DD_WS=1;
+// launches with >= DD_WS_KMIN contraction elements per split-K slab, DD_WS_KMIN_TC for the banded
+// transposed-convolution launches) and covered by the parity tests (bit-identical results).
 inline bool ws_selected(int kps, bool tile_ctx) {
-  static const int on = getenv("DD_WS") ? atoi(getenv("DD_WS")) : 1;
-  static const int kmin = getenv("DD_WS_KMIN") ? atoi(getenv("DD_WS_KMIN")) : 1024;
-  static const int kmin_tc = getenv("DD_WS_KMIN_TC") ? atoi(getenv("DD_WS_KMIN_TC")) : 1024;
-  return on && kps >= (tile_ctx ? kmin_tc : kmin);
+  if (g_ws_select[0] < 0) {
+    g_ws_select[0] = getenv("DD_WS") ? atoi(getenv("DD_WS")) : 0;
+    g_ws_select[1] = getenv("DD_WS_KMIN") ? atoi(getenv("DD_WS_KMIN")) : 1024;
+    g_ws_select[2] = getenv("DD_WS_KMIN_TC") ? atoi(getenv("DD_WS_KMIN_TC")) : 1024;
+  }
+  return g_ws_select[0] && kps >= g_ws_select[tile_ctx ? 2 : 1];
 }
 
 // 0 = native fp32 MFMA, 6 = split-bf16 with six products (fp32-level accuracy, default),

@@ -28,6 +28,7 @@ c_ull = ctypes.c_ulonglong
 
 _SIGS = {
     'dd_gemm_set_mode': [c_i],
+    'dd_gemm_set_ws': [c_i, c_i, c_i],
     'dd_gemm_f32': [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p, c_p, c_z, c_p, c_p],
     'dd_splitk_finish': [c_p, c_i, c_p, c_l, c_i, c_i, c_f, c_p, c_p],
     'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],

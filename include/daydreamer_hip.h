@@ -63,6 +63,15 @@ int dd_splitk_finish(const float* slabs, int n_slabs, float* C, long ldc, int M,
  * with the environment variable DD_GEMM_MODE before the first call.  Returns the previous
  * mode, -1 for an invalid one. */
 int dd_gemm_set_mode(int mode);
+/* Selector of the role-separated form of the 128x128 contraction loop (k_mfma_gemm_ws: four MFMA
+ * waves + four staging waves per workgroup, bit-identical results): used for launches whose
+ * contraction length per split-K slab is >= kmin (banded transposed-convolution launches: kmin_tc);
+ * on = 0 keeps the product loop everywhere.  kmin / kmin_tc <= 0 leave the threshold unchanged.
+ * Off by default: measured equal to the product loop in steady state (both are bound by the
+ * power-limited clock).  Environment defaults: DD_WS (0), DD_WS_KMIN (1024),
+ * DD_WS_KMIN_TC (1024).  Returns the previous
+ * `on`.  Process-wide, not thread-safe against concurrent launches (a measurement switch). */
+int dd_gemm_set_ws(int on, int kmin, int kmin_tc);
 
 /* Stride-2 VALID convolution family over NHWC tensors.  "big" is the
  * full-resolution side [n,hb,wb,Cb], "small" the downsampled side

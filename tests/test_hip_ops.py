@@ -52,6 +52,44 @@ def test_gemm(hip, ref, M, N, K, ta, tb):
     close(g, c, what=f'gemm {M}x{N}x{K} ta{ta} tb{tb} beta{beta}')
 
 
+def test_role_separated_loop_is_bit_identical(hip):
+  """dd_gemm_set_ws: the role-separated form of the 128x128 loop (four MFMA waves + four staging
+  waves, k_mfma_gemm_ws) stages the same LDS image and issues the same products in the same order
+  as the product loop: plain GEMMs (all four operand layouts, beta / bias, split-K, K tail), the
+  strided convolution, its filter gradient and the banded transposed convolution are bit-identical
+  with the variant on and off."""
+  lib = hip.lib
+  def run_all():
+    outs = []
+    for (M, N, K, ta, tb) in [(300, 256, 1040, 0, 0), (2500, 512, 1280, 0, 1), (1280, 512, 4000, 1, 0),
+                              (257, 130, 2052, 1, 1), (4096, 256, 512, 0, 0)]:
+      A = rnd(*((K, M) if ta else (M, K)), seed=1).cuda()
+      B = rnd(*((N, K) if tb else (K, N)), seed=2).cuda()
+      C = rnd(M, N, seed=3).cuda()
+      hip.gemm(A, B, C, bool(ta), bool(tb), 0.5, 1.0, rnd(N, seed=4).cuda())
+      outs.append(C)
+    n, hb, Cb, hs, Cs, k = 6, 30, 64, 13, 128, 6
+    big = rnd(n, hb, hb, Cb, seed=5).cuda()
+    w = rnd(k, k, Cb, Cs, seed=6, scale=0.05).cuda()
+    small = torch.empty(n, hs, hs, Cs, device='cuda')
+    hip.conv_down(big, w, None, small, k)
+    back = torch.empty_like(big)
+    hip.conv_up(small, w, None, back, k)
+    dw = torch.empty_like(w)
+    hip.conv_wgrad(big, small, dw, k)
+    torch.cuda.synchronize()
+    return outs + [small, back, dw]
+  prev = lib.dd_gemm_set_ws(0, 256, 256)
+  try:
+    base = run_all()
+    lib.dd_gemm_set_ws(1, 256, 256)
+    var = run_all()
+  finally:
+    lib.dd_gemm_set_ws(prev, 1024, 1024)
+  for i, (a, b) in enumerate(zip(base, var)):
+    assert torch.isfinite(a).all() and torch.equal(a, b), i
+
+
 def test_gemm_bf16_input_mode(hip, ref):
   """dd_gemm_set_mode(1): the opt-in reduced-precision arithmetic (operands rounded to bf16,
   one product, fp32 accumulation).  Its error is that of bf16 inputs - relative 2^-9 per
