@@ -13,20 +13,42 @@ own outputs.  It follows the reference source line by line instead; every
 function cites the file:line it restates (paths relative to
 /root/reference/embodied/agents/dreamerv2plus/).
 
-TF/TFP semantics assumed from documentation (falsify these if TF is available):
-  * tf.nn.conv2d: NHWC, filter [kh,kw,in,out], cross-correlation, VALID.
+TF/TFP semantics assumed from documentation (falsify these if TF is available).  Each one is
+pinned WITHOUT PyTorch by a loop-form numpy / scalar restatement written from the documented
+formula; the test is named after the arrow (tests/test_oracle_pins.py unless a file is given):
+  * tf.nn.conv2d: NHWC, filter [kh,kw,in,out], cross-correlation, VALID; stride 1 'SAME' pads
+    floor(k/2) zeros per side for odd k          -> test_oracle_independent.py::test_conv2d_matches_direct_loops,
+                                                    ::test_same_conv_pool_repeat_and_residual_block_match_direct_loops
   * tf.nn.conv2d_transpose: filter [kh,kw,out,in], == input-gradient of conv2d
-    (no kernel flip), VALID output = stride*in + k - stride.
+    (no kernel flip), VALID output = stride*in + k - stride
+                                                 -> test_oracle_independent.py::test_conv2d_transpose_matches_direct_loops_and_is_the_adjoint
+  * tf.nn.avg_pool 2x2 / stride 2, tf.repeat     -> test_oracle_independent.py::test_same_conv_pool_repeat_and_residual_block_match_direct_loops
   * tf.nn.moments: population variance; batch_normalization(x,m,v,off,scale,eps)
-    = (x-m)*rsqrt(v+eps)*scale+off.
-  * tf.nn.elu alpha=1; reduce_std population.
+    = (x-m)*rsqrt(v+eps)*scale+off               -> test_layer_norm_is_population_moments_and_batch_normalization
+  * tf.nn.elu alpha=1                            -> test_elu
+  * symlog / symexp (tfutils.py:77-82)           -> test_symlog_symexp
   * tfd.kl_divergence(OneHotCategorical(a), OneHotCategorical(b))
-    = sum softmax(a)*(log_softmax(a)-log_softmax(b)).
-  * OneHotCategorical.entropy = -sum p log p; .mode = one_hot(argmax), no grad.
+    = sum softmax(a)*(log_softmax(a)-log_softmax(b));
+    OneHotCategorical.entropy = -sum p log p     -> test_categorical_kl_and_entropy
+  * .mode = one_hot(argmax), no grad; OneHotDist.sample straight-through (tfutils.py:368-382)
+                                                 -> test_onehot_mode_and_straight_through_sample
   * Bernoulli(logits=l).log_prob(x) = x*logsigmoid(l)+(1-x)*logsigmoid(-l);
-    .mean() = sigmoid(l).
-  * Normal.entropy = 0.5*log(2*pi*e*sigma^2); Normal.sample is reparameterised.
-  * tf.clip_by_global_norm: g * clip / max(norm, clip).
+    .mean() = sigmoid(l)                         -> test_bernoulli_log_prob_and_mean
+  * Normal.entropy = 0.5*log(2*pi*e*sigma^2); Normal.sample is reparameterised
+                                                 -> test_normal_entropy_and_reparameterised_sample
+  * tf.math.cumprod inclusive along axis 0 (agent.py:258)
+                                                 -> test_discount_weights_are_cumprod_over_time
+  * tf.linalg.global_norm; tf.clip_by_global_norm: g * clip / max(norm, clip); the reference's own
+    Adam (tfutils.py:271-283) and the order clip -> decay -> Adam (:205-266)
+                                                 -> test_global_norm_clip_and_literal_adam,
+                                                    test_optimizer_order_clip_then_decay_then_adam
+  * reduce_std / .std() population               -> (through AutoAdapt's metrics) test_autoadapt_*
+and the reference's own control logic restated from its lines: the lambda-return recurrences
+(agent.py:422-442) -> test_lambda_return_recurrences; AutoAdapt update-before-use (tfutils.py:
+440-482) -> test_autoadapt_mult_updates_before_use, test_autoadapt_prop_and_fixed; Normalize's
+bias-corrected float64 EMA (:498-527) -> test_normalize_bias_correction; balance_stats (:395-411)
+-> test_balance_stats.  The autograd gradients are checked against float64 finite differences
+in tests/test_oracle_independent.py.
 
 Determinism contract: weights are an explicit name->tensor dict and every
 stochastic site takes explicit noise (uniforms for the categorical latents,
@@ -124,6 +146,67 @@ def categorical_kl(a, b):
 def categorical_entropy(a):
   la = torch.log_softmax(a, -1)
   return -(torch.exp(la) * la).sum(-1).sum(-1)
+
+
+def bernoulli_log_prob(logit, x):
+  """tfd.Bernoulli(logits=l).log_prob(x), nets.py:469-471 (the `cont` head):
+  x * log sigmoid(l) + (1 - x) * log sigmoid(-l)."""
+  return x * F.logsigmoid(logit) + (1 - x) * F.logsigmoid(-logit)
+
+
+def normal_entropy(std):
+  """tfd.Normal(mean, std).entropy() = 0.5 * log(2 pi e) + log(std)  (agent.py:361-371;
+  `std` may be a python float for the minent / maxent bounds of nets.py:466-467)."""
+  if not torch.is_tensor(std):
+    return 0.5 * math.log(2 * math.pi * math.e) + math.log(std)
+  return 0.5 * math.log(2 * math.pi * math.e) + torch.log(std)
+
+
+def discount_weights(cont, discount):
+  """agent.py:258: tf.math.cumprod(discount * cont) / discount along the time axis."""
+  return torch.cumprod(discount * cont, 0) / discount
+
+
+def lambda_return(reward, value, disc, lam, impl='gve'):
+  """agent.py:422-442 (VFunction.target): reward [H], value [H+1], disc [H] (all with trailing
+  batch axes).  'gve': ret_t = r_t + disc_t * ((1 - lam) * v_{t+1} + lam * ret_{t+1}), bootstrap
+  ret_H = v_H; 'gae': adv_t = delta_t + disc_t * lam * adv_{t+1}, returns adv + v.  Returns
+  (target [H], baseline value[:-1])."""
+  if impl == 'gae':  # :428-433
+    advs = [torch.zeros_like(value[0])]
+    deltas = reward + disc * value[1:] - value[:-1]
+    for t in reversed(range(len(disc))):
+      advs.append(deltas[t] + disc[t] * lam * advs[-1])
+    adv = torch.stack(list(reversed(advs))[:-1])
+    return adv + value[:-1], value[:-1]
+  assert impl == 'gve', impl  # :434-440
+  vals = [value[-1]]
+  interm = reward + disc * value[1:] * (1 - lam)
+  for t in reversed(range(len(disc))):
+    vals.append(interm[t] + disc[t] * lam * vals[-1])
+  ret = torch.stack(list(reversed(vals))[:-1])
+  return ret, value[:-1]
+
+
+def global_norm(grads):
+  """tf.linalg.global_norm, tfutils.py:243: sqrt(sum over tensors of sum of squares)."""
+  return torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).to(grads[0].dtype)
+
+
+def clip_by_global_norm(grads, clip, norm):
+  """tf.clip_by_global_norm(grads, clip, use_norm=norm), tfutils.py:244-245:
+  g * clip / max(norm, clip)."""
+  return [g * clip / torch.clamp(norm, min=clip) for g in grads]
+
+
+def adam_update(p, g, m, v, t, lr, eps, b1=0.9, b2=0.999):
+  """tfutils.py:271-283 (_apply_adam), one tensor: returns the new (m, v); p is updated in place."""
+  m = b1 * m + (1. - b1) * g
+  v = b2 * v + (1. - b2) * g * g
+  m_hat = m / (1. - b1 ** t)
+  v_hat = v / (1. - b2 ** t)
+  p.sub_(lr * m_hat / (torch.sqrt(v_hat) + eps))
+  return m, v
 
 
 class AutoAdapt:
@@ -248,10 +331,9 @@ class Optimizer:
     if world_grads is not None:  # :221-223 all_reduce('mean')
       grads = world_grads(grads)
     raw = {n: g.detach().clone() for n, g in zip(names, grads)}
-    norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)
-                      ).to(grads[0].dtype)  # :243
+    norm = global_norm(grads)  # :243
     if self.clip:  # :244-245
-      grads = [g * self.clip / torch.clamp(norm, min=self.clip) for g in grads]
+      grads = clip_by_global_norm(grads, self.clip, norm)
     if not torch.isfinite(norm):  # :249
       raise FloatingPointError(self.name + '_norm')
     metrics[f'{self.name}_grad_norm'] = norm
@@ -262,16 +344,11 @@ class Optimizer:
             p.mul_(1 - self.wd * self.lr)
       self.step += 1  # :260
       t = float(self.step)
-      b1, b2 = 0.9, 0.999
       for n, p, g in zip(names, plist, grads):  # :271-283
         if n not in self.m:
           self.m[n] = torch.zeros_like(p)
           self.v[n] = torch.zeros_like(p)
-        self.m[n] = b1 * self.m[n] + (1. - b1) * g
-        self.v[n] = b2 * self.v[n] + (1. - b2) * g * g
-        m_hat = self.m[n] / (1. - b1 ** t)
-        v_hat = self.v[n] / (1. - b2 ** t)
-        p.sub_(self.lr * m_hat / (torch.sqrt(v_hat) + self.eps))
+        self.m[n], self.v[n] = adam_update(p, g, self.m[n], self.v[n], t, self.lr, self.eps)
     metrics[f'{self.name}_grad_steps'] = torch.tensor(self.step)
     return metrics, raw
 
@@ -682,7 +759,7 @@ class RefAgent:
     cont = self.head('cont', feat if 'cont' in gh else feat_const,
                      'cont_head')
     x = data['cont']
-    losses['cont'] = -(x * F.logsigmoid(cont) + (1 - x) * F.logsigmoid(-cont))
+    losses['cont'] = -bernoulli_log_prob(cont, x)
     metrics.update({f'{k}_loss_mean': v.mean() for k, v in losses.items()})
     metrics.update(
         {f'{k}_loss_std': v.std(unbiased=False) for k, v in losses.items()})
@@ -700,7 +777,7 @@ class RefAgent:
       metrics[f'reward_{k}'] = v
     for k, v in balance_stats(
         torch.sigmoid(cont),
-        lambda t: t * F.logsigmoid(cont) + (1 - t) * F.logsigmoid(-cont),
+        lambda t: bernoulli_log_prob(cont, t),
         data['cont'], 0.5).items():
       metrics[f'cont_{k}'] = v
     last_state = {k: v[:, -1].detach() for k, v in post.items()}
@@ -738,7 +815,7 @@ class RefAgent:
     cont = torch.sigmoid(self.head('cont', feat_of(traj), 'cont_head'))
     traj['cont'] = torch.cat([first_cont[None], cont[1:]], 0)  # :256-257
     disc = self.cfg['discount']
-    traj['weight'] = torch.cumprod(disc * traj['cont'], 0) / disc  # :258
+    traj['weight'] = discount_weights(traj['cont'], disc)  # :258
     traj['idx'] = torch.stack(idxs, 0) if idxs else None
     traj['policy_mean'] = torch.stack([d[0] for d in dists], 0)
     traj['policy_std'] = torch.stack([d[1] for d in dists], 0)
@@ -748,21 +825,7 @@ class RefAgent:
     cfg = self.cfg
     disc = traj['cont'][1:] * cfg['discount']
     value = symexp(self.head(prefix, feat_of(traj), 'critic'))
-    lam = cfg['return_lambda']
-    if impl == 'gae':  # :428-433
-      advs = [torch.zeros_like(value[0])]
-      deltas = reward + disc * value[1:] - value[:-1]
-      for t in reversed(range(len(disc))):
-        advs.append(deltas[t] + disc[t] * lam * advs[-1])
-      adv = torch.stack(list(reversed(advs))[:-1])
-      return adv + value[:-1], value[:-1]
-    assert impl == 'gve', impl  # :434-440
-    vals = [value[-1]]
-    interm = reward + disc * value[1:] * (1 - lam)
-    for t in reversed(range(len(disc))):
-      vals.append(interm[t] + disc[t] * lam * vals[-1])
-    ret = torch.stack(list(reversed(vals))[:-1])
-    return ret, value[:-1]
+    return lambda_return(reward, value, disc, cfg['return_lambda'], impl)
 
   def update_slow(self):  # agent.py:444-454
     cfg = self.cfg
@@ -853,10 +916,10 @@ class RefAgent:
       loss = loss + ent_loss
     else:  # 'backprop', agent.py:355-356; entropy :361-371
       loss = -score
-      ent = (0.5 * math.log(2 * math.pi * math.e) + torch.log(std))[:-1]
+      ent = normal_entropy(std)[:-1]
       if cfg['actent_norm']:  # :364-367, minent/maxent nets.py:466-467
-        lo = 0.5 * math.log(2 * math.pi * math.e) + math.log(ca['minstd'])
-        hi = 0.5 * math.log(2 * math.pi * math.e) + math.log(ca['maxstd'])
+        lo = normal_entropy(ca['minstd'])
+        hi = normal_entropy(ca['maxstd'])
         ent = (ent - lo) / (hi - lo)
       ent_loss, mets = self.actent(ent)
       metrics.update({f'actent_{k}': v.detach() for k, v in mets.items()})

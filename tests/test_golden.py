@@ -1,5 +1,6 @@
-"""Golden vectors (tests/golden/debug_step.npz, made by make_golden.py from the
-float64 oracle): the oracle must reproduce them, the learner's host logic must
+"""Golden vectors (tests/golden/{debug,onehot,resnet}_step.npz, made by make_golden.py from the
+float64 oracle: continuous actions / actor by backprop, one-hot actions / actor by REINFORCE,
+residual encoder / decoder): the oracle must reproduce them, the learner's host logic must
 match them on CPU, and the HIP path must match them on the GPU."""
 
 import importlib.util
@@ -16,7 +17,8 @@ HERE = pathlib.Path(__file__).parent
 spec_ = importlib.util.spec_from_file_location('make_golden', HERE / 'golden' / 'make_golden.py')
 mg = importlib.util.module_from_spec(spec_)
 spec_.loader.exec_module(mg)
-GOLD = np.load(HERE / 'golden' / 'debug_step.npz')
+GOLDS = {case: np.load(HERE / 'golden' / f'{case}_step.npz') for case in mg.CASES}
+CASES = list(mg.CASES)
 
 KEYS = ('model_loss', 'image_loss_mean', 'vector_loss_mean', 'kl_loss_mean',
         'reward_loss_mean', 'cont_loss_mean', 'extr_critic_loss', 'actor_loss',
@@ -24,11 +26,12 @@ KEYS = ('model_loss', 'image_loss_mean', 'vector_loss_mean', 'kl_loss_mean',
         'actent_mean', 'prior_ent_mean', 'post_ent_mean')
 
 
-def test_oracle_reproduces_golden():
-  from oracle import dreamer_ref
-  plain, sp, shapes, params, data, B, T = mg.build()
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_reproduces_golden(case):
+  GOLD = GOLDS[case]
+  plain, sp, shapes, params, data, B, T = mg.build(case)
   H = plain['imag_horizon']
-  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64)
+  ag = mg.make_ref(case, plain, sp, shapes, params)
   state = None
   for step in (1, 2):
     noise = mg.golden_noise(B, T, H, sp.groups, sp.act_dim, step)
@@ -38,16 +41,22 @@ def test_oracle_reproduces_golden():
       assert abs(float(mets[k]) - g) <= 1e-9 * max(1, abs(g)), (step, k)
     assert np.array_equal(ag.last['wm']['idxs']['post'].numpy(), GOLD[f's{step}/idx_post'])
     assert np.array_equal(ag.last['traj']['idx'].numpy(), GOLD[f's{step}/idx_img'])
+    if case == 'onehot':
+      assert np.array_equal(ag.last['traj']['action'].argmax(-1).numpy(), GOLD[f's{step}/idx_act'])
 
 
-def check_learner(L, data, mtol, gtol, exact_idx):
+def check_learner(L, data, mtol, gtol, exact_idx, case='debug'):
+  GOLD = GOLDS[case]
   B, T, N, H, D, F, G, C = L.B, L.T, L.N, L.H, L.D, L.F, L.G, L.C
   for step in (1, 2):
     L.upload(data)
     L.train_step_device(use_carry=(step > 1))
     mets = L.read_metrics()
     f = helpers.forced_from_learner(L)
-    for nm, key in (('obs_post', 'idx_post'), ('obs_prior', 'idx_prior'), ('img', 'idx_img')):
+    sites = [('obs_post', 'idx_post'), ('obs_prior', 'idx_prior'), ('img', 'idx_img')]
+    if case == 'onehot':
+      sites.append(('act', 'idx_act'))
+    for nm, key in sites:
       same = (f[nm].numpy() == GOLD[f's{step}/{key}'])
       if exact_idx:
         assert same.all(), (step, nm)
@@ -60,21 +69,22 @@ def check_learner(L, data, mtol, gtol, exact_idx):
     for name, g in grads.items():
       ref = GOLD[f's{step}/gradsum/{name}']
       assert abs(g.astype(np.float64).sum() - ref[0]) <= gtol * max(ref[1], 1e-12), (step, name)
-    for k in ('rssm/initial_deter', 'actor/dist_out/std/kernel',
-              'reward/dist_out/out/kernel', 'rssm/obs_stats/bias'):
+    for k in mg.grad_keys(case):
       assert helpers.rel_err(grads[k], GOLD[f's{step}/grad/{k}']) < gtol * 10, (step, k)
 
 
-def test_learner_host_logic_matches_golden():
+@pytest.mark.parametrize('case', CASES)
+def test_learner_host_logic_matches_golden(case):
   from oracle import ref_ops
-  plain, sp, shapes, params, data, B, T = mg.build()
+  plain, sp, shapes, params, data, B, T = mg.build(case)
   L = LM.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params,
                  noise_seed=mg.NOISE_SEED, dtype=torch.float64)
-  check_learner(L, data, 1e-6, 1e-6, True)
+  check_learner(L, data, 1e-6, 1e-6, True, case)
 
 
 @pytest.mark.gpu
-def test_hip_matches_golden(hip):
-  plain, sp, shapes, params, data, B, T = mg.build()
+@pytest.mark.parametrize('case', CASES)
+def test_hip_matches_golden(hip, case):
+  plain, sp, shapes, params, data, B, T = mg.build(case)
   L = LM.Learner(sp, hip, 'cuda:0', B, T, params=params, noise_seed=mg.NOISE_SEED)
-  check_learner(L, data, 1e-3, 1e-3, False)
+  check_learner(L, data, 1e-3, 1e-3, False, case)
