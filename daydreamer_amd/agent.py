@@ -509,7 +509,9 @@ class Agent:
         self.spec, self.ops, self.device, batch // self.world, length,
         rank=self.rank, world=self.world, comm=self.comm,
         noise_seed=self._noise_seed, dtype=self._dtype, groups=self.groups,
-        ops2=self.ops2, ops_b=self.ops_b, comm_b=self.comm_b, ops_b2=self.ops_b2)
+        ops2=self.ops2, ops_b=self.ops_b, comm_b=self.comm_b, ops_b2=self.ops_b2,
+        dp_overlap=(self.comm is not None and not self._pipeline
+                    and os.environ.get('DD_DP_OVERLAP', '1') != '0'))
     if self._pending_load is not None:
       self._apply_load(self._pending_load)
       self._pending_load = None

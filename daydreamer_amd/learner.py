@@ -120,8 +120,16 @@ class Learner:
 
   def __init__(self, spec, ops, device, batch, length, params=None, seed=0,
                rank=0, world=1, comm=None, noise_seed=0, dtype=F32,
-               groups=None, ops2=None, ops_b=None, comm_b=None, ops_b2=None):
+               groups=None, ops2=None, ops_b=None, comm_b=None, ops_b2=None, dp_overlap=False):
     self.spec, self.ops, self.device = spec, ops, torch.device(device)
+    # data parallel, default schedule: the all-reduce of the decoder / head gradients (the
+    # contiguous [dec | reward | cont] kernel range of the model arena, 71 % of it at
+    # configs[1]) is issued as soon as they are complete - after the reverse observe scan,
+    # on the process's `comm` stream - and runs next to the encoder's backward pass; the rest
+    # of the arena follows in front of the optimizer (tfutils.py:221-223 reduces after the whole
+    # backward).  Same sums, same order of collectives on every rank.
+    self.dp_overlap = bool(dp_overlap) and comm is not None
+    self._early = None
     # ops_b: launch context (own scratch workspace) of the behaviour phase, so that it
     # can run on its own stream next to the next step's world-model phase (pipeline)
     self.ops_a, self.ops_b = ops, (ops_b if ops_b is not None else ops)
@@ -536,6 +544,47 @@ class Learner:
     stream = stream or self.side_stream
     if stream is not None:
       torch.cuda.current_stream(self.device).wait_stream(stream)
+
+  def early_range(self):
+    """[start, stop) of the model gradient arena that is complete once the head / decoder
+    weight gradients are: the longest run of consecutive dec / reward / cont tensors in arena
+    order (with weight decay: their kernels, which lie together in the decayed prefix; the few
+    scale / bias vectors of those modules in the other part go with the rest)."""
+    g = self.groups['model']
+    mods = ('dec', 'reward', 'cont')
+    specs = list(g.specs)            # arena order (offsets ascending)
+    best, i = None, 0
+    while i < len(specs):
+      if specs[i].name.split('/')[0] not in mods:
+        i += 1
+        continue
+      j = i
+      while j < len(specs) and specs[j].name.split('/')[0] in mods:
+        j += 1
+      start = g.offset[specs[i].name]
+      stop = g.offset[specs[j].name] if j < len(specs) else g.gflat.numel()   # (incl. zero padding)
+      if best is None or stop - start > best[1] - best[0]:
+        best = (start, stop)
+      i = j
+    return best
+
+  def allreduce_early(self):
+    """Issue the all-reduce of the early range on the comm stream (a graph cut point)."""
+    rng = self.early_range()
+    if rng is None:
+      return
+    g, comm = self.groups['model'], self.comm
+    view = g.gflat[rng[0]:rng[1]]
+    cs = graphs.stream(self.device, 'comm') if self.device.type == 'cuda' else None
+    def issue():
+      if cs is None:
+        comm.allreduce_sum(view)
+        return
+      cs.wait_stream(torch.cuda.current_stream(self.device))
+      with torch.cuda.stream(cs):
+        comm.allreduce_sum(view)
+    self.plan.cut(issue)
+    self._early = (rng, cs)
 
   def allreduce(self, t):
     """Sum over data-parallel ranks (RCCL); a graph cut point."""
@@ -1122,7 +1171,20 @@ class Learner:
   def opt_step(self, name, cfgkey):
     g = self.groups[name]
     c = self.cfg[cfgkey]
-    self.allreduce(g.gflat)
+    if name == 'model' and self._early is not None:
+      (lo, hi), cs = self._early
+      self._early = None
+      comm, head, tail = self.comm, g.gflat[:lo], g.gflat[hi:]
+      def rest():
+        if head.numel():
+          comm.allreduce_sum(head)
+        if tail.numel():
+          comm.allreduce_sum(tail)
+        if cs is not None:   # the early range's sum must have landed before the norm reads it
+          torch.cuda.current_stream(self.device).wait_stream(cs)
+      self.plan.cut(rest)
+    else:
+      self.allreduce(g.gflat)
     self.ops.grad_norm(g.gflat, g.opt_state, self.mixed)
     self.ops.adam_step(g.flat, g.gflat, g.m, g.v, g.n_decay, g.opt_state,
                        c['lr'], c['wd'], c['eps'], 0.9, 0.999, c['clip'])
@@ -1260,6 +1322,9 @@ class Learner:
         for f in defer:
           f(self.ops2)
     self.observe_bwd()
+    if self.dp_overlap:
+      self.join()            # head / decoder weight gradients complete
+      self.allreduce_early()
     self.encoder_bwd()
     self.join()
 

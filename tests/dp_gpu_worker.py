@@ -1,6 +1,8 @@
-"""Worker of tests/test_dp_gpu.py: one data-parallel rank on the HIP kernels.  All ranks share
-the one visible GPU (LOCAL_RANK forced to 0); collectives run on device tensors through the
-backend in DD_DIST_BACKEND (gloo by default; nccl = RCCL where two ranks may share a device).
+"""Worker of tests/test_dp_gpu.py: one data-parallel rank on the HIP kernels.  With
+DD_DP_DISTINCT=1 (set by the test when the box has at least as many GPUs as ranks) rank r runs on
+GPU r, as the driver launches bench.py; otherwise all ranks share the one visible GPU (LOCAL_RANK
+forced to 0).  Collectives run on device tensors through the backend in DD_DIST_BACKEND (gloo by
+default; nccl = RCCL, which needs one GPU per rank).  DD_DP_BATCH: the global batch (default 6).
 
   python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P \\
       tests/dp_gpu_worker.py OUTDIR
@@ -12,7 +14,9 @@ import pathlib
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / 'tests'))
-os.environ['LOCAL_RANK'] = '0'
+DISTINCT = os.environ.get('DD_DP_DISTINCT') == '1'
+if not DISTINCT:
+  os.environ['LOCAL_RANK'] = '0'
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -24,11 +28,20 @@ import helpers  # noqa: E402
 
 def main():
   outdir = sys.argv[1]
-  dist.init_process_group(os.environ.get('DD_DIST_BACKEND', 'gloo'))
+  local = int(os.environ['LOCAL_RANK'])
+  torch.cuda.set_device(local)
+  backend = os.environ.get('DD_DIST_BACKEND', 'gloo')
+  if backend == 'nccl':
+    dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+  else:
+    dist.init_process_group(backend)
   rank, world = dist.get_rank(), dist.get_world_size()
-  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=6, replay_chunk=8, imag_horizon=4)
+  BG = int(os.environ.get('DD_DP_BATCH', 6))
+  dev = f'cuda:{local}'
+  print(f'rank {rank}/{world}: device {dev} of {torch.cuda.device_count()}, backend {backend}', flush=True)
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=BG, replay_chunk=8, imag_horizon=4)
   obs, act = synthetic.make_spaces(64, 5, 3)
-  batches = [synthetic.make_batch(obs, act, 6, 8, seed=s, smooth_images=True, terminals=0.1)
+  batches = [synthetic.make_batch(obs, act, BG, 8, seed=s, smooth_images=True, terminals=0.1)
              for s in range(3)]
   res = {}
   # DD_DP_TUNE=1: enough pipelined calls for the stream-pair measurement (12 pairs x 3 steps) to
@@ -41,7 +54,7 @@ def main():
     for i in range(steps):
       batch = batches[i % 3]
       if i >= 3:  # rank-sharded minibatches, as a sharded Agent.dataset yields them
-        per = 6 // world
+        per = BG // world
         batch = agent_mod.ShardedBatch({k: v[rank * per:(rank + 1) * per] for k, v in batch.items()})
       _, state, m = ag.train(batch, state)
     last = ag.flush()
@@ -49,7 +62,7 @@ def main():
   if os.environ.get('DD_DP_TUNE') == '1':
     best = agent_mod.Pipeline.BEST
     assert len(best) == 1, best
-    pick = torch.tensor(list(best.values())[0], dtype=torch.int64, device='cuda:0')
+    pick = torch.tensor(list(best.values())[0], dtype=torch.int64, device=dev)
     picks = [torch.zeros_like(pick) for _ in range(world)]
     dist.all_gather(picks, pick)
     assert all(torch.equal(p, picks[0]) for p in picks), picks

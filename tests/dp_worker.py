@@ -9,7 +9,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / 'tests'))
 
 
-def run(rank, world, port, outdir, steps):
+def run(rank, world, port, outdir, steps, overlap=False):
   import numpy as np
   import torch
   import torch.distributed as dist
@@ -26,7 +26,9 @@ def run(rank, world, port, outdir, steps):
   per = B // world
   shard = {k: v[rank * per:(rank + 1) * per] for k, v in data.items()}
   L = LM.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', per, T, params=params, rank=rank,
-                 world=world, comm=agent_mod.DistComm(), noise_seed=5, dtype=torch.float64)
+                 world=world, comm=agent_mod.DistComm(), noise_seed=5, dtype=torch.float64,
+                 dp_overlap=overlap)
+  assert L.dp_overlap == bool(overlap) and (not overlap or L.early_range() is not None)
   for i in range(steps):
     L.upload(shard)
     L.train_step_device(use_carry=(i > 0))

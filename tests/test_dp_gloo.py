@@ -23,11 +23,17 @@ def free_port():
   return p
 
 
-def test_two_ranks_equal_one():
+import pytest
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_two_ranks_equal_one(overlap):
+  """overlap: the all-reduce of the decoder / head gradient range issued before the encoder's
+  backward pass, the rest in front of the optimizer (Learner.allreduce_early) - same sums."""
   from oracle import ref_ops
   steps = 2
   with tempfile.TemporaryDirectory() as d:
-    mp.spawn(dp_worker.run, args=(2, free_port(), d, steps), nprocs=2, join=True)
+    mp.spawn(dp_worker.run, args=(2, free_port(), d, steps, overlap), nprocs=2, join=True)
     got = dict(np.load(f'{d}/dp.npz'))
   cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=4, imag_horizon=3)
   plain, sp, shapes, params, data, B, T = helpers.make_problem(

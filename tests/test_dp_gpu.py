@@ -6,8 +6,10 @@ launches them - share the one visible MI355X, each on its shard of the global ba
     grouping than one batch), metrics within 1e-5;
   * the two-stream pipeline under data parallelism == the sequential schedule, bit for bit;
   * global and rank-sharded (ShardedBatch) minibatches are both exercised.
-Collectives: gloo on device tensors; the RCCL (nccl) variant runs where two ranks may share a
-device and is skipped, with the reason, where RCCL refuses a duplicate GPU."""
+Collectives: gloo on device tensors when the ranks share one GPU.  The RCCL (nccl) variants need
+one GPU per rank: they run - rank r on GPU r, exactly as the driver launches bench.py - as soon as
+torch.cuda.device_count() >= ranks (2, 4 and 8 ranks), and are skipped with that reason on a
+smaller box (RCCL refuses two ranks on one device)."""
 
 import os
 import socket
@@ -17,6 +19,7 @@ import pathlib
 
 import numpy as np
 import pytest
+import torch
 
 import helpers
 
@@ -32,21 +35,23 @@ def free_port():
   return p
 
 
-def launch(tmp_path, backend, tune=False):
+def launch(tmp_path, backend, tune=False, ranks=2, batch=6):
+  distinct = torch.cuda.device_count() >= ranks
   env = dict(os.environ, DD_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0',
-             DD_PIPE_TUNE='1' if tune else '0', DD_DP_TUNE='1' if tune else '0')
-  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+             DD_PIPE_TUNE='1' if tune else '0', DD_DP_TUNE='1' if tune else '0',
+             DD_DP_DISTINCT='1' if distinct else '0', DD_DP_BATCH=str(batch))
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks),
          '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
          str(ROOT / 'tests' / 'dp_gpu_worker.py'), str(tmp_path)]
   return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                         timeout=420)
 
 
-def single_rank_reference():
+def single_rank_reference(batch=6):
   from daydreamer_amd import agent as agent_mod, synthetic
-  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=6, replay_chunk=8, imag_horizon=4)
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=batch, replay_chunk=8, imag_horizon=4)
   obs, act = synthetic.make_spaces(64, 5, 3)
-  batches = [synthetic.make_batch(obs, act, 6, 8, seed=s, smooth_images=True, terminals=0.1)
+  batches = [synthetic.make_batch(obs, act, batch, 8, seed=s, smooth_images=True, terminals=0.1)
              for s in range(3)]
   ag = agent_mod.Agent(obs, act, None, cfg)
   state = None
@@ -55,9 +60,9 @@ def single_rank_reference():
   return ag.save(), m
 
 
-def compare(tmp_path):
+def compare(tmp_path, batch=6):
   got = dict(np.load(tmp_path / 'dp_gpu.npz'))
-  want, mets = single_rank_reference()
+  want, mets = single_rank_reference(batch)
   worst = max((helpers.rel_err(got[f'p/{k}'], np.asarray(v)), k) for k, v in want.items()
               if k.startswith('params/'))
   print('2 ranks vs 1 rank: worst parameter rel err', worst)
@@ -78,15 +83,19 @@ def test_two_ranks_on_hip_kernels_gloo(hip, tmp_path):
   compare(tmp_path)
 
 
-def test_two_ranks_on_hip_kernels_rccl(hip, tmp_path):
-  r = launch(tmp_path, 'nccl')
+@pytest.mark.parametrize('ranks,batch', [(2, 6), (4, 8), (8, 8)])
+def test_ranks_on_hip_kernels_rccl(hip, tmp_path, ranks, batch):
+  """RCCL over xGMI, one GPU per rank: N ranks == 1 rank on the global batch, pipelined ==
+  sequential bitwise (the worker exits non-zero otherwise), incl. the early all-reduce of the
+  decoder / head gradient range on the comm stream and the three communicators of the pipeline."""
+  have = torch.cuda.device_count()
+  if have < ranks:
+    pytest.skip(f'{have} GPU(s) visible, {ranks} needed: RCCL refuses two ranks on one device, '
+                'so multi-rank RCCL needs one GPU per rank (runs automatically on a larger box)')
+  r = launch(tmp_path, 'nccl', ranks=ranks, batch=batch)
   print(r.stdout[-3000:])
-  if r.returncode != 0 and any(s in r.stdout for s in (
-      'Duplicate GPU', 'duplicate GPU', 'invalid usage', 'ncclInvalidUsage')):
-    pytest.skip('RCCL refuses two ranks on one device (single-GPU box): multi-rank RCCL needs '
-                'one GPU per rank')
   assert r.returncode == 0, r.stdout[-3000:]
-  compare(tmp_path)
+  compare(tmp_path, batch)
 
 
 def test_two_ranks_pick_the_same_stream_pair(hip, tmp_path):
