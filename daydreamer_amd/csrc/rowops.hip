@@ -77,7 +77,8 @@ template <int NPL>
 __global__ void __launch_bounds__(256)
 k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
              const float* __restrict__ out, long ldo, const float* __restrict__ stats, long lds,
-             const float* __restrict__ gamma, float* __restrict__ dz, long lddz,
+             const float* __restrict__ gamma, const float* __restrict__ beta,
+             float* __restrict__ dz, long lddz,
              float* __restrict__ partials, int rows, int C, int act) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float pg[NPL > 0 ? NPL : 1], pb[NPL > 0 ? NPL : 1];
@@ -87,8 +88,14 @@ k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__
     const float mean = stats[row * lds], rstd = stats[row * lds + 1];
     const float* dr = dout + row * ldd;
     const float* zr = z + row * ldz;
-    const float* orow = out + row * ldo;
+    const float* orow = out ? out + row * ldo : nullptr;
     float* dzr = dz + row * lddz;
+    // ELU'(y) = 1 (y > 0) or elu(y) + 1: from the stored activation, or - out == NULL - from
+    // y = LN(z) * gamma + beta recomputed with the forward kernel's own expression (same bits)
+    auto dact = [&](int c) {
+      const float o = orow ? orow[c] : elu_((zr[c] - mean) * rstd * gamma[c] + beta[c]);
+      return o > 0.f ? 1.f : o + 1.f;
+    };
     if (NPL > 0) {
       float g[NPL > 0 ? NPL : 1], xh[NPL > 0 ? NPL : 1];
       float s1 = 0.f, s2 = 0.f;
@@ -97,7 +104,7 @@ k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__
         int c = lane + 64 * i;
         if (c < C) {
           float dy = dr[c];
-          if (act) { float o = orow[c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
+          if (act) dy *= dact(c);
           xh[i] = (zr[c] - mean) * rstd;
           g[i] = dy * gamma[c];
           pg[i] += dy * xh[i];
@@ -117,7 +124,7 @@ k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__
       float s1 = 0.f, s2 = 0.f;
       for (int c = lane; c < C; c += 64) {
         float dy = dr[c];
-        if (act) { float o = orow[c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
+        if (act) dy *= dact(c);
         float xh = (zr[c] - mean) * rstd;
         float g = dy * gamma[c];
         s1 += g; s2 += g * xh;
@@ -126,7 +133,7 @@ k_ln_act_bwd(const float* __restrict__ dout, long ldd, const float* __restrict__
       s2 = wave_sum(s2) / (float)C;
       for (int c = lane; c < C; c += 64) {
         float dy = dr[c];
-        if (act) { float o = orow[c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
+        if (act) dy *= dact(c);
         float xh = (zr[c] - mean) * rstd;
         dzr[c] = rstd * (dy * gamma[c] - s1 - xh * s2);
       }
@@ -226,7 +233,8 @@ template <int LPR, int V>
 __global__ void __launch_bounds__(256)
 k_ln_act_bwd_v(float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
                const float* __restrict__ out, long ldo, const float* __restrict__ stats, long lds,
-               const float* __restrict__ gamma, float* __restrict__ dz, long lddz,
+               const float* __restrict__ gamma, const float* __restrict__ beta,
+               float* __restrict__ dz, long lddz,
                float* __restrict__ partials, int rows, int C, int act, PreSum ps) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -256,13 +264,20 @@ k_ln_act_bwd_v(float* __restrict__ dout, long ldd, const float* __restrict__ z, 
         } else {
           dy = *dyp;
         }
+        float4 zz = *reinterpret_cast<const float4*>(z + row * ldz + c);
+        float4 gm = *reinterpret_cast<const float4*>(gamma + c);
         if (act) {
-          float4 o = *reinterpret_cast<const float4*>(out + row * ldo + c);
+          float4 o;
+          if (out) {
+            o = *reinterpret_cast<const float4*>(out + row * ldo + c);
+          } else {   // recomputed with the forward kernel's expression: the same bits, one tensor less to read
+            const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+            o.x = elu_((zz.x - mean) * rstd * gm.x + bt.x); o.y = elu_((zz.y - mean) * rstd * gm.y + bt.y);
+            o.z = elu_((zz.z - mean) * rstd * gm.z + bt.z); o.w = elu_((zz.w - mean) * rstd * gm.w + bt.w);
+          }
           dy.x *= (o.x > 0.f ? 1.f : o.x + 1.f); dy.y *= (o.y > 0.f ? 1.f : o.y + 1.f);
           dy.z *= (o.z > 0.f ? 1.f : o.z + 1.f); dy.w *= (o.w > 0.f ? 1.f : o.w + 1.f);
         }
-        float4 zz = *reinterpret_cast<const float4*>(z + row * ldz + c);
-        float4 gm = *reinterpret_cast<const float4*>(gamma + c);
         xh[i].x = (zz.x - mean) * rstd; xh[i].y = (zz.y - mean) * rstd;
         xh[i].z = (zz.z - mean) * rstd; xh[i].w = (zz.w - mean) * rstd;
         g[i].x = dy.x * gm.x; g[i].y = dy.y * gm.y; g[i].z = dy.z * gm.z; g[i].w = dy.w * gm.w;
@@ -316,14 +331,19 @@ k_ln_act_bwd_v(float* __restrict__ dout, long ldd, const float* __restrict__ z, 
 __global__ void __launch_bounds__(256)
 k_ln_param_grad(const float* __restrict__ dout, long ldd, const float* __restrict__ z, long ldz,
                 const float* __restrict__ out, long ldo, const float* __restrict__ stats, long lds,
-                float* __restrict__ partials, int rows, int C, int act) {
+                float* __restrict__ partials, int rows, int C, int act,
+                const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float a = 0.f, b = 0.f;
   if (c < C) {
     for (long row = (long)blockIdx.y * 4 + rl; row < rows; row += (long)gridDim.y * 4) {
       float dy = dout[row * ldd + c];
-      if (act) { float o = out[row * ldo + c]; dy *= (o > 0.f ? 1.f : o + 1.f); }
+      if (act) {   // (out == NULL: recomputed as in k_ln_act_bwd)
+        const float o = out ? out[row * ldo + c]
+                            : elu_((z[row * ldz + c] - stats[row * lds]) * stats[row * lds + 1] * gamma[c] + beta[c]);
+        dy *= (o > 0.f ? 1.f : o + 1.f);
+      }
       float xh = (z[row * ldz + c] - stats[row * lds]) * stats[row * lds + 1];
       a += dy * xh;
       b += dy;
@@ -698,6 +718,7 @@ extern "C" int dd_ln_bwd_parts(int rows, int C) {
 
 extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
                              const float* out, long ldo, const float* stats, long lds, const float* gamma,
+                             const float* beta_ln,
                              float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
                              int accumulate, int rows, int C, int act, float* ws, size_t ws_bytes,
                              const float* slabs, int n_slabs, float beta_pre, void* stream) {
@@ -705,9 +726,12 @@ extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
   hipStream_t st = (hipStream_t)stream;
   const bool want = dgamma != nullptr;
   const float b = accumulate ? 1.f : 0.f;
+  DD_REQUIRE(!act || out != nullptr || beta_ln != nullptr,
+             "dd_ln_act_bwd: act without `out` needs the LayerNorm offset to recompute it");
+  if (!out) ldo = 4;
   const bool vec = C % 4 == 0 && C <= 1024 && ldd % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 &&
                    lddz % 4 == 0 && al16(dout) && al16(z) && al16(out) && al16(dz) && al16(gamma) &&
-                   al16(slabs);
+                   al16(beta_ln) && al16(slabs);
   // the deferred sum shares the workspace with the parameter-gradient partials: only
   // the parameter-free vector path consumes it in place
   if (n_slabs > 0 && (!vec || want)) {
@@ -730,7 +754,7 @@ extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
       size_t shmem = want ? (size_t)WPB * RPW * 3 * C * sizeof(float) : 0;
       if (want) DD_REQUIRE(ws && (size_t)blocks * 3 * C * sizeof(float) <= ws_bytes, "dd_ln_act_bwd: workspace too small");
       k_ln_act_bwd_v<LPR, V><<<blocks, 256, shmem, st>>>(
-          dout, ldd, z, ldz, out, ldo, stats, lds, gamma, dz, lddz, want ? ws : nullptr, rows, C, act, ps);
+          dout, ldd, z, ldz, out, ldo, stats, lds, gamma, beta_ln, dz, lddz, want ? ws : nullptr, rows, C, act, ps);
       DD_CHECK_LAUNCH("dd_ln_act_bwd");
       if (want) {
         k_col_reduce_n<<<dim3((C + 15) / 16, dbias_pre ? 3 : 2), 256, 0, st>>>(
@@ -746,14 +770,14 @@ extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
   int blocks = fused ? parts : row_blocks(rows, 1 << 20);
   int rc = dispatch_npl(C, [&](auto npl) {
     k_ln_act_bwd<decltype(npl)::value><<<blocks, 256, 0, st>>>(
-        dout, ldd, z, ldz, out, ldo, stats, lds, gamma, dz, lddz, fused ? ws : nullptr, rows, C, act);
+        dout, ldd, z, ldz, out, ldo, stats, lds, gamma, beta_ln, dz, lddz, fused ? ws : nullptr, rows, C, act);
     DD_CHECK_LAUNCH("dd_ln_act_bwd");
     return 0;
   });
   if (rc || !want) return rc;
   if (!fused) {
     dim3 grid((C + 63) / 64, parts);
-    k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, lds, ws, rows, C, act);
+    k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, lds, ws, rows, C, act, gamma, beta_ln);
     DD_CHECK_LAUNCH("dd_ln_act_bwd(param grad)");
   }
   // partials are [parts][2][C]: gamma rows at stride 2C from ws, beta rows from ws + C.
@@ -774,6 +798,7 @@ extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, lon
   long chunks = (rows + 63) / 64;
   const int parts = (int)(chunks > 256 ? 256 : (chunks < 1 ? 1 : chunks));
   DD_REQUIRE(ws && (size_t)parts * 2 * C * sizeof(float) <= ws_bytes, "dd_ln_param_grad: workspace too small");
+  DD_REQUIRE(!act || out != nullptr, "dd_ln_param_grad: act needs the stored activation");
   dim3 grid((C + 63) / 64, parts);
   k_ln_param_grad<<<grid, 256, 0, st>>>(dout, ldd, z, ldz, out, ldo, stats, lds, ws, rows, C, act);
   DD_CHECK_LAUNCH("dd_ln_param_grad");

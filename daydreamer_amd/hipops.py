@@ -40,7 +40,7 @@ _SIGS = {
     'dd_pool2': [c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
     'dd_repeat2': [c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
     'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_i, c_f, c_p, c_p],
-    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p, c_i, c_f, c_p],
+    'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p, c_i, c_f, c_p],
     'dd_ln_bwd_parts': [c_i, c_i],
     'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_col_sum': [c_p, c_l, c_p, c_f, c_l, c_i, c_p, c_z, c_p],
@@ -106,7 +106,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
-ABI_VERSION = 3   # include/daydreamer_hip.h DD_ABI_VERSION
+ABI_VERSION = 4   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -342,14 +342,16 @@ class HipOps:
         rows, C, int(act), *self._pre(pre, rows, C), self.stream), 'dd_ln_act_fwd')
 
   def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
-                 dbeta=None, accumulate=False, act=True, dbias_pre=None, pre=None):
+                 dbeta=None, accumulate=False, act=True, dbias_pre=None, pre=None, beta=None):
+    """beta (the LayerNorm offset): the activation's derivative is recomputed from z instead of
+    read from `out` - bit-identical, one tensor less through HBM."""
     rows, C = z.shape
     dp, ldd = _mat(dout)
     zp, ldz = _mat(z)
-    op, ldo = _mat(out)
+    op, ldo = _mat(out) if (beta is None or not act) else (0, 0)
     dzp, lddz = _mat(dz)
     self._check(self.lib.dd_ln_act_bwd(
-        dp, ldd, zp, ldz, op, ldo, *_mat(stats), gamma.data_ptr(), dzp,
+        dp, ldd, zp, ldz, op, ldo, *_mat(stats), gamma.data_ptr(), _ptr(beta), dzp,
         lddz, _ptr(dgamma), _ptr(dbeta), _ptr(dbias_pre), int(accumulate),
         rows, C, int(act),
         self.ws.data_ptr(), self.ws_bytes, *self._pre(pre, rows, C)[:3], self.stream),

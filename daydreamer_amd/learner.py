@@ -620,7 +620,7 @@ class Learner:
       dz = sel(A.dz)
       ops.ln_act_bwd(sel(A.dout), sel(A.z), sel(A.out), sel(A.stats), P.gamma,
                      dz, P.dgamma if params else None,
-                     P.dbeta if params else None, False, True)
+                     P.dbeta if params else None, False, True, beta=P.beta)
     else:
       dz = sel(A.dout)
       if params:
@@ -711,12 +711,13 @@ class Learner:
     ops.conv_same_bwd(do, m.p[f'{nm}b/kernel'], t2, 3, alpha=0.1)
     ops.ln_act_bwd(t2.view(-1, Dp), a['za'].view(-1, Dp), a['a2'].view(-1, Dp), a['st_b'],
                    m.p[f'{nm}b/norm/scale'], t1.view(-1, Dp), m.g[f'{nm}b/norm/scale'],
-                   m.g[f'{nm}b/norm/bias'], False, True, m.g[f'{nm}a/bias'])
+                   m.g[f'{nm}b/norm/bias'], False, True, m.g[f'{nm}a/bias'],
+                   beta=m.p[f'{nm}b/norm/bias'])
     ops.conv_same_wgrad(a['a1'], t1, m.g[f'{nm}a/kernel'], 3)
     ops.conv_same_bwd(t1, m.p[f'{nm}a/kernel'], t3, 3)
     ops.ln_act_bwd(t3.view(-1, C), x.view(-1, C), a['a1'].view(-1, C), a['st_a'],
                    m.p[f'{nm}a/norm/scale'], a['dx'].view(-1, C), m.g[f'{nm}a/norm/scale'],
-                   m.g[f'{nm}a/norm/bias'], False, True, None)
+                   m.g[f'{nm}a/norm/bias'], False, True, None, beta=m.p[f'{nm}a/norm/bias'])
     if blk.skip:
       ops.gemm(x.view(-1, C), do.view(-1, Dp), m.g[f'{nm}s/kernel'].view(C, Dp), ta=True)
       ops.gemm(do.view(-1, Dp), m.p[f'{nm}s/kernel'].view(C, Dp), a['dx'].view(-1, C),
@@ -854,7 +855,7 @@ class Learner:
                        a['out'].view(-1, C), a['stats'],
                        m.p[f'{cl.name}/norm/scale'], a['dz'].view(-1, C),
                        m.g[f'{cl.name}/norm/scale'], m.g[f'{cl.name}/norm/bias'],
-                       False, True, m.g[f'{cl.name}/bias'])
+                       False, True, m.g[f'{cl.name}/bias'], beta=m.p[f'{cl.name}/norm/bias'])
         big = b['image'] if i == 0 else self.enc_act[i - 1]['out']
         ops.conv_wgrad(big, a['dz'], m.g[f'{cl.name}/kernel'], cl.k,
                        1.0 / 255.0 if i == 0 else 1.0)
@@ -925,7 +926,7 @@ class Learner:
                          m.p[f'{cl.name}/norm/scale'], a['dz'].view(-1, C),
                          m.g[f'{cl.name}/norm/scale'],
                          m.g[f'{cl.name}/norm/bias'], False, True,
-                         m.g[f'{cl.name}/bias'])
+                         m.g[f'{cl.name}/bias'], beta=m.p[f'{cl.name}/norm/bias'])
         else:
           run(lambda o, a=a, C=C, cl=cl: self._image_bias_grad(o, a, C, cl))
         if i > 0:
@@ -1137,7 +1138,7 @@ class Learner:
       pre = ops.gemm(sel(self.a_obs_stats.dout), P['obs_stats'].W, sel(Ao.dout), tb=True,
                      defer=True)
       ops.ln_act_bwd(sel(Ao.dout), sel(Ao.z), sel(Ao.out), sel(Ao.stats),
-                     Po.gamma, sel(Ao.dz), None, None, False, True, pre=pre)
+                     Po.gamma, sel(Ao.dz), None, None, False, True, pre=pre, beta=Po.beta)
       ops.gemm(sel(Ao.dz), Po.W, ddeter, tb=True, beta=1.0)
       self.core_bwd(ddeter, sel(b['hprev']), self.a_img_in, b['z3'],
                     b['gstats'], sel, sel(b['dz3']), sel(b['dy3']),

@@ -26,8 +26,9 @@ extern "C" {
 
 /* ABI version.  1: rounds 1-2.  2 (round 3): dd_grad_norm gained `int mixed` in front of
  * `stream` and its opt_state grew from 3 to 5 doubles - a caller built against version 1 must
- * not call it.  3 (round 4): the version was bumped for that change; no signature changed since. */
-#define DD_ABI_VERSION 3
+ * not call it.  3 (round 4): the version was bumped for that change.  4: dd_ln_act_bwd gained
+ * `beta_ln` after `gamma` (out may then be NULL); dd_gemm_set_ws added. */
+#define DD_ABI_VERSION 4
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -133,9 +134,13 @@ int dd_ln_act_fwd(float* z, long ldz, const float* gamma, const float* beta,
                   void* stream);
 /* dz from dout; if dgamma != NULL also dgamma/dbeta and, if dbias_pre != NULL,
  * the column sum of dz (gradient of a bias added before the norm, as in Conv2D
- * nets.py:548-553); accumulate: += . */
+ * nets.py:548-553); accumulate: += .  The activation's derivative is taken from the stored
+ * activation `out`, or - out == NULL, beta_ln = the LayerNorm offset - from z, stats, gamma and
+ * beta_ln recomputed with dd_ln_act_fwd's own expression (bit-identical result, one tensor less to
+ * read: the pass is HBM-bound).  beta_ln may be NULL when out is given.  (ABI version 4.) */
 int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
                   const float* out, long ldo, const float* stats, long lds, const float* gamma,
+                  const float* beta_ln,
                   float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
                   int accumulate,
                   int rows, int C, int act, float* ws, size_t ws_bytes,

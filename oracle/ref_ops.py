@@ -246,8 +246,8 @@ class RefOps:
     return dout
 
   def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
-                 dbeta=None, accumulate=False, act=True, dbias_pre=None, pre=None):
-    assert pre is None
+                 dbeta=None, accumulate=False, act=True, dbias_pre=None, pre=None, beta=None):
+    assert pre is None   # (beta: the device recomputes `out` from z; the value is the same)
     mean, rstd = stats[:, :1], stats[:, 1:2]
     dy = self._ln_dy(dout, out, act)
     xh = (z - mean) * rstd

@@ -337,6 +337,23 @@ def test_ln_act(hip, ref, rows, C, act):
   res = both(hip, ref, fn2, [z, gamma, beta, out, stats, dout, dg2, db2], [6, 7])
   for (g, c), nm in zip(res, ['dgamma', 'dbeta']):
     close(g, c, rtol=1e-4, what=f'ln_param_grad {nm}')
+  # the activation recomputed from z (beta given: `out` is not read) == read from `out`, bit for bit
+  zg, gg, bg, dog = z.cuda(), gamma.cuda(), beta.cuda(), dout.cuda()
+  og, sg = torch.zeros(rows, C, device='cuda'), torch.zeros(rows, 2, device='cuda')
+  hip.ln_act_fwd(zg, gg, bg, og, sg, bool(act))
+  got = []
+  for kw in (dict(), dict(beta=bg)):
+    dzg, dgg, dbg, dpg = (torch.zeros(rows, C, device='cuda'), torch.zeros(C, device='cuda'),
+                          torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda'))
+    hip.ln_act_bwd(dog.clone(), zg, og if not kw else torch.full_like(og, float('nan')), sg, gg, dzg,
+                   dgg, dbg, False, bool(act), dpg, **kw)
+    dz0 = torch.zeros(rows, C, device='cuda')
+    hip.ln_act_bwd(dog.clone(), zg, og if not kw else torch.full_like(og, float('nan')), sg, gg, dz0,
+                   None, None, False, bool(act), **kw)
+    got.append((dzg, dgg, dbg, dpg, dz0))
+  torch.cuda.synchronize()
+  for a, b in zip(*got):
+    assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 def test_ln_gru_strided_rows(hip, ref):

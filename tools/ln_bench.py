@@ -23,5 +23,9 @@ for rows, C in ((2500 * 31 * 31, 64), (2500 * 30 * 30, 64), (2500 * 14 * 14, 128
   f = timeit(lambda: ops.ln_act_fwd(z, g, b, out, stats, True))
   bw = timeit(lambda: ops.ln_act_bwd(dout, z, out, stats, g, dz, dg, db, False, True, dbp))
   bn = timeit(lambda: ops.ln_act_bwd(dout, z, out, stats, g, dz, None, None, False, True))
+  # the activation recomputed from z instead of read from `out` (three tensors instead of four)
+  rw = timeit(lambda: ops.ln_act_bwd(dout, z, out, stats, g, dz, dg, db, False, True, dbp, beta=b))
+  rn = timeit(lambda: ops.ln_act_bwd(dout, z, out, stats, g, dz, None, None, False, True, beta=b))
   gb = rows * C * 4 / 1e9
-  print(f'rows {rows:8d} C {C:4d} | fwd {f:8.1f} us {2*gb/f*1e3:6.2f} TB/s | bwd+params {bw:8.1f} us {4*gb/bw*1e3:6.2f} TB/s | bwd {bn:8.1f} us {4*gb/bn*1e3:6.2f} TB/s', flush=True)
+  print(f'rows {rows:8d} C {C:4d} | fwd {f:8.1f} us {2*gb/f*1e3:6.2f} TB/s | bwd+params {bw:8.1f} us {4*gb/bw*1e3:6.2f} TB/s | bwd {bn:8.1f} us {4*gb/bn*1e3:6.2f} TB/s'
+        f' | recompute: bwd+params {rw:8.1f} us {3*gb/rw*1e3:6.2f} TB/s | bwd {rn:8.1f} us {3*gb/rn*1e3:6.2f} TB/s', flush=True)
