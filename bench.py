@@ -217,6 +217,12 @@ def main():
   backend = None
   if world > 1 or os.environ.get('DD_FORCE_DIST') == '1':
     import torch.distributed as dist
+    if 'RANK' not in os.environ:   # DD_FORCE_DIST=1 without a launcher: a one-rank group of our own
+      import socket
+      s_ = socket.socket()
+      s_.bind(('127.0.0.1', 0))
+      os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(s_.getsockname()[1]))
+      s_.close()
     # nccl == RCCL on ROCm; RCCL refuses two ranks on one device -> gloo on device tensors
     backend = os.environ.get('DD_DIST_BACKEND', 'gloo' if shared_devices else 'nccl')
     if backend == 'nccl':
