@@ -6,7 +6,7 @@ import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [
     ('off', dict(DD_WS='0')),
     ('k1024', dict(DD_WS='1', DD_WS_KMIN='1024', DD_WS_KMIN_TC='1024')),

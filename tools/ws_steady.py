@@ -2,7 +2,7 @@
 launches (the chip boosts for the first few ms of a busy period and then settles at its
 power-limited clock, so short timing loops measure the boost), per-launch HIP events."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from daydreamer_amd import hipops
 ops = hipops.HipOps('cuda:0')
