@@ -404,6 +404,21 @@ class Learner:
                       (self.P['gru'].W, i16(3 * (D + U) * 3 * D)), (self.P['img_in_s'].W, i16(3 * S * U))]
       self.scan_sync = torch.zeros(64 + 2 * 4 * 64, dtype=torch.int32, device=self.device)   # counter, error word, debug stamps
       self.scan_idx = torch.zeros((N + B + 1) * G, dtype=torch.int32, device=self.device)
+    # World-model forward as two batch halves, software-pipelined (default schedule): the
+    # latency-bound observe scan of one half (64 workgroups) runs on the main stream next to the
+    # GPU-filling encoder of the other half / decoder + heads of the first on the side stream.  The
+    # rows of a minibatch never interact in the forward pass (tfagent.py:105-116 shards the same
+    # axis), every half writes its own row range of the full-size buffers, so the backward pass and
+    # everything downstream is unchanged; noise is keyed by global row, so the draws are too.
+    self.split_fwd = (bool(self.cfg.get('hip', {}).get('split_fwd', True)) and self.fused_scan and
+                      self.ops2 is not None and self.side_stream is not None and B >= 2 and
+                      not s.enc_res and not s.dec_res)
+    if self.split_fwd:
+      bm = (B + 1) // 2
+      self.halves = [(0, bm), (bm, B)]
+      self.u_post_h = [z(T, b1 - b0, G) for b0, b1 in self.halves]
+      self.scan_idx_h = [torch.zeros(((b1 - b0) * T + (b1 - b0) + 1) * G, dtype=torch.int32, device=self.device)
+                         for b0, b1 in self.halves]
     # ---- heads on the posterior
     self.acts_wm = {k: self._head_acts(k, N) for k in ('reward', 'cont')}
     if s.dec_mlp_keys:
@@ -797,32 +812,37 @@ class Learner:
     ops.col_sum(dxin, m.g['dec/cnn/in/bias'])
     ops.gemm(dxin, m.p['dec/cnn/in/kernel'], dfeat, tb=True, beta=beta)
 
-  def encoder_fwd(self):
+  def encoder_fwd(self, rows=None):
+    """rows = (r0, r1): only those minibatch rows (images / vectors r0 .. r1 - 1 of the N)."""
     s, ops, b = self.spec, self.ops, self.b
     m = self.groups['model']
+    r0, r1 = rows if rows is not None else (0, self.N)
+    R = lambda t: t[r0:r1]
     x = b.get('image')
+    x = R(x) if x is not None else None
     if s.enc_res:
+      assert rows is None
       self.encoder_res_fwd()
     for i, (cl, a) in enumerate(zip(s.enc_convs, self.enc_act)):
-      ops.conv_down(x, m.p[f'{cl.name}/kernel'], m.p[f'{cl.name}/bias'], a['z'],
+      ops.conv_down(x, m.p[f'{cl.name}/kernel'], m.p[f'{cl.name}/bias'], R(a['z']),
                     cl.k, 1.0 / 255.0 if i == 0 else 1.0)
-      C = cl.c_small
-      ops.ln_act_fwd(a['z'].view(-1, C), m.p[f'{cl.name}/norm/scale'],
-                     m.p[f'{cl.name}/norm/bias'], a['out'].view(-1, C),
-                     a['stats'], True)
-      x = a['out']
+      C, px = cl.c_small, cl.h_small * cl.h_small
+      ops.ln_act_fwd(R(a['z']).view(-1, C), m.p[f'{cl.name}/norm/scale'],
+                     m.p[f'{cl.name}/norm/bias'], R(a['out']).view(-1, C),
+                     a['stats'][r0 * px:r1 * px], True)
+      x = R(a['out'])
     if s.enc_mlp_keys:
       layers = [self.P[f'enc/mlp/dense{i}'] for i in range(len(self.enc_mlp_act))]
-      self.mlp_fwd(layers, self.enc_mlp_act, b['vec_in'])
+      self.mlp_fwd(layers, self.enc_mlp_act, R(b['vec_in']), R)
     # hoisted embed part of obs_out: written straight into its pre-LN buffer
-    zo = self.a_obs_out.z
+    zo = R(self.a_obs_out.z)
     first = True
     if s.enc_convs or s.enc_res:
-      top = self.enc_res['emb'] if s.enc_res else self.enc_act[-1]['out'].view(self.N, -1)
+      top = self.enc_res['emb'] if s.enc_res else R(self.enc_act[-1]['out']).view(r1 - r0, -1)
       ops.gemm(top, self.P['obs_out_cnn'].W, zo)
       first = False
     if s.enc_mlp_keys:
-      ops.gemm(self.enc_mlp_act[-1].out, self.P['obs_out_mlp'].W, zo,
+      ops.gemm(R(self.enc_mlp_act[-1].out), self.P['obs_out_mlp'].W, zo,
                beta=0.0 if first else 1.0)
 
   def encoder_bwd(self):
@@ -865,11 +885,16 @@ class Learner:
 
   # ----------------------------------------------------------------- decoder
 
-  def decoder_fwd(self, feat):
+  def decoder_fwd(self, feat, rows=None):
+    """rows = (r0, r1): only those minibatch rows (`feat` is the full [N, F] matrix either way)."""
     s, ops, b = self.spec, self.ops, self.b
     m = self.groups['model']
-    N = self.N
+    r0, r1 = rows if rows is not None else (0, self.N)
+    R = lambda t: t[r0:r1]
+    n = r1 - r0
+    feat = R(feat)
     if s.dec_res:
+      assert rows is None
       self.decoder_res_fwd(feat)
     elif s.dec_convs:
       c0, a0 = s.dec_convs[0], self.dec_act[0]
@@ -877,32 +902,32 @@ class Learner:
       bt = b['bias_tiled'].view(kk, c0.c_big)
       ops.copy2d(m.p[f'{c0.name}/bias'].view(1, -1).expand(kk, c0.c_big), bt)
       ops.gemm(feat, m.p[f'{c0.name}/kernel'].view(kk * c0.c_big, self.F),
-               a0['z'].view(N, -1), tb=True, bias=b['bias_tiled'])
+               R(a0['z']).view(n, -1), tb=True, bias=b['bias_tiled'])
       x = None
       for i, (cl, a) in enumerate(zip(s.dec_convs, self.dec_act)):
         if i > 0:
           ops.conv_up(x, m.p[f'{cl.name}/kernel'], m.p[f'{cl.name}/bias'],
-                      a['z'], cl.k)
+                      R(a['z']), cl.k)
         if cl.norm:
-          C = cl.c_big
-          ops.ln_act_fwd(a['z'].view(-1, C), m.p[f'{cl.name}/norm/scale'],
-                         m.p[f'{cl.name}/norm/bias'], a['out'].view(-1, C),
-                         a['stats'], True)
-          x = a['out']
+          C, px = cl.c_big, cl.h_big * cl.h_big
+          ops.ln_act_fwd(R(a['z']).view(-1, C), m.p[f'{cl.name}/norm/scale'],
+                         m.p[f'{cl.name}/norm/bias'], R(a['out']).view(-1, C),
+                         a['stats'][r0 * px:r1 * px], True)
+          x = R(a['out'])
     if s.dec_convs:
       last = self.dec_act[-1]
       c0 = 0
       for key, shp in s.dec_cnn_keys.items():
         scale = self.cfg['loss_scales'].get(key, 1.0)
-        ops.image_loss(last['z'], b['image'], b['loss_image'][key], last['dz'],
+        ops.image_loss(R(last['z']), R(b['image']), R(b['loss_image'][key]), R(last['dz']),
                        scale / self.Ng, c0, c0 + shp[2])
         c0 += shp[2]
     if s.dec_mlp_keys:
-      outs = self.head_fwd('dec_mlp', self.acts_wm['dec_mlp'], feat)
+      outs = self.head_fwd('dec_mlp', self.acts_wm['dec_mlp'], feat, R if rows is not None else None)
       for (k, v), o, A in zip(s.dec_mlp_keys.items(), outs,
                               self.acts_wm['dec_mlp'][1]):
         scale = self.cfg['loss_scales'].get(k, 1.0)
-        ops.mse_loss(o, b['vec_tgt'][k], b['loss_vec'][k], A.dout,
+        ops.mse_loss(o, R(b['vec_tgt'][k]), R(b['loss_vec'][k]), R(A.dout),
                      scale / self.Ng)
 
   def decoder_bwd(self, feat, dfeat, beta, defer=None):
@@ -1032,22 +1057,35 @@ class Learner:
     self.ops.copy2d(b['init_deter'].expand(self.B, D), b['carry'][:, :D])
     self.ops.copy2d(b['init_stoch'].expand(self.B, self.S), b['carry'][:, D:])
 
-  def observe_scan_fused(self, use_carry):
+  def observe_scan_fused(self, use_carry, half=None):
     """The T obs_steps as one persistent launch (dd_observe_scan_fwd): same buffers, same
-    values up to the summation order of the small contractions."""
+    values up to the summation order of the small contractions.  half: index into self.halves -
+    the scan of that batch range only (its rows of every batch-major buffer, its own noise tensor
+    and draw-index workspace)."""
     ops, b, P = self.ops, self.b, self.P
-    for W, planes, kp in self.scan_w[1:]:   # the weights changed in the last optimizer step (P1 gathers img_in rows in fp32: no planes)
-      ops.scan_wprep(W, planes, kp)
+    if half in (None, 0):
+      for W, planes, kp in self.scan_w[1:]:   # the weights changed in the last optimizer step (P1 gathers img_in rows in fp32: no planes)
+        ops.scan_wprep(W, planes, kp)
     g = P['gru_h']
+    T = self.T
+    if half is None:
+      B, rows, u_post, idx = self.B, (lambda t: t), b['u_post'], self.scan_idx
+      carry = b['carry']
+    else:
+      b0, b1 = self.halves[half]
+      B, u_post, idx = b1 - b0, self.u_post_h[half], self.scan_idx_h[half]
+      rows = lambda t: t[b0 * T:b1 * T]
+      carry = b['carry'][b0:b1]
     ops.observe_scan_fwd(
-        self.B, self.T, self.D, self.U, self.G, self.C, self.A, use_carry, self.unimix,
-        b['first'], b['carry'] if use_carry else None, b['init_deter'], b['init_stoch'],
-        b['u_post'], [w[1] for w in self.scan_w],
+        B, T, self.D, self.U, self.G, self.C, self.A, use_carry, self.unimix,
+        rows(b['first']), carry if use_carry else None, b['init_deter'], b['init_stoch'],
+        u_post, [w[1] for w in self.scan_w],
         [P['img_in'].gamma, P['img_in'].beta, g.gamma, g.beta, P['obs_out_h'].gamma,
          P['obs_out_h'].beta, P['obs_stats'].bias],
-        [b['xin'], self.a_img_in.z, self.a_img_in.stats, b['gin'], b['z3'], b['gstats'], b['post'],
-         self.a_obs_out.z, self.a_obs_out.out, self.a_obs_out.stats, self.a_obs_stats.z,
-         b['post_logit']], P['img_in'].W, self.scan_idx, self.scan_sync)
+        [rows(t) for t in (b['xin'], self.a_img_in.z, self.a_img_in.stats, b['gin'], b['z3'], b['gstats'],
+                           b['post'], self.a_obs_out.z, self.a_obs_out.out, self.a_obs_out.stats,
+                           self.a_obs_stats.z, b['post_logit'])],
+        P['img_in'].W, idx, self.scan_sync)
 
   def observe_scan_bwd_fused(self):
     """The data gradient of the T obs_steps as one persistent launch (dd_observe_scan_bwd): same
@@ -1070,14 +1108,17 @@ class Learner:
         [b['dfeat'], Aq.dout, Ao.dout, Ao.dz, b['dz3'], b['dy3'], b['dgin'], Ai.dz, b['dxin_s']],
         self.scan_sync)
 
-  def observe_fwd(self, use_carry=True):
+  def observe_fwd(self, use_carry=True, prior=True):
+    """prior=False: with the fused scan the caller computes the prior of the observe steps
+    (phase_wm_fwd's post_fwd); the launch sequence always computes it inside its time loop."""
     ops, b = self.ops, self.b
     B, T, D, S, F = self.B, self.T, self.D, self.S, self.F
     if self.fused_scan:
       self.observe_scan_fused(use_carry)
-      xs = self.prior_fwd(b['post'][:, :D], self.a_img_out, self.a_img_stats)
-      ops.stats_fwd(xs, b['u_prior'].view(self.N, self.G), b['prior_logit'],
-                    b['prior_stoch'], self.G, self.C, self.unimix, 0)
+      if prior:
+        xs = self.prior_fwd(b['post'][:, :D], self.a_img_out, self.a_img_stats)
+        ops.stats_fwd(xs, b['u_prior'].view(self.N, self.G), b['prior_logit'],
+                      b['prior_stoch'], self.G, self.C, self.unimix, 0)
       return
     bt = lambda t_: (lambda buf: buf.view(B, T, -1)[:, t_])
     first = b['first'].view(B, T)
@@ -1228,6 +1269,9 @@ class Learner:
     r0 = self.rank * B
     ops.philox(b['u_prior'], B, T, G, T, r0 * T, self.noise_seed, self.step_ctr, SITE_OBS_PRIOR, 0)
     ops.philox(b['u_post'], T, B, G, self.Bg, r0, self.noise_seed, self.step_ctr, SITE_OBS_POST, 0)
+    if getattr(self, 'split_fwd', False):   # the same uniforms (keyed by global row) in per-half tensors
+      for (b0, b1), u in zip(self.halves, self.u_post_h):
+        ops.philox(u, T, b1 - b0, G, self.Bg, r0 + b0, self.noise_seed, self.step_ctr, SITE_OBS_POST, 0)
 
   def phase_prep_b(self):
     """The behaviour phase's own step number and sampling noise (same Philox keys as
@@ -1246,20 +1290,55 @@ class Learner:
   def phase_wm_fwd(self, use_carry=True, training=True):
     ops, b, cfg = self.ops, self.b, self.cfg
     N = self.N
-    self.encoder_fwd()
-    self.initial_fwd()
-    self.observe_fwd(use_carry)
     feat = b['post']
-    self.decoder_fwd(feat)
     ls = cfg['loss_scales']
-    (rew,) = self.head_fwd('reward', self.acts_wm['reward'], feat)
-    ops.scalar_loss(rew.view(-1), b['reward'], b['loss_reward'],
-                    self.acts_wm['reward'][1][0].dout.view(-1),
+    def post_fwd(rows=None):
+      """Everything of the forward pass that consumes the posterior of a row range: prior of the
+      observe steps, decoder, reward / cont heads and their losses (uses self.ops: the caller's
+      launch context)."""
+      o = self.ops
+      R = (lambda t: t[rows[0]:rows[1]]) if rows is not None else (lambda t: t)
+      sel = R if rows is not None else None
+      if self.fused_scan:   # (the launch sequence computes the prior inside its time loop)
+        xs = self.prior_fwd(R(feat)[:, :self.D], self.a_img_out, self.a_img_stats, sel)
+        o.stats_fwd(xs, R(b['u_prior'].view(N, self.G)), R(b['prior_logit']),
+                    R(b['prior_stoch']), self.G, self.C, self.unimix, 0)
+      self.decoder_fwd(feat, rows)
+      (rew,) = self.head_fwd('reward', self.acts_wm['reward'], R(feat), sel)
+      o.scalar_loss(rew.view(-1), R(b['reward'].view(-1)), R(b['loss_reward']),
+                    R(self.acts_wm['reward'][1][0].dout).view(-1),
                     ls.get('reward', 1.0) / self.Ng, 0)
-    (cont,) = self.head_fwd('cont', self.acts_wm['cont'], feat)
-    ops.scalar_loss(cont.view(-1), b['cont'], b['loss_cont'],
-                    self.acts_wm['cont'][1][0].dout.view(-1),
+      (cont,) = self.head_fwd('cont', self.acts_wm['cont'], R(feat), sel)
+      o.scalar_loss(cont.view(-1), R(b['cont'].view(-1)), R(b['loss_cont']),
+                    R(self.acts_wm['cont'][1][0].dout).view(-1),
                     ls.get('cont', 1.0) / self.Ng, 1)
+    if self.split_fwd and self.plan is not None:
+      T = self.T
+      (a0, a1), (c0, c1) = self.halves
+      main = self.ops
+      def on_side(fn):   # fn on the side stream with the side launch context, after all work issued so far
+        with self.fork():
+          self.ops = self.ops2
+          try:
+            fn()
+          finally:
+            self.ops = main
+      self.encoder_fwd((a0 * T, a1 * T))
+      on_side(lambda: self.encoder_fwd((c0 * T, c1 * T)))       # || scan of the first half
+      self.initial_fwd()
+      self.observe_scan_fused(use_carry, 0)
+      self.join()
+      on_side(lambda: post_fwd((a0 * T, a1 * T)))               # || scan of the second half
+      self.observe_scan_fused(use_carry, 1)
+      self.join()
+      post_fwd((c0 * T, c1 * T))
+    else:
+      self.encoder_fwd()
+      self.initial_fwd()
+      self.observe_fwd(use_carry, prior=False)
+      post_fwd()
+    rew = self.acts_wm['reward'][1][0].z
+    cont = self.acts_wm['cont'][1][0].z
     ops.kl_fwd(b['post_logit'], b['prior_logit'], b['kl'], b['ent_post'],
                b['ent_prior'], self.G, self.C)
     k = self.stat('kl_loss', b['kl'])
