@@ -404,13 +404,18 @@ class Learner:
                       (self.P['gru'].W, i16(3 * (D + U) * 3 * D)), (self.P['img_in_s'].W, i16(3 * S * U))]
       self.scan_sync = torch.zeros(64 + 2 * 4 * 64, dtype=torch.int32, device=self.device)   # counter, error word, debug stamps
       self.scan_idx = torch.zeros((N + B + 1) * G, dtype=torch.int32, device=self.device)
-    # World-model forward as two batch halves, software-pipelined (default schedule): the
-    # latency-bound observe scan of one half (64 workgroups) runs on the main stream next to the
-    # GPU-filling encoder of the other half / decoder + heads of the first on the side stream.  The
-    # rows of a minibatch never interact in the forward pass (tfagent.py:105-116 shards the same
-    # axis), every half writes its own row range of the full-size buffers, so the backward pass and
-    # everything downstream is unchanged; noise is keyed by global row, so the draws are too.
-    self.split_fwd = (bool(self.cfg.get('hip', {}).get('split_fwd', True)) and self.fused_scan and
+    # World-model forward as two batch halves, software-pipelined (opt-in, hip.split_fwd /
+    # DD_SPLIT_FWD=1): the latency-bound observe scan of one half (64 workgroups) on the main
+    # stream next to the GPU-filling encoder of the other half / decoder + heads of the first on
+    # the side stream.  The rows of a minibatch never interact in the forward pass (tfagent.py:
+    # 105-116 shards the same axis), every half writes its own row range of the full-size buffers,
+    # so the backward pass is unchanged; noise is keyed by global row, so the draws are too (the
+    # whole parity suite passes with it on).  MEASURED SLOWER (round 4, same box, alternating
+    # runs: 36.26 / 36.09 ms with, 35.84 / 35.76 ms without): the scan's 64 persistent workgroups
+    # need > 256 registers per lane and are only placed as the other stream's convolution grids
+    # drain, so the two halves of the pipeline barely overlap while the half-size convolutions
+    # are less efficient.  Off by default.
+    self.split_fwd = (bool(int(os.environ.get('DD_SPLIT_FWD', self.cfg.get('hip', {}).get('split_fwd', False)))) and self.fused_scan and
                       self.ops2 is not None and self.side_stream is not None and B >= 2 and
                       not s.enc_res and not s.dec_res)
     if self.split_fwd:
@@ -1312,7 +1317,7 @@ class Learner:
       o.scalar_loss(cont.view(-1), R(b['cont'].view(-1)), R(b['loss_cont']),
                     R(self.acts_wm['cont'][1][0].dout).view(-1),
                     ls.get('cont', 1.0) / self.Ng, 1)
-    if self.split_fwd and self.plan is not None:
+    if self.split_fwd and self.ops2 is not None:
       T = self.T
       (a0, a1), (c0, c1) = self.halves
       main = self.ops

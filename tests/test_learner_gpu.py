@@ -92,6 +92,19 @@ def test_e2e_side_stream(hip):
   run(hip, cfg, 2, kw_side=side, image=64, vector=5, action=3, terminals=0.1)
 
 
+def test_e2e_split_forward(hip):
+  """hip.split_fwd (opt-in): the world-model forward as two batch halves - the fused observe scan
+  of one half next to the encoder / decoder of the other on the side stream, per-half noise
+  tensors keyed by global row - against the float64 oracle at the same parity bar (odd batch:
+  halves of 3 and 2 rows), image + vector keys."""
+  from daydreamer_amd import hipops
+  side = hipops.HipOps('cuda:0', ws_bytes=256 << 20)
+  cfg = helpers.make_config(('a1_vision',), batch_size=5, replay_chunk=6, imag_horizon=3)
+  cfg = cfg.update({'hip.split_fwd': True})
+  L = run(hip, cfg, 2, kw_side=side, image=64, vector=16, action=16, terminals=0.1)
+  assert L.split_fwd and L.halves == [(0, 3), (3, 5)]
+
+
 def test_e2e_a1_proprio(hip):
   """BASELINE configs[0]: a1 block, proprio only, batch 16 x seq 16, horizon 5."""
   cfg = helpers.make_config(('a1',), batch_size=16, replay_chunk=16, imag_horizon=5)
