@@ -185,6 +185,7 @@ def main():
   ap.add_argument('--config', default='a1_vision')
   ap.add_argument('--batch', type=int, default=0, help='override the config batch size')
   ap.add_argument('--length', type=int, default=0, help='override the config sequence length')
+  ap.add_argument('--horizon', type=int, default=0, help='override the config imagination horizon')
   ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cnn', choices=('simple', 'resnet'), default='simple',
@@ -243,6 +244,8 @@ def main():
     cfg = cfg.update({'batch_size': args.batch})
   if args.length:
     cfg = cfg.update({'replay_chunk': args.length})
+  if args.horizon:
+    cfg = cfg.update({'imag_horizon': args.horizon})
   plain = config_mod.to_plain(cfg)
   T, H = plain['replay_chunk'], plain['imag_horizon']
   if args.scaling == 'strong':
@@ -393,6 +396,8 @@ def main():
         tail += ['--batch', str(args.batch)]
       if args.length:
         tail += ['--length', str(args.length)]
+      if args.horizon:
+        tail += ['--horizon', str(args.horizon)]
       torch.cuda.synchronize()
       pmc = pmc_live(tail)
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')

@@ -30,5 +30,5 @@ bash tools/pmc_bench.sh > gpurun_out/${tag}_pmc_hbm_traffic.txt 2>&1
 (timeout 120 python tools/graph_stress.py --iters 45 > gpurun_out/${tag}_graph_stress.log 2>&1)
 (timeout 300 python tools/dp_preflight.py --gpus 1 2>&1 | grep -a preflight > gpurun_out/${tag}_dp_preflight_1rank_rccl.log)
 # the other BASELINE configs at their per-GPU shard (configs[0] 16, [2] 50 / 2 GPUs, [3] 64 / 4, [4] 256 / 8)
-(for c in "a1 --batch 16 --length 16" "xarm --batch 25 --length 50" "ur5_multicam --batch 16 --length 64" "a1_scaled --batch 32 --length 64"; do timeout 400 python bench.py --config $c --no-cpu-baseline --pmc off 2>/dev/null | grep -a -o '{"metric.*'; done > gpurun_out/${tag}_bench_other_configs.jsonl)
+(for c in "a1 --batch 16 --length 16 --horizon 5" "xarm --batch 25 --length 50" "ur5_multicam --batch 16 --length 64" "a1_scaled --batch 32 --length 64"; do timeout 400 python bench.py --config $c --no-cpu-baseline --pmc off 2>/dev/null | grep -a -o '{"metric.*'; done > gpurun_out/${tag}_bench_other_configs.jsonl)
 tail -3 gpurun_out/${tag}_pytest_gpu.log; cat gpurun_out/${tag}_smoke.log | tail -2; head -c 600 gpurun_out/${tag}_bench.json

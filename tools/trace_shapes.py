@@ -4,8 +4,13 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import torch
 import helpers
 from daydreamer_amd import learner as LM, hipops
-cfg = helpers.make_config(('a1_vision',))
-plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, image=64, vector=16, action=16, terminals=0.0, smooth=False)
+# usage: trace_shapes.py [top_n] [config batch length]   (default: a1_vision at its own batch / length)
+if len(sys.argv) > 2:
+  name, B, T = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+  plain, sp, shapes, params, data = helpers.make_named_problem(name, B, T, terminals=0.0)
+else:
+  cfg = helpers.make_config(('a1_vision',))
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, image=64, vector=16, action=16, terminals=0.0, smooth=False)
 ops = hipops.HipOps('cuda:0')
 L = LM.Learner(sp, ops, 'cuda:0', B, T, params=params)
 L.upload(data)
