@@ -371,21 +371,56 @@ k_col_reduce_n(const float* __restrict__ partials, int P, long stride, int W,
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int w = blockIdx.x * 16 + cl, j = blockIdx.y;
   float* out = j == 0 ? o0 : (j == 1 ? o1 : o2);
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (w < W) {
     const float* q = partials + (long)j * W + w;
     int p = pl;
-    for (; p + 16 < P; p += 32) { s0 += q[(long)p * stride]; s1 += q[(long)(p + 16) * stride]; }
-    if (p < P) s0 += q[(long)p * stride];
+    for (; p + 48 < P; p += 64) {   // four partial rows per lane in flight
+      s0 += q[(long)p * stride]; s1 += q[(long)(p + 16) * stride];
+      s2 += q[(long)(p + 32) * stride]; s3 += q[(long)(p + 48) * stride];
+    }
+    for (; p < P; p += 16) s0 += q[(long)p * stride];
   }
   __shared__ float sh[16][17];
-  sh[pl][cl] = s0 + s1;
+  sh[pl][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (pl == 0 && w < W) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += sh[i][cl];
     out[w] = (beta != 0.f ? beta * out[w] : 0.f) + t;
+  }
+}
+
+// First level of a two-level column reduce: block (16 columns x 16 partial lanes), grid
+// (ceil(W/16), nout, chunks): inter[(z * nout + j) * W + w] = sum of the partial rows
+// [z * rpc, (z + 1) * rpc) of output j.  With thousands of partial rows (the big convolutional
+// LayerNorms use 8192 blocks) the one-level pass is a 12-block launch whose threads walk 512 rows
+// each: 117 us; two levels are two launches of a few us.
+__global__ void __launch_bounds__(256)
+k_col_reduce_chunks(const float* __restrict__ partials, int P, long stride, int W, int rpc,
+                    float* __restrict__ inter) {
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int w = blockIdx.x * 16 + cl, j = blockIdx.y, nout = gridDim.y;
+  const int p0 = blockIdx.z * rpc, p1 = min(P, p0 + rpc);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (w < W) {
+    const float* q = partials + (long)j * W + w;
+    int p = p0 + pl;
+    for (; p + 48 < p1; p += 64) {   // four rows per lane in flight
+      s[0] += q[(long)p * stride]; s[1] += q[(long)(p + 16) * stride];
+      s[2] += q[(long)(p + 32) * stride]; s[3] += q[(long)(p + 48) * stride];
+    }
+    for (; p < p1; p += 16) s[0] += q[(long)p * stride];
+  }
+  __shared__ float sh[16][17];
+  sh[pl][cl] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (pl == 0 && w < W) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][cl];
+    inter[((long)blockIdx.z * nout + j) * W + w] = t;
   }
 }
 
@@ -757,8 +792,21 @@ extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
           dout, ldd, z, ldz, out, ldo, stats, lds, gamma, beta_ln, dz, lddz, want ? ws : nullptr, rows, C, act, ps);
       DD_CHECK_LAUNCH("dd_ln_act_bwd");
       if (want) {
-        k_col_reduce_n<<<dim3((C + 15) / 16, dbias_pre ? 3 : 2), 256, 0, st>>>(
-            ws, blocks, 3L * C, C, dgamma, dbeta, dbias_pre, b);
+        const int nout = dbias_pre ? 3 : 2;
+        // (many partial rows: two levels, chunks of 128 rows; the intermediate rows follow the
+        // partials in the workspace)
+        const int rpc = 128, chunks = (blocks + rpc - 1) / rpc;
+        const size_t need = ((size_t)blocks * 3 + (size_t)chunks * 3) * C * sizeof(float);
+        if (blocks >= 1024 && need <= ws_bytes) {
+          float* inter = ws + (size_t)blocks * 3 * C;
+          k_col_reduce_chunks<<<dim3((C + 15) / 16, nout, chunks), 256, 0, st>>>(ws, blocks, 3L * C, C, rpc, inter);
+          DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce level 1)");
+          k_col_reduce_n<<<dim3((C + 15) / 16, nout), 256, 0, st>>>(
+              inter, chunks, (long)nout * C, C, dgamma, dbeta, dbias_pre, b);
+        } else {
+          k_col_reduce_n<<<dim3((C + 15) / 16, nout), 256, 0, st>>>(
+              ws, blocks, 3L * C, C, dgamma, dbeta, dbias_pre, b);
+        }
         DD_CHECK_LAUNCH("dd_ln_act_bwd(reduce)");
       }
       return 0;
