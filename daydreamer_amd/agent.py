@@ -406,6 +406,7 @@ class PolicyState:
 class Agent:
 
   configs = config_mod.load_configs()
+  _warned_host_shard = False
 
   def __init__(self, obs_space, act_space, step, config, _ops=None,
                _device=None, _dtype=torch.float32):
@@ -535,7 +536,11 @@ class Agent:
   def dataset(self, generator_fn):
     """Iterable of [B,T,...] minibatches (reference agent.py:108-121).  A
     `DeviceReplay.dataset` generator is recognised and replaced by minibatches
-    gathered in HBM (no host staging); any other generator is zipped on the host."""
+    gathered in HBM (no host staging); any other generator is zipped on the host.
+    Data parallel with `hip.shard_dataset` (default): this rank's B / world rows only.  A
+    `DeviceReplay` is reseeded by rank here; a HOST generator is the caller's: every rank must
+    draw different rows (seed the sampler by rank, as the reference's per-process replays do) -
+    identical generators would hand every rank the same rows (a warning is printed once)."""
     owner = getattr(generator_fn, '__self__', None)
     B = self.cfg['batch_size']
     sharded = self.world > 1 and self._shard_dataset
@@ -549,6 +554,11 @@ class Agent:
         owner.reseed(self.rank)
       it = owner.batches(B)
       return (ShardedBatch(b) for b in it) if sharded else it
+    if sharded and not Agent._warned_host_shard:
+      Agent._warned_host_shard = True
+      print(f'[daydreamer_amd] rank {self.rank}/{self.world}: rank-sharded dataset over a host generator - '
+            'make sure every rank samples with its own seed (DeviceReplay(seed=rank) or a rank-seeded sampler)',
+            flush=True)
     batcher = Batcher(generator_fn, B, device=self.device, sharded=sharded)
     weakref.finalize(self, batcher.close)   # the dataset belongs to this agent
     return batcher
