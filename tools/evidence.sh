@@ -9,6 +9,10 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rA 2>&1 | tail -260 > gpurun_out/${tag}_pytest_gpu.log)
 (timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1)
 (timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err)
+# multi-rank plumbing on the one GPU (ranks share the device, gloo): not a measurement
+(timeout 250 python bench.py --gpus 2 --steps 3 --warmup 3 --no-cpu-baseline --pmc off 2>/dev/null | grep -a -o '{"metric.*' > gpurun_out/${tag}_bench_2ranks_shared_gpu.json)
+(timeout 250 python bench.py --gpus 2 --config xarm --batch 50 --length 50 --scaling strong --steps 3 --warmup 3 --no-cpu-baseline --pmc off 2>/dev/null | grep -a -o '{"metric.*' > gpurun_out/${tag}_bench_dp2_xarm_strong_shared_gpu.json)
+(timeout 500 python bench.py --gpus 8 --config a1_scaled --batch 256 --length 64 --scaling strong --steps 2 --warmup 3 --no-cpu-baseline --pmc off 2>/dev/null | grep -a -o '{"metric.*' > gpurun_out/${tag}_bench_dp8_a1_scaled_strong_shared_gpu.json)
 cd /tmp && export TMPDIR=/tmp
 K=10; W=3
 for mode in 0 1; do
