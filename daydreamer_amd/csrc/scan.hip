@@ -26,7 +26,9 @@
 // statistics, hprev, masked stoch, z3, deter, zo, xo, xq, post_logit, stoch) is written exactly
 // as the unfused path writes it.
 //
-// Grid barrier: one monotonic counter, arrive = release fence + relaxed agent-scope add, wait =
+// Barrier: one monotonic counter per 16-row block (its 16 workgroups are the only producers a
+// phase consumes; forward scan 1.55 -> 1.44 ms, reverse 1.68 -> 1.61 ms against one grid-wide counter,
+// profiles/r04_fused_scan_times.txt), arrive = release fence + relaxed agent-scope add, wait =
 // relaxed agent-scope polling by one lane + acquire fence (MI355X_MICROARCH.md, valid forms);
 // every spin is bounded - on a timeout bit 0 of the error word is set and the kernel runs on
 // (garbage out, never a hang).  The error word is STICKY: launches reset the counter only, the
@@ -111,7 +113,7 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 // `prefetch` runs between the arrival and the wait: loads that do not depend on the other
 // workgroups' results (the next phase's weight planes) travel while the barrier completes.
 template <class PF>
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, PF prefetch) {
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned* err, unsigned target, PF prefetch) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -124,7 +126,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, PF 
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > SPIN_LIMIT) {
-        __hip_atomic_fetch_or(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
     }
@@ -132,8 +134,8 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, PF 
   }
   __syncthreads();
 }
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
-  grid_barrier(ctr, target, [] {});
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned* err, unsigned target) {
+  grid_barrier(ctr, err, target, [] {});
 }
 
 // Activations of the fused scan: every workgroup of a row block rebuilds the phase's whole
@@ -257,6 +259,12 @@ __device__ __forceinline__ void tiles_gemm_stream(const bf16x8 (&af)[KP / 128][3
 }
 
 constexpr int NWG = 64, NSTR = NWG / 4;   // 4 row blocks of 16 batch rows x 16 column strides
+// Barrier scope: a phase only consumes what the 16 workgroups of its own row block produced, so each
+// row block has its own counter (sync2[576 + 128 m], 128 words apart behind the debug stamps; the
+// error word stays at sync2[1]).  Flag bit 7 of use_carry / flags selects the grid-wide counter
+// sync2[0] instead (A/B measurements, tools/scan_time.py).
+#define RB_CTR(mblk) (bar_rb ? 576 + 128 * (mblk) : 0)
+#define RB_N (bar_rb ? NSTR : NWG)
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 constexpr int cmax_(int a, int b) { return a > b ? a : b; }
 
@@ -327,9 +335,10 @@ k_observe_scan_fwd(ScanArgs a) {
   const bool alive = mblk * 16 + (lane & 15) < a.B;
   const int kq = (lane >> 4) * 8 + wave * 32;                         // this lane's k offset in a k-step
   const long pl2 = (long)3 * D * (D + U), pl3 = (long)U * D, pl4 = (long)S * U;
+  const bool bar_rb = !(a.use_carry & 128);
   unsigned gen = 0;
   if (a.use_carry & 2) {   // measurement aid: the barriers alone (4 per step), no work
-    for (int i = 0; i < 4 * T; ++i) grid_barrier(a.ctr, ++gen * NWG);
+    for (int i = 0; i < 4 * T; ++i) grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N);
     return;
   }
   // P1's dense action columns of W_img_in for this thread's output columns: step-invariant
@@ -422,7 +431,7 @@ k_observe_scan_fwd(ScanArgs a) {
     constexpr bool ALL2 = T2 * NIT2 <= 12;
     constexpr int NITC2 = NIT2 % 4 == 0 ? 4 : NIT2;
     uint4 bq2[ALL2 ? T2 : 2][ALL2 ? NIT2 : NITC2][3];
-    grid_barrier(a.ctr, ++gen * NWG, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
       if constexpr (ALL2) {
 #pragma unroll
         for (int j = 0; j < T2; ++j) load_planes<NIT2>(bq2[j], a.wt2, pl2, D + U, (nstr + NSTR * j) * 16);
@@ -496,7 +505,7 @@ k_observe_scan_fwd(ScanArgs a) {
     }
     TS(6); TSW(1);
     uint4 bq3[T3][NIT3][3];
-    grid_barrier(a.ctr, ++gen * NWG, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
 #pragma unroll
       for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.wt3, pl3, D, (nstr + NSTR * j) * 16);
     });
@@ -572,7 +581,7 @@ k_observe_scan_fwd(ScanArgs a) {
     constexpr bool ALL4 = T4 * NIT4 <= 12;
     constexpr int NITC4 = NIT4 % 4 == 0 ? 4 : NIT4;
     uint4 bq4[ALL4 ? T4 : 2][ALL4 ? NIT4 : NITC4][3];
-    grid_barrier(a.ctr, ++gen * NWG, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
       if constexpr (ALL4) {
 #pragma unroll
         for (int j = 0; j < T4; ++j)
@@ -678,7 +687,7 @@ k_observe_scan_fwd(ScanArgs a) {
       }
     }
     TS(17); TSW(3);
-    grid_barrier(a.ctr, ++gen * NWG);
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N);
     TS(18);
   }
 }
@@ -818,6 +827,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
   const int kq = (lane >> 4) * 8 + wave * 32;
   const long pl1 = (long)U * S, pl2 = (long)D * U, pl3 = (long)(D + U) * 3 * D, pl4 = (long)S * U;
   const float um = 1.f - a.unimix;
+  const bool bar_rb = !(a.flags & 128);
   unsigned gen = 0;
   __syncthreads();
   uint4 bq1[1][NIT1][3];
@@ -840,7 +850,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
     }
     TSB(1);
     uint4 bq2[1][NIT2][3];
-    grid_barrier(a.ctr, ++gen * NWG, [&] { load_planes<NIT2>(bq2[0], a.w2, pl2, U, nstr * 16); });
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] { load_planes<NIT2>(bq2[0], a.w2, pl2, U, nstr * 16); });
     TSB(2);
 
     // ---------------- Q2: dzo = LN-ELU'(dxo);  ddeter_t += dzo @ W_out_h^T
@@ -864,7 +874,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
     }
     TSB(3);
     uint4 bq3[T3][NIT3][3];
-    grid_barrier(a.ctr, ++gen * NWG, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
 #pragma unroll
       for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.w3, pl3, 3 * D, (nstr + NSTR * j) * 16);
     });
@@ -953,7 +963,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
     }
     TSB(5);
     uint4 bq4[T4][NIT4][3];
-    grid_barrier(a.ctr, ++gen * NWG, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
 #pragma unroll
       for (int j = 0; j < T4; ++j)
         load_planes<NIT4>(bq4[j], a.w4, pl4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
@@ -1031,7 +1041,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
       }
     }
     TSB(7);
-    grid_barrier(a.ctr, ++gen * NWG, [&] { load_planes<NIT1>(bq1[0], a.w1, pl1, S, nstr * 16); });
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] { load_planes<NIT1>(bq1[0], a.w1, pl1, S, nstr * 16); });
     TSB(8);
   }
 }
@@ -1134,6 +1144,7 @@ extern "C" int dd_observe_scan_bwd(
   a.dfeat = dfeat; a.dxq = dxq; a.dxo = dxo; a.dzo = dzo; a.dz3 = dz3; a.dy3 = dy3; a.dgin = dgin;
   a.dz1 = dz1; a.dxs = dxs; a.ctr = sync2;
   hipError_t e = hipMemsetAsync(sync2, 0, sizeof(unsigned), st);
+  if (e == hipSuccess) e = hipMemsetAsync(sync2 + 576, 0, 512 * sizeof(unsigned), st);   // row-block counters
   if (e != hipSuccess) { dd_set_error("dd_observe_scan_bwd(memset)", e); return (int)e; }
   if (D == 256 && U == 256 && G == 32 && C == 32)
     k_observe_scan_bwd<256, 256, 32, 32><<<NWG, 256, 0, st>>>(a);
@@ -1180,7 +1191,7 @@ extern "C" int dd_observe_scan_fwd(
   ScanArgs a;
   a.B = B; a.T = T; a.D = D; a.U = U; a.G = G; a.C = C; a.A = A; a.S = G * C;
   a.XK = a.S + A; a.XKp = (a.XK + 31) / 32 * 32;
-  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 126); a.unimix = unimix;
+  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 254); a.unimix = unimix;
   a.first = first; a.carry = carry; a.init_deter = init_deter; a.init_stoch = init_stoch;
   a.u_post = u_post;
   a.wt1 = (const unsigned short*)wt1; a.wt2 = (const unsigned short*)wt2;
@@ -1193,6 +1204,7 @@ extern "C" int dd_observe_scan_fwd(
   a.idx = idx_ws; a.idx_carry = idx_ws + N * G; a.idx_init = idx_ws + (N + B) * G;
   a.nwg = NWG;
   hipError_t e = hipMemsetAsync(sync2, 0, sizeof(unsigned), st);
+  if (e == hipSuccess) e = hipMemsetAsync(sync2 + 576, 0, 512 * sizeof(unsigned), st);   // row-block counters
   if (e != hipSuccess) { dd_set_error("dd_observe_scan_fwd(memset)", e); return (int)e; }
   if (a.use_carry & 1) {
     k_onehot_argmax<<<(B * G + 255) / 256, 256, 0, st>>>(carry + D, D + a.S, idx_ws + N * G, B, G, C, sync2 + 1);

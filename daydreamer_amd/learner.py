@@ -402,7 +402,7 @@ class Learner:
                              self.ops.observe_scan_bwd_supported(B, D, U, G, self.C))
       self.scan_wb = [(self.P['obs_stats'].W, i16(3 * U * S)), (self.P['obs_out_h'].W, i16(3 * D * U)),
                       (self.P['gru'].W, i16(3 * (D + U) * 3 * D)), (self.P['img_in_s'].W, i16(3 * S * U))]
-      self.scan_sync = torch.zeros(64 + 2 * 4 * 64, dtype=torch.int32, device=self.device)   # counter, error word, debug stamps
+      self.scan_sync = torch.zeros(64 + 2 * 4 * 64 + 512, dtype=torch.int32, device=self.device)   # counter, error word, debug stamps, row-block counters
       self.scan_idx = torch.zeros((N + B + 1) * G, dtype=torch.int32, device=self.device)
     # World-model forward as two batch halves, software-pipelined (opt-in, hip.split_fwd /
     # DD_SPLIT_FWD=1): the latency-bound observe scan of one half (64 workgroups) on the main
