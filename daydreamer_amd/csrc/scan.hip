@@ -27,8 +27,10 @@
 // as the unfused path writes it.
 //
 // Barrier: one monotonic counter per 16-row block (its 16 workgroups are the only producers a
-// phase consumes; forward scan 1.55 -> 1.44 ms, reverse 1.68 -> 1.61 ms against one grid-wide counter,
-// profiles/r04_fused_scan_times.txt), arrive = release fence + relaxed agent-scope add, wait =
+// phase consumes), inter-workgroup outputs stored write-through (st_wt) so that the arrival is a
+// drained-stores + relaxed agent-scope add WITHOUT a release fence (Guideline 16, form R1: the fence
+// would write back the whole L2's dirty side outputs); together forward scan 1.55 -> 1.26 ms,
+// reverse 1.68 -> 1.42 ms (profiles/r04_fused_scan_times.txt, flags 128 / 256 select the old forms).  Wait =
 // relaxed agent-scope polling by one lane + acquire fence (MI355X_MICROARCH.md, valid forms);
 // every spin is bounded - on a timeout bit 0 of the error word is set and the kernel runs on
 // (garbage out, never a hang).  The error word is STICKY: launches reset the counter only, the
@@ -112,12 +114,29 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 
 // `prefetch` runs between the arrival and the wait: loads that do not depend on the other
 // workgroups' results (the next phase's weight planes) travel while the barrier completes.
+// Write-through (sc1) store of a word another workgroup reads in a later phase (Guideline 16, form
+// R1): the data goes past the XCD's L2 at once, so the arrival needs NO release fence - which
+// would also write back every other dirty line of that L2, i.e. the ~1 MB per step of side outputs
+// the backward pass reads after the launch.  Consumers keep the acquire fence + plain loads.
+__device__ __forceinline__ void st_wt(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_wt(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// `wt`: the phase's inter-workgroup outputs were stored write-through (st_wt): every wave drains
+// its stores, then one lane arrives without a release fence.  !wt: plain stores + release fence (the
+// protocol of rounds 2-3; flag bit 8, A/B measurements - the st_wt stores are harmless under it).
 template <class PF>
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned* err, unsigned target, PF prefetch) {
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned* err, unsigned target, bool wt, PF prefetch) {
+  if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!wt) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   prefetch();
@@ -130,12 +149,16 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned* err, unsig
         break;
       }
     }
+    // (tried: the arrival's returned count so that the last arriver skips the poll, and the bare
+    // `buffer_inv sc1` without the `s_waitcnt vmcnt(0)` the builtin puts in front of it, which drains
+    // the prefetch above: 1.284 -> 1.262 ms forward, 1.435 -> 1.413 ms reverse - not worth leaving
+    // the documented fence form)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned* err, unsigned target) {
-  grid_barrier(ctr, err, target, [] {});
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned* err, unsigned target, bool wt) {
+  grid_barrier(ctr, err, target, wt, [] {});
 }
 
 // Activations of the fused scan: every workgroup of a row block rebuilds the phase's whole
@@ -335,10 +358,10 @@ k_observe_scan_fwd(ScanArgs a) {
   const bool alive = mblk * 16 + (lane & 15) < a.B;
   const int kq = (lane >> 4) * 8 + wave * 32;                         // this lane's k offset in a k-step
   const long pl2 = (long)3 * D * (D + U), pl3 = (long)U * D, pl4 = (long)S * U;
-  const bool bar_rb = !(a.use_carry & 128);
+  const bool bar_rb = !(a.use_carry & 128), bar_wt = !(a.use_carry & 256);
   unsigned gen = 0;
   if (a.use_carry & 2) {   // measurement aid: the barriers alone (4 per step), no work
-    for (int i = 0; i < 4 * T; ++i) grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N);
+    for (int i = 0; i < 4 * T; ++i) grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt);
     return;
   }
   // P1's dense action columns of W_img_in for this thread's output columns: step-invariant
@@ -414,7 +437,7 @@ k_observe_scan_fwd(ScanArgs a) {
         for (int g = 0; g < G; ++g) acc += w[g];
 #pragma unroll
         for (int j = 0; j < A; ++j) acc += act[j] * wa[jt][j];
-        if (live) a.z1[row * U + n] = acc;
+        if (live) st_wt(a.z1 + row * U + n, acc);
       }
 #pragma unroll
       for (int q = 0; q < S / (NSTR * 64); ++q) {
@@ -431,7 +454,7 @@ k_observe_scan_fwd(ScanArgs a) {
     constexpr bool ALL2 = T2 * NIT2 <= 12;
     constexpr int NITC2 = NIT2 % 4 == 0 ? 4 : NIT2;
     uint4 bq2[ALL2 ? T2 : 2][ALL2 ? NIT2 : NITC2][3];
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
       if constexpr (ALL2) {
 #pragma unroll
         for (int j = 0; j < T2; ++j) load_planes<NIT2>(bq2[j], a.wt2, pl2, D + U, (nstr + NSTR * j) * 16);
@@ -501,11 +524,11 @@ k_observe_scan_fwd(ScanArgs a) {
       TS(5);
 #pragma unroll
       for (int j = 0; j < T2; ++j)
-        if (olive) a.z3[oidx * 3 * D + n0[j] + ocol] = out[j];
+        if (olive) st_wt(a.z3 + oidx * 3 * D + n0[j] + ocol, out[j]);
     }
     TS(6); TSW(1);
     uint4 bq3[T3][NIT3][3];
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
 #pragma unroll
       for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.wt3, pl3, D, (nstr + NSTR * j) * 16);
     });
@@ -575,13 +598,13 @@ k_observe_scan_fwd(ScanArgs a) {
       TS(10);
 #pragma unroll
       for (int j = 0; j < T3; ++j)
-        if (olive) a.zo[oidx * U + n0[j] + ocol] = zold[j] + out[j];
+        if (olive) st_wt(a.zo + oidx * U + n0[j] + ocol, zold[j] + out[j]);
     }
     TS(11); TSW(2);
     constexpr bool ALL4 = T4 * NIT4 <= 12;
     constexpr int NITC4 = NIT4 % 4 == 0 ? 4 : NIT4;
     uint4 bq4[ALL4 ? T4 : 2][ALL4 ? NIT4 : NITC4][3];
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
       if constexpr (ALL4) {
 #pragma unroll
         for (int j = 0; j < T4; ++j)
@@ -681,13 +704,13 @@ k_observe_scan_fwd(ScanArgs a) {
             const long row = (long)(mblk * 16 + item) * T + t;
             a.post_logit[row * S + g * C + c] = lg[i];
             a.post[row * F + D + g * C + c] = (c == idx[i]) ? 1.f : 0.f;
-            if (c == 0) a.idx[row * G + g] = idx[i];
+            if (c == 0) st_wt(a.idx + row * G + g, idx[i]);
           }
         }
       }
     }
     TS(17); TSW(3);
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N);
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt);
     TS(18);
   }
 }
@@ -827,7 +850,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
   const int kq = (lane >> 4) * 8 + wave * 32;
   const long pl1 = (long)U * S, pl2 = (long)D * U, pl3 = (long)(D + U) * 3 * D, pl4 = (long)S * U;
   const float um = 1.f - a.unimix;
-  const bool bar_rb = !(a.flags & 128);
+  const bool bar_rb = !(a.flags & 128), bar_wt = !(a.flags & 256);
   unsigned gen = 0;
   __syncthreads();
   uint4 bq1[1][NIT1][3];
@@ -846,11 +869,11 @@ k_observe_scan_bwd(ScanBwdArgs a) {
       for (int it = 0; it < NIT1; ++it) split8(raw[it], afr[it]);
       float out[1];
       tiles_gemm<S, 1>(afr, bq1, red, out);
-      if (olive) a.dxo[oidx * U + nstr * 16 + ocol] = out[0];
+      if (olive) st_wt(a.dxo + oidx * U + nstr * 16 + ocol, out[0]);
     }
     TSB(1);
     uint4 bq2[1][NIT2][3];
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] { load_planes<NIT2>(bq2[0], a.w2, pl2, U, nstr * 16); });
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] { load_planes<NIT2>(bq2[0], a.w2, pl2, U, nstr * 16); });
     TSB(2);
 
     // ---------------- Q2: dzo = LN-ELU'(dxo);  ddeter_t += dzo @ W_out_h^T
@@ -870,11 +893,11 @@ k_observe_scan_bwd(ScanBwdArgs a) {
       for (int it = 0; it < NIT2; ++it) split8(dz[it], afr[it]);
       float out[1];
       tiles_gemm<U, 1>(afr, bq2, red, out);
-      if (olive) a.dfeat[oidx * F + nstr * 16 + ocol] = dold + out[0];
+      if (olive) st_wt(a.dfeat + oidx * F + nstr * 16 + ocol, dold + out[0]);
     }
     TSB(3);
     uint4 bq3[T3][NIT3][3];
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
 #pragma unroll
       for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.w3, pl3, 3 * D, (nstr + NSTR * j) * 16);
     });
@@ -953,17 +976,17 @@ k_observe_scan_bwd(ScanBwdArgs a) {
         if (olive) {
           if (col < D) {
             const float dh = dh_lds[orow][col] + out[j];
-            a.dgin[oidx * (D + U) + col] = dh;
-            if (t > 0) a.dfeat[(oidx - 1) * F + col] = dprev[j] + dh * (1.f - fo);
+            st_wt(a.dgin + oidx * (D + U) + col, dh);
+            if (t > 0) st_wt(a.dfeat + (oidx - 1) * F + col, dprev[j] + dh * (1.f - fo));
           } else {
-            a.dgin[oidx * (D + U) + col] = out[j];
+            st_wt(a.dgin + oidx * (D + U) + col, out[j]);
           }
         }
       }
     }
     TSB(5);
     uint4 bq4[T4][NIT4][3];
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] {
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
 #pragma unroll
       for (int j = 0; j < T4; ++j)
         load_planes<NIT4>(bq4[j], a.w4, pl4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
@@ -1033,7 +1056,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
             const int col = (nstr + NSTR * gi) * C + q * 16 + ocol;
             if (olive) {
               a.dfeat[(oidx - 1) * F + D + col] = ds[q];
-              a.dxq[(oidx - 1) * S + col] = pr[q] * (dp[q] - dot);
+              st_wt(a.dxq + (oidx - 1) * S + col, pr[q] * (dp[q] - dot));
             }
             (void)j;
           }
@@ -1041,7 +1064,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
       }
     }
     TSB(7);
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, [&] { load_planes<NIT1>(bq1[0], a.w1, pl1, S, nstr * 16); });
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] { load_planes<NIT1>(bq1[0], a.w1, pl1, S, nstr * 16); });
     TSB(8);
   }
 }
@@ -1191,7 +1214,7 @@ extern "C" int dd_observe_scan_fwd(
   ScanArgs a;
   a.B = B; a.T = T; a.D = D; a.U = U; a.G = G; a.C = C; a.A = A; a.S = G * C;
   a.XK = a.S + A; a.XKp = (a.XK + 31) / 32 * 32;
-  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 254); a.unimix = unimix;
+  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 510); a.unimix = unimix;
   a.first = first; a.carry = carry; a.init_deter = init_deter; a.init_stoch = init_stoch;
   a.u_post = u_post;
   a.wt1 = (const unsigned short*)wt1; a.wt2 = (const unsigned short*)wt2;

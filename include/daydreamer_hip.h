@@ -184,7 +184,8 @@ int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
  * dd_stats_sample_fwd / dd_onehot_sample_host given the same statistics.
  * wt1..wt4: weight caches from dd_scan_wprep for img_in [U][pad32(S+A)], gru_out [3D][D+U],
  * obs_out[:D] [U][D], obs_stats [S][U].  sync2: 1088 zero-initialised device words - [0] grid-wide
- * barrier counter (use_carry bit 7 selects it: measurement aid), [1] error word, [2, 576) time
+ * barrier counter (use_carry bit 7 selects it; bit 8: release fence at every arrival instead of
+ * write-through stores - measurement aids), [1] error word, [2, 576) time
  * stamps of the measurement flag, [576 + 128 m] the barrier counter of row block m (a phase only
  * consumes what the 16 workgroups of its own 16-row block produced, so the blocks synchronise
  * separately).  The launch resets the counters only; the error word is sticky (bit 0: a

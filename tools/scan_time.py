@@ -52,8 +52,9 @@ def scan(flag):
 timed('weight planes (4 x dd_scan_wprep)', lambda: [ops.scan_wprep(W, p, k) for W, p, k in L.scan_w])
 timed('fused scan, full (T = %d steps)' % T, lambda: scan(1))
 timed('fused scan, full, grid-wide barrier counter (flag 128)', lambda: scan(1 | 128))
-timed('fused scan, full (row-block counters) again', lambda: scan(1))
-timed('fused scan, full, grid-wide barrier counter again', lambda: scan(1 | 128))
+timed('fused scan, full, release fence at every arrival (flag 256)', lambda: scan(1 | 256))
+timed('fused scan, full (write-through stores, no release fence) again', lambda: scan(1))
+timed('fused scan, full, release fence again', lambda: scan(1 | 256))
 timed('fused scan, barriers only (4 per step)', lambda: scan(3))
 for nm, bit in (('P1 img_in (gather)', 4), ('P2 gru gemm', 8), ('P3 gru gates + obs_out', 16), ('P4 obs_stats + draw', 32)):
   timed('fused scan without ' + nm, lambda bit=bit: scan(1 | bit))
@@ -108,8 +109,9 @@ L.fused_scan_bwd = True
 L.observe_scan_bwd_fused()
 timed('reverse scan kernel alone (T = %d steps)' % T, lambda: (reseed(), scan_bwd()))
 timed('reverse scan kernel, grid-wide barrier counter (flag 128)', lambda: (reseed(), scan_bwd(128)))
-timed('reverse scan kernel alone (row-block counters) again', lambda: (reseed(), scan_bwd()))
-timed('reverse scan kernel, grid-wide barrier counter again', lambda: (reseed(), scan_bwd(128)))
+timed('reverse scan kernel, release fence at every arrival (flag 256)', lambda: (reseed(), scan_bwd(256)))
+timed('reverse scan kernel alone (write-through stores, no release fence) again', lambda: (reseed(), scan_bwd()))
+timed('reverse scan kernel, release fence again', lambda: (reseed(), scan_bwd(256)))
 timed('  (the three seed copies in that figure)', reseed)
 for fused in (False, True):
   L.fused_scan_bwd = fused
