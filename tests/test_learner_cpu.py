@@ -337,3 +337,26 @@ def test_chunked_heads_equal_bulk():
     assert np.array_equal(v, outs[1][0][k]), k
   for k, v in outs[0][1].items():
     assert np.array_equal(v, outs[1][1][k], equal_nan=True), k
+
+
+def test_early_allreduce_range_of_the_model_arena():
+  """Learner.early_range (data parallel, default schedule): the part of the model gradient arena
+  that is all-reduced before the encoder's backward pass is exactly the contiguous run of decoder /
+  reward / cont tensors - with weight decay (a1_vision: decayed kernels first) their kernels,
+  71 % of the arena - and the two ranges around it cover everything else exactly once."""
+  cfg = helpers.make_config(('a1_vision',), batch_size=2, replay_chunk=3, imag_horizon=2)
+  plain, sp, shapes, params, data, B, T = helpers.make_problem(cfg, image=64, vector=16, action=16)
+  L = learner_mod.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params)
+  g = L.groups['model']
+  lo, hi = L.early_range()
+  assert lo % 4 == 0 and hi % 4 == 0 and 0 < lo < hi <= g.gflat.numel()
+  inside = [p for p in g.specs if lo <= g.offset[p.name] < hi]
+  assert inside and all(p.name.split('/')[0] in ('dec', 'reward', 'cont') for p in inside)
+  assert all(g.offset[p.name] + p.size <= hi for p in inside)
+  mods = {p.name.split('/')[0] for p in inside}
+  assert mods == {'dec', 'reward', 'cont'}
+  # every decayed tensor of those modules is inside (the kernels), the range is most of the arena
+  for p in g.specs:
+    if p.decay and p.name.split('/')[0] in mods:
+      assert lo <= g.offset[p.name] < hi, p.name
+  assert (hi - lo) / g.gflat.numel() > 0.6
