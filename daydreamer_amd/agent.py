@@ -750,7 +750,7 @@ class Agent:
     self.ops.copy2d(post[:nseq, ctx - 1], roll.b['traj'][0][:, :R.F])
     roll.phase_prep_b()
     roll.imagine_rollout()
-    dec.decoder_fwd(roll.b['traj'].view(-1, R.F + R.A)[:, :R.F])
+    dec.decoder_fwd(roll.b['traj'].view(-1, R.TW)[:, :R.F])
     z = host(dec.dec_act[-1]['z'])
     z = z.reshape((H + 1, nseq) + z.shape[1:])
     model = 1.0 / (1.0 + np.exp(-z.astype(np.float64)))

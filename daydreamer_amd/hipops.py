@@ -235,6 +235,21 @@ class HipOps:
     a, lda = _mat(A)
     b, ldb = _mat(B)
     c, ldc = _mat(C)
+    # A ragged float4 axis (a multiple-of-four rule of the branch-free 16-byte loaders that only
+    # the LAST 1-3 elements break: K = stoch + action = 1030 of the one-hot-action configs) would put
+    # the whole contraction on the bounds-checked scalar loaders.  Peel the remainder off instead:
+    # the 1-3 leftover k (or rows) as their own small call, the multiple-of-four bulk on the fast path.
+    if a % 16 == 0 and b % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0:
+      if ta and M % 4 and M >= 256:               # rows of C past the last multiple of four
+        M4 = M & ~3
+        self.gemm(A[:, M4:], B, C[M4:], ta, tb, alpha, beta, bias)
+        self.gemm(A[:, :M4], B, C[:M4], ta, tb, alpha, beta, bias)
+        return None
+      if (not ta or tb) and K % 4 and K >= 64 and (not ta or M % 4 == 0) and (tb or N % 4 == 0):
+        K4 = K & ~3
+        self.gemm(A[K4:] if ta else A[:, K4:], B[:, K4:] if tb else B[K4:], C, ta, tb, alpha, beta)
+        return self.gemm(A[:K4] if ta else A[:, :K4], B[:, :K4] if tb else B[:K4], C, ta, tb,
+                         alpha, 1.0, bias, defer)
     # in deferred mode bias / beta are applied by the consumer together with the sum
     flag = ctypes.c_int(0) if (defer and alpha == 1.0) else None
     self._check(self._traced(f'gemm {M}x{N}x{K} ta{int(ta)} tb{int(tb)} B{4 * (M * K + K * N + M * N)}', 2.0 * M * N * K, lambda: self.lib.dd_gemm_f32(

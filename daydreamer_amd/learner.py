@@ -446,8 +446,21 @@ class Learner:
       b['bias_tiled'] = z(c0.k * c0.k * c0.c_big)
       b['dbias_tiled'] = z(c0.k * c0.k * c0.c_big)
     # ---- imagination (time-major [H+1, N, ...])
-    W = F + A
-    b['traj'] = z(H + 1, N, W)     # [deter | stoch | action]
+    # Row width of the trajectory: F + A, padded with zero columns to a multiple of four floats
+    # when it is not one (one-hot action spaces: xarm / ur5 have A = 6, F + A = 1542): every row of a
+    # column slice then starts on a 16-byte boundary and the contractions over traj[:, :F] (all heads,
+    # the actor's first layer, their weight gradients) take the branch-free 16-byte loaders instead
+    # of the bounds-checked scalar ones (5.2 ms of the 30.5 ms of kernel time per step at the xarm
+    # shard ran on those, profiles/r04_rocprof_kernel_stats_xarm_shard.csv).  The fused imagination
+    # kernels index rows by F + A themselves, so shapes they cover keep the exact width.
+    ca = self.cfg['actor']
+    self.fused_imag = (bool(self.cfg.get('hip', {}).get('fused_imag', True)) and
+                       self.dtype == torch.float32 and hasattr(self.ops, 'imagine_rollout_fwd') and H >= 1 and
+                       self.ops.imagine_rollout_supported(D, U, G, self.C, A, ca['units'], ca['layers'],
+                                                          self.n_prior, self.discrete))
+    self.TW = F + A if self.fused_imag else (F + A + 3) // 4 * 4
+    W = self.TW
+    b['traj'] = z(H + 1, N, W)     # [deter | stoch | action | zero padding]
     b['dtraj'] = z(H + 1, N, W)
     self.ai_img_in = Act(self, H * N, U, True)
     b['iz3'] = z(H * N, 3 * D)
@@ -465,12 +478,7 @@ class Learner:
         'critic': self._head_acts('critic', H * N),
         'critic_target': self._head_acts('critic_target', M)}
     # fused imagination rollout (csrc/imag.hip): fragment-major bf16 weight planes
-    ca = self.cfg['actor']
     self.fused_imag_bwd = False
-    self.fused_imag = (bool(self.cfg.get('hip', {}).get('fused_imag', True)) and
-                       self.dtype == torch.float32 and hasattr(self.ops, 'imagine_rollout_fwd') and H >= 1 and
-                       self.ops.imagine_rollout_supported(D, U, G, self.C, A, ca['units'], ca['layers'],
-                                                          self.n_prior, self.discrete))
     if self.fused_imag:
       i16 = lambda k, n: torch.zeros(3 * k * ((n + 15) // 16 * 16), dtype=torch.int16, device=self.device)
       layers, outs = self.heads['actor']
@@ -1457,14 +1465,14 @@ class Learner:
       st = lambda buf, t_=t: buf.view(H + 1, N, -1)[t_]
       if self.discrete:
         (xa,) = self.head_fwd('actor', self.acts_im['actor'], traj[t][:, :F], st)
-        ops.stats_fwd(xa, b['u_act'][t], st(b['alogit']), traj[t][:, F:], 1, A,
+        ops.stats_fwd(xa, b['u_act'][t], st(b['alogit']), traj[t][:, F:F + A], 1, A,
                       float(ca['unimix']), 0)
       else:
         om, os_ = self.head_fwd('actor', self.acts_im['actor'], traj[t][:, :F], st)
-        ops.normal_head_fwd(om, os_, b['eps'][t], traj[t][:, F:], lo, hi)
+        ops.normal_head_fwd(om, os_, b['eps'][t], traj[t][:, F:F + A], lo, hi)
       if t < H:
         si = lambda buf, t_=t: buf.view(H, N, -1)[t_]
-        self.core_fwd(traj[t][:, D:], traj[t][:, :D], traj[t + 1][:, :D],
+        self.core_fwd(traj[t][:, D:F + A], traj[t][:, :D], traj[t + 1][:, :D],
                       self.ai_img_in, b['iz3'], b['igstats'], si)
         xs = self.prior_fwd(traj[t + 1][:, :D], self.ai_img_out,
                             self.ai_img_stats, si)
@@ -1525,7 +1533,7 @@ class Learner:
     ops, b, cfg = self.ops, self.b, self.cfg
     N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
     traj = b['traj']  # traj[0][:, :F] = start states, set by phase_wm_opt
-    feat = traj.view(M, F + A)[:, :F]
+    feat = traj.view(M, self.TW)[:, :F]
     # reward / cont / target-critic heads over the trajectory (rewfn, cont head, target net:
     # agent.py:255-257, 400-403, 426).  They only read finished latent states, so each chunk
     # of time rows is evaluated on the side stream while the rollout - a chain of mid-size
@@ -1601,8 +1609,8 @@ class Learner:
     N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
     HN = H * N
     traj, dtraj = b['traj'], b['dtraj']
-    feat = traj.view(M, F + A)[:, :F]
-    dfeat = dtraj.view(M, F + A)[:, :F]
+    feat = traj.view(M, self.TW)[:, :F]
+    dfeat = dtraj.view(M, self.TW)[:, :F]
     ca = cfg['actor']
     lo, hi = ca['minstd'], ca['maxstd']
     # score with the post-update slow critic (reference agent.py:329-344).  It changes only
@@ -1652,8 +1660,8 @@ class Learner:
     ops, b, cfg = self.ops, self.b, self.cfg
     N, H, M, A, F = self.N, self.H, self.M, self.A, self.F
     HN = H * N
-    feat = b['traj'].view(M, F + A)[:, :F]
-    act = b['traj'].view(M, F + A)[:, F:]
+    feat = b['traj'].view(M, self.TW)[:, :F]
+    act = b['traj'].view(M, self.TW)[:, F:F + A]
     ent_div = math.log(A) if cfg['actent_norm'] else 1.0
     ops.onehot_entropy(b['alogit'], b['ent_norm'], ent_div)
     k = self.stat('actent', b['ent_norm'][:HN])
@@ -1679,8 +1687,8 @@ class Learner:
     N, H, M, D, S, A, F = self.N, self.H, self.M, self.D, self.S, self.A, self.F
     HN = H * N
     traj, dtraj = b['traj'], b['dtraj']
-    feat = traj.view(M, F + A)[:, :F]
-    dfeat = dtraj.view(M, F + A)[:, :F]
+    feat = traj.view(M, self.TW)[:, :F]
+    dfeat = dtraj.view(M, self.TW)[:, :F]
     ca = cfg['actor']
     lo, hi = ca['minstd'], ca['maxstd']
     # entropy regulariser scale (AutoAdapt, inverse; reference agent.py:361-371)
@@ -1728,7 +1736,7 @@ class Learner:
                      si, params=False)
       self.core_bwd(dtraj[t][:, :D], traj[t - 1][:, :D], self.ai_img_in,
                     b['iz3'], b['igstats'], si, b['idz3'], b['idy3'], b['idh'],
-                    dtraj[t - 1][:, D:], 1.0, self.P['img_in'])
+                    dtraj[t - 1][:, D:F + A], 1.0, self.P['img_in'])
       ops.reset_mask_bwd(b['idh'], zr, dtraj[t - 1][:, :D])
     side = self.side_stream_b
     if self.fused_imag_bwd:
@@ -1758,7 +1766,7 @@ class Learner:
             self.join(side)        # row t0-1 belongs to the chunk evaluated on the side stream
           scan_step(t)
     # policy head + entropy bonus, then the actor network (bulk)
-    dact = dtraj.view(M, F + A)[:, F:]
+    dact = dtraj.view(M, self.TW)[:, F:F + A]
     oa = self.acts_im['actor'][1]
     ops.normal_head_bwd(om_all, os_all, b['eps'].view(M, A), dact, b['i_weight'],
                         self.actent_scale, oa[0].dout, oa[1].dout, b['i_ent_row'],
@@ -1780,14 +1788,14 @@ class Learner:
     feat = b.setdefault('report_feat', self.zeros(B, T, F))
     ops.copy2d(b['post'], feat.view(B * T, F))
     act = b['action'].view(B, T, A)
-    tr = b['traj'].view(-1, F + A)          # scratch rows: [deter | stoch | action]
+    tr = b['traj'].view(-1, self.TW)          # scratch rows: [deter | stoch | action]
     state = tr[:B]
     ops.copy2d(post[:, ctx - 1], state[:, :F])
     for i, t in enumerate(range(ctx, T)):
       nxt = tr[(i + 1) * B:(i + 2) * B]
-      ops.copy2d(act[:, t], state[:, F:])
+      ops.copy2d(act[:, t], state[:, F:F + A])
       si = lambda buf, i_=i: buf[i_ * B:(i_ + 1) * B]
-      self.core_fwd(state[:, D:], state[:, :D], nxt[:, :D], self.ai_img_in,
+      self.core_fwd(state[:, D:F + A], state[:, :D], nxt[:, :D], self.ai_img_in,
                     b['iz3'], b['igstats'], si)
       xs = self.prior_fwd(nxt[:, :D], self.ai_img_out, self.ai_img_stats, si)
       ops.stats_fwd(xs, b['u_img'].view(-1, self.G)[i * B:(i + 1) * B],
@@ -1825,19 +1833,19 @@ class Learner:
     if self.discrete:
       ops.philox(b['u_act'][0], 1, B, 1, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 2, 0)
       (xa,) = self.head_fwd('actor', self.acts_im['actor'], t0[:, :F], sel)
-      ops.stats_fwd(xa, b['u_act'][0], sel(b['alogit']), t0[:, F:], 1, A,
+      ops.stats_fwd(xa, b['u_act'][0], sel(b['alogit']), t0[:, F:F + A], 1, A,
                     float(ca['unimix']), 0 if sample else 1)
     else:
       om, os_ = self.head_fwd('actor', self.acts_im['actor'], t0[:, :F], sel)
-      ops.normal_head_fwd(om, os_, b['eps'][0] if sample else None, t0[:, F:],
+      ops.normal_head_fwd(om, os_, b['eps'][0] if sample else None, t0[:, F:F + A],
                           ca['minstd'], ca['maxstd'])
     if noise:  # tfutils.py:85-93
       nz = b.setdefault('act_noise', self.zeros(B, A))
       ops.philox(nz, 1, B, A, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 3,
                  0 if self.discrete else 1)
-      ops.action_noise(t0[:, F:], nz, float(noise), self.discrete)
+      ops.action_noise(t0[:, F:F + A], nz, float(noise), self.discrete)
     ops.copy2d(b['post'], b['carry'])
-    return t0[:, F:]
+    return t0[:, F:F + A]
 
   # --------------------------------------------------------------- train step
 

@@ -126,7 +126,7 @@ def report_parity(backend, discrete, tol, device_batch=False, cameras=1, cnn='si
       u_obs_prior=R.b['u_prior'].permute(1, 0, 2).cpu().numpy(), u_obs_post=R.b['u_post'].cpu().numpy(),
       u_openl=torch.stack([u_img[i * B:i * B + n] for i in range(T - ctx)]).cpu().numpy(),
       u_img=roll.b['u_img'].cpu().numpy(), eps_act=roll.b['eps'].cpu().numpy())
-  tr = R.b['traj'].view(-1, F + R.A)
+  tr = R.b['traj'].view(-1, R.TW)
   forced = dict(
       obs_post=R.b['post'].view(B, T, F)[:, :, D:].reshape(B, T, G, C).argmax(-1).permute(1, 0, 2).cpu(),
       obs_prior=R.b['prior_stoch'].view(B, T, G, C).argmax(-1).permute(1, 0, 2).cpu(),
@@ -135,7 +135,7 @@ def report_parity(backend, discrete, tol, device_batch=False, cameras=1, cnn='si
       img=roll.b['traj'][1:, :, D:F].reshape(H, n, G, C).argmax(-1).cpu())
   if discrete:
     noise['u_act'] = roll.b['u_act'][..., 0].cpu().numpy()
-    forced['act'] = roll.b['traj'][:, :, F:].argmax(-1).cpu()
+    forced['act'] = roll.b['traj'][:, :, F:F + R.A].argmax(-1).cpu()
   want = ref.report(data, noise, forced)
   keys = [f'openl_{k}' for k in ag.spec.dec_cnn_keys] + [f'task_imag_{k}' for k in ag.spec.dec_cnn_keys]
   for k in keys:

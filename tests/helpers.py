@@ -78,7 +78,7 @@ def forced_from_learner(L):
   img = b['traj'][1:, :, D:F].reshape(H, N, G, C)
   extra = {}
   if L.discrete:
-    extra['act'] = b['traj'][:, :, F:].argmax(-1).cpu()
+    extra['act'] = b['traj'][:, :, F:F + L.A].argmax(-1).cpu()
   return dict(
       **extra,
       obs_post=post.argmax(-1).permute(1, 0, 2).cpu(),

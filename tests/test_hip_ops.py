@@ -52,6 +52,31 @@ def test_gemm(hip, ref, M, N, K, ta, tb):
     close(g, c, what=f'gemm {M}x{N}x{K} ta{ta} tb{tb} beta{beta}')
 
 
+@pytest.mark.parametrize('M,N,K,ta,tb', [
+    (300, 512, 1030, 0, 0), (200, 300, 1030, 0, 1), (1030, 512, 300, 1, 0), (1030, 64, 1031, 1, 1),
+    (514, 256, 66, 1, 1), (1250, 512, 1030, 0, 0)])
+def test_gemm_peeled_remainder(hip, ref, M, N, K, ta, tb):
+  """Operands that are column slices of 16-byte aligned rows with a ragged float4 axis (the
+  [stoch | action] columns of the padded trajectory rows, K = 1030): HipOps.gemm peels the last
+  1-3 k (or output rows) off into their own small call and runs the bulk on the fast loaders."""
+  def padded(r, c, seed):
+    return rnd(r, (c + 3) // 4 * 4 + 8, seed=seed)
+  A = padded(*((K, M) if ta else (M, K)), seed=1)
+  B = padded(*((N, K) if tb else (K, N)), seed=2)
+  C, bias = rnd(M, N, seed=3), rnd(N, seed=4)
+  ac, bc = (M if ta else K), (K if tb else N)
+  for beta, bs in ((0.0, None), (1.0, bias)):
+    def fn(ops, A, B, C, bias):
+      if ops is hip:
+        ops.trace = []
+      ops.gemm(A[:, :ac], B[:, :bc], C, bool(ta), bool(tb), 0.5, beta, bias if bs is not None else None)
+      if ops is hip:
+        assert len(ops.trace) >= 2, 'the remainder was not peeled off'
+        ops.trace = None
+    (g, c), = both(hip, ref, fn, [A, B, C, bias], [2])
+    close(g, c, what=f'gemm {M}x{N}x{K} ta{ta} tb{tb} beta{beta}')
+
+
 def test_role_separated_loop_is_bit_identical(hip):
   """dd_gemm_set_ws: the role-separated form of the 128x128 loop (four MFMA waves + four staging
   waves, k_mfma_gemm_ws) stages the same LDS image and issues the same products in the same order
@@ -762,6 +787,26 @@ def test_deferred_splitk_sum(hip):
     hip.ln_act_bwd(dout, zz, oo, st, g, dz, None, None, False, True, pre=pre)
     return (dz,)
   pair(D, lnb)
+
+
+def test_deferred_splitk_sum_with_peeled_remainder(hip, ref):
+  """K = stoch + action = 1030 (one-hot-action configs): HipOps.gemm runs k = 1028.. as a small call
+  into C first (beta applied there) and the multiple-of-four bulk deferred with beta = 1, so the
+  consumer's `pre` sum still yields beta * C + x @ W + bias followed by the LayerNorm."""
+  torch.manual_seed(1)
+  rows, K, D = 50, 1030, 512
+  x, W = torch.randn(rows, K + 2), torch.randn(K, D) * 0.05   # row stride 1032: 16-byte aligned rows
+  z0, bias = torch.randn(rows, D), torch.randn(D)
+  g, bt = torch.rand(D) + 0.5, torch.randn(D)
+  for beta in (0.0, 1.0):
+    def fn(ops, x, W, z, bias, g, bt, out, st):
+      pre = ops.gemm(x[:, :K], W, z, beta=beta, bias=bias, defer=True)
+      if ops is hip:
+        assert pre is not None and pre.n > 1 and pre.beta == 1.0
+      ops.ln_act_fwd(z, g, bt, out, st, True, pre=pre)
+    res = both(hip, ref, fn, [x, W, z0, bias, g, bt, torch.zeros(rows, D), torch.zeros(rows, 2)], [2, 6])
+    close(*res[0], what=f'z beta{beta}')
+    close(*res[1], what=f'ln(z) beta{beta}')
 
 
 def test_native_fp32_mode(hip, ref):
