@@ -459,11 +459,11 @@ def main():
                 ranks_share_devices=shared_devices),
             hip_graphs=plan.n_graphs,
             schedule=('opt-in hip.pipeline: behaviour phase of step k overlaps world-model phase '
-                      'of step k+1, bit-identical parameters, metrics returned one call late'
+                      'of step k+1, bit-identical parameters, each call\'s own metrics returned lazily'
                       if pipelined else 'shipped default (hip.pipeline off): train() returns this call\'s metrics')),
         resident=rate(dt_res),
         pipelined=None if dt_pipe is None else dict(
-            **rate(dt_pipe), note='opt-in hip.pipeline: true - bit-identical parameters, metrics one call late'),
+            **rate(dt_pipe), note='opt-in hip.pipeline: true - bit-identical parameters, each call\'s own metrics returned lazily (LazyMetrics)'),
         sequential_default=rate(dt_seq),
         replay_inclusive=None if dt_replay is None else dict(
             **rate(dt_replay), note='DeviceReplay.sample_batch (dd_replay_gather from the HBM '

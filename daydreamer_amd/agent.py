@@ -17,6 +17,7 @@ controllers are summed over ranks.
 """
 
 import atexit
+import collections.abc
 import os
 import queue
 import threading
@@ -192,6 +193,97 @@ def _close_batchers():
     b.close(join=True)
 
 
+class LazyScalar:
+  """One metric of a pipelined train call; the device is waited for when it is looked at
+  (float(), np.asarray(), format, arithmetic, comparison), not when train() returns."""
+
+  __slots__ = ('_owner', '_key')
+
+  def __init__(self, owner, key):
+    self._owner, self._key = owner, key
+
+  def _value(self):
+    return self._owner.resolve()[self._key]
+
+  def __array__(self, dtype=None, copy=None):
+    a = np.asarray(self._value())
+    return a if dtype is None else a.astype(dtype)
+
+  def __float__(self):
+    return float(self._value())
+
+  def __int__(self):
+    return int(self._value())
+
+  def __bool__(self):
+    return bool(self._value())
+
+  def __format__(self, spec):
+    return format(self._value(), spec)
+
+  def __repr__(self):
+    return repr(self._value())
+
+  def item(self):
+    return np.asarray(self._value()).item()
+
+  def __add__(self, o): return self._value() + o
+  def __radd__(self, o): return o + self._value()
+  def __sub__(self, o): return self._value() - o
+  def __rsub__(self, o): return o - self._value()
+  def __mul__(self, o): return self._value() * o
+  def __rmul__(self, o): return o * self._value()
+  def __truediv__(self, o): return self._value() / o
+  def __rtruediv__(self, o): return o / self._value()
+  def __neg__(self): return -self._value()
+  def __abs__(self): return abs(self._value())
+  def __lt__(self, o): return self._value() < o
+  def __le__(self, o): return self._value() <= o
+  def __gt__(self, o): return self._value() > o
+  def __ge__(self, o): return self._value() >= o
+
+
+class LazyMetrics(collections.abc.Mapping):
+  """The metrics dict of ONE pipelined train call - that call's own metrics, as the reference's
+  train() returns them (tfagent.py train -> _convert_mets) - read from the device when first
+  looked at.  A loop that only collects the values (`metrics[key].append(value)`, run/train.py)
+  and aggregates them at its log interval never waits inside train(); `float(mets[k])` right
+  after the call waits for that step (and serialises the two streams).  At the latest it is
+  fetched when the call after the next one is enqueued (its snapshot slot is reused then)."""
+
+  def __init__(self, keys, fetch):
+    self._keys, self._fetch, self._vals, self._error = tuple(keys), fetch, None, None
+
+  def resolve(self):
+    if self._vals is None:
+      if self._error is not None:
+        raise self._error
+      fetch, self._fetch = self._fetch, None
+      try:
+        self._vals = fetch()
+      except Exception as e:   # (e.g. read_metrics: a loss is not finite) - every later look raises it again
+        self._error = e
+        raise
+    return self._vals
+
+  @property
+  def resolved(self):
+    return self._vals is not None
+
+  def __getitem__(self, key):
+    if self._vals is not None:
+      return self._vals[key]
+    if key not in self._keys:
+      raise KeyError(key)
+    return LazyScalar(self, key)
+
+  def __iter__(self):
+    return iter(self._vals if self._vals is not None else self._keys)
+
+  def __len__(self):
+    return len(self._vals if self._vals is not None else self._keys)
+
+
 class Pipeline:
   """Two-stream software pipeline of the train step (hip.pipeline: true).
 
@@ -203,7 +295,9 @@ class Pipeline:
   second stream while A1(k+1) runs on the first; A2(k+1), which writes the world-model
   weights, waits for B(k).  The arithmetic and its order inside every phase are those
   of the sequential step (parameters after n steps are bit-identical,
-  tests/test_learner_gpu.py); only the metrics come back one call late.
+  tests/test_learner_gpu.py).  Every call returns ITS OWN metrics as a `LazyMetrics`: they are
+  copied out of the per-step snapshot when first looked at, or when the next call has been
+  enqueued, whichever comes first.
   """
 
   def __init__(self, learner, device, comm=None):
@@ -246,7 +340,9 @@ class Pipeline:
     self.pub_a = [{k: torch.empty_like(v) for k, v in live.items()} for _ in range(2)]
     self.pub_b = [{k: torch.empty_like(v) for k, v in live.items()} for _ in range(2)]
     self.k = 0
-    self.pending = None  # parity of the step whose metrics have not been returned yet
+    self.pending = None  # parity of the step whose metrics have not been fetched yet
+    self.handle = None   # its LazyMetrics
+    self.keys = ()       # metric names (those of the eager first step)
 
   POOLS = {}  # device -> ([4 phase streams], read-out stream)
   BEST = {}   # device -> selected (world-model stream, behaviour stream) indices
@@ -303,8 +399,9 @@ class Pipeline:
           plan.release()
 
   def step(self):
-    """Enqueue one step; returns the metrics of the previous pipelined step (None for
-    the first).  The caller's current stream holds the uploaded inputs."""
+    """Enqueue one step; returns its metrics as a LazyMetrics.  The previous step's metrics
+    are fetched here (after this step's world-model phase has been enqueued), if the caller has
+    not looked at them yet.  The caller's current stream holds the uploaded inputs."""
     cur = torch.cuda.current_stream(self.device)
     if not self.tuned:
       self._tune()   # (first pipelined agent of the process: measure the stream pairs)
@@ -337,9 +434,12 @@ class Pipeline:
       tick.record(s2)
       self.ticks.append(tick)
     cur.wait_event(self.ev_in)             # the next upload must not overtake A1's reads
-    prev, self.pending = self.pending, par
+    prev, self.pending = self.handle, par
     self.k += 1
-    return None if prev is None else self._read(prev)
+    if prev is not None:
+      prev.resolve()   # (its snapshot slot is the one the NEXT step publishes into)
+    self.handle = LazyMetrics(self.keys, lambda: self._read(par))
+    return self.handle
 
   def tune(self, run_step, force=False):
     """Finish the stream-pair selection now (instead of inside the next train calls):
@@ -380,8 +480,8 @@ class Pipeline:
     """Wait for everything in flight; returns the last step's metrics (or None)."""
     mets = None
     if self.pending is not None:
-      mets = self._read(self.pending)
-      self.pending = None
+      mets = self.handle.resolve()
+      self.pending = self.handle = None
     cur = torch.cuda.current_stream(self.device)
     cur.wait_stream(self.s1)
     cur.wait_stream(self.s2)
@@ -595,12 +695,10 @@ class Agent:
     if self._pipeline and self._train_calls >= 1 and 'key' not in data:
       if self._pipe is None:
         self._pipe = Pipeline(L, self.device, self.comm_m)
+        self._pipe.keys = tuple(self._last_metrics)   # (the first call of a learner is eager)
         self._plan = self._pipe
-      metrics = self._pipe.step()   # metrics of the previous step
+      metrics = self._last_metrics = self._pipe.step()   # this call's metrics, fetched lazily
       self._train_calls += 1
-      if metrics is None:
-        metrics = self._last_metrics
-      self._last_metrics = metrics
       return {}, TrainState(L), metrics
     self.flush()
     if self._use_graph and self._train_calls >= 1:
@@ -638,8 +736,8 @@ class Agent:
     return box[0]
 
   def flush(self):
-    """Drain the two-stream pipeline (no-op otherwise); returns the metrics of the
-    last step if they had not been handed out yet."""
+    """Drain the two-stream pipeline (no-op otherwise); returns the (fetched) metrics of the
+    last step if one was still in flight."""
     if self._pipe is None:
       return None
     mets = self._pipe.flush()

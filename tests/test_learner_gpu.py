@@ -582,7 +582,7 @@ def test_training_reduces_loss_through_agent(hip):
     assert helpers.metrics_finite(mets), i
     first = first if first is not None else float(mets['model_loss'])
     last = float(mets['model_loss'])
-  mets = ag.flush() or mets  # pipelined: train() hands out the previous step's metrics
+  mets = ag.flush() or mets
   last = float(mets['model_loss'])
   assert ag._plan is not None and ag._plan.n_graphs >= 2   # replayed from HIP graphs
   assert last < 0.9 * first, (first, last)
@@ -628,7 +628,8 @@ def test_pipelined_steps_equal_sequential(hip):
   """hip.pipeline: step k's behaviour phase (imagination, critic, actor) runs on a second
   stream next to step k+1's world-model phase.  Same arithmetic in the same order inside
   each phase => parameters, optimizer moments and controller state after n steps are
-  bit-identical to the sequential schedule; metrics arrive one call late."""
+  bit-identical to the sequential schedule, and every call returns its own metrics (lazily: a
+  LazyMetrics that is fetched when looked at, or when the next call has been enqueued)."""
   import numpy as np
   from daydreamer_amd import agent as agent_mod, synthetic
   cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=6, replay_chunk=8, imag_horizon=4)
@@ -641,11 +642,18 @@ def test_pipelined_steps_equal_sequential(hip):
     for i in range(9):
       # (call 5 starts from the initial state again: reset_carry next to work in flight)
       _, state, m = ag.train(batches[i % 4], None if i == 5 else state)
+      if mode and i >= 1:
+        assert isinstance(m, agent_mod.LazyMetrics) and not m.resolved    # train() did not wait for the step
+        if len(mets) >= 2 and isinstance(mets[-1], agent_mod.LazyMetrics):
+          assert mets[-1].resolved                                         # fetched when this call was enqueued
+        if i == 3:
+          assert float(m['model_loss']) == float(m['model_loss_mean']) and m.resolved   # looked at right away
       mets.append(m)
     last = ag.flush()
     if mode:
       assert isinstance(ag._plan, agent_mod.Pipeline) and last is not None
-      mets = mets[:1] + mets[2:] + [last]   # call i >= 2 returned step i-1; call 1 repeated step 0
+      assert dict(last) == dict(mets[-1])
+      mets = [dict(m) for m in mets]
     runs[mode] = (ag.save(), mets)
   (sa, ma), (sb, mb) = runs[False], runs[True]
   assert sa.keys() == sb.keys()
