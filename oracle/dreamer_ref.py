@@ -5,13 +5,17 @@ DreamerV2+ learner step of danijar/daydreamer.  Only `tests/`, `bench.py`'s
 `cpu_baseline` leg and `__graft_entry__.smoke()` may import this module; the
 product package `daydreamer_amd` never does.
 
-PARITY UNPINNED: the reference holds no golden vectors / known-answer tests for
-this path (all its agent tests are timing smoke tests on zeros; sampling uses
-seed=None, weight init is unseeded), and TensorFlow / TFP / sonnet are not
-installable here, so this restatement cannot be checked against the reference's
-own outputs.  It follows the reference source line by line instead; every
-function cites the file:line it restates (paths relative to
-/root/reference/embodied/agents/dreamerv2plus/).
+PARITY: the reference holds no golden vectors / known-answer tests for this path (all its agent
+tests are timing smoke tests on zeros; sampling uses seed=None, weight init is unseeded), and
+TensorFlow / TFP / sonnet are not installable here.  This restatement follows the reference
+source line by line - every function cites the file:line it restates (paths relative to
+/root/reference/embodied/agents/dreamerv2plus/) - and is PINNED TO THE REFERENCE'S OWN SOURCES
+EXECUTED ON A TENSORFLOW STAND-IN: tests/golden/make_reference_golden.py imports agent.py,
+nets.py, tfutils.py, tfagent.py and behaviors.py unmodified and runs two Agent.train calls on
+oracle/tf_on_torch.py (the tf / tfd / snt primitives those files reach, on torch, float64);
+tests/test_reference_golden.py holds this module to every metric, drawn class, per-parameter
+gradient, updated parameter and controller state of those runs at 1e-9 (4 cases).  Not pinned
+by that: TensorFlow's own numerics under the primitives, i.e. the documented semantics below.
 
 TF/TFP semantics assumed from documentation (falsify these if TF is available).  Each one is
 pinned WITHOUT PyTorch by a loop-form numpy / scalar restatement written from the documented
@@ -213,14 +217,17 @@ class AutoAdapt:
   """tfutils.py:414-482 ('fixed', 'mult' and 'prop' impls)."""
 
   def __init__(self, shape, impl, scale, target, min, max, vel=0.1,
-               thres=0.1, inverse=False):
+               thres=0.1, inverse=False, dtype=torch.float32):
+    """dtype: the scale is a float32 variable in the reference (:430-432); the comparison with the
+    reference's sources run in float64 (tests/test_reference_golden.py) keeps it in float64."""
     self.shape = tuple(shape)
     self.impl, self.target, self.min, self.max = impl, target, min, max
     self.vel, self.thres, self.inverse = vel, thres, inverse
+    self.dtype = dtype
     if impl == 'fixed':
-      self.scale = torch.tensor(float(scale), dtype=torch.float32)
+      self.scale = torch.tensor(float(scale), dtype=dtype)
     elif impl in ('mult', 'prop'):
-      self.scale = torch.ones(self.shape, dtype=torch.float32)  # :430-432
+      self.scale = torch.ones(self.shape, dtype=dtype)  # :430-432
     else:
       raise NotImplementedError(impl)
 
@@ -239,7 +246,7 @@ class AutoAdapt:
     if self.impl == 'fixed':
       return
     dims = list(range(reg.dim() - len(self.shape)))
-    avg = reg.detach().mean(dims).float()
+    avg = reg.detach().mean(dims).to(self.dtype)
     if self.impl == 'prop':  # :475-480
       direction = avg - self.target
       if self.inverse:
@@ -252,9 +259,9 @@ class AutoAdapt:
       below, above = above, below
     inside = ~below & ~above
     adjusted = (
-        above.float() * self.scale * (1 + self.vel) +
-        below.float() * self.scale / (1 + self.vel) +
-        inside.float() * self.scale)
+        above.to(self.dtype) * self.scale * (1 + self.vel) +
+        below.to(self.dtype) * self.scale / (1 + self.vel) +
+        inside.to(self.dtype) * self.scale)
     self.scale = torch.clamp(adjusted, self.min, self.max)
 
 
@@ -588,7 +595,7 @@ class RefAgent:
   actor trained by backprop through the imagined rollout."""
 
   def __init__(self, cfg, obs_shapes, act_dim, params, dtype=torch.float64,
-               act_discrete=False):
+               act_discrete=False, ctrl_dtype=torch.float32):
     """cfg: nested dict as in configs.yaml; obs_shapes: name->shape tuple of
     the observation space (without batch dims); params: name->array.
     act_discrete: one-hot action space -> 'onehot' actor trained by REINFORCE
@@ -617,7 +624,7 @@ class RefAgent:
     self.dec_mlp = {k: v for k, v in s_dec.items()
                     if re.match(dec['mlp_keys'], k) and len(v) == 1}
     self.rssm = RSSM(self.p, **cfg['rssm'])
-    self.wmkl = AutoAdapt((), **cfg['wmkl'], inverse=False)  # agent.py:155
+    self.wmkl = AutoAdapt((), **cfg['wmkl'], inverse=False, dtype=ctrl_dtype)  # agent.py:155
     self.model_opt = Optimizer('model', **cfg['model_opt'])
     self.actor_opt = Optimizer('actor', **cfg['actor_opt'])
     self.critic_opt = Optimizer('critic', **cfg['critic_opt'])
@@ -626,7 +633,7 @@ class RefAgent:
     self.scorenorm = Normalize(**cfg['scorenorm'])  # agent.py:304-305
     # agent.py:306-308: per-dimension scale for continuous, scalar for discrete
     self.actent = AutoAdapt(() if act_discrete else (act_dim,), **cfg['actent'],
-                            inverse=True)
+                            inverse=True, dtype=ctrl_dtype)
     self.slow_updates = -1  # agent.py:393
     self.last = {}
 

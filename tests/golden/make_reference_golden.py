@@ -1,0 +1,243 @@
+"""Generates tests/golden/reference_{debug,onehot,resnet,decay}.npz by EXECUTING THE REFERENCE'S OWN
+SOURCES - /root/reference/embodied/agents/dreamerv2plus/{agent,nets,tfutils,tfagent,behaviors}.py,
+imported unmodified from where they lie - on the tf-on-torch stand-in of oracle/tf_on_torch.py
+(TensorFlow / TFP / sonnet cannot be installed in this container; that module's header says exactly
+what is the reference's code and what is substituted library).  Two consecutive `Agent.train`
+calls of the reference agent on the tiny seeded problems of make_golden.py, in float64, with
+
+  * this package's deterministic initial parameters assigned into the reference's variables (the
+    reference initialises from unseeded np.random; the module tree is walked and every trainable
+    variable must be matched by name and shape - so the fixture need not store ~3 M weights),
+  * the categorical / normal draws taken from the device RNG's uniforms / normals
+    (make_golden.golden_noise) by inverse CDF, in the order the reference's code asks for them,
+
+and recorded: every metric the reference returns, the gradient the reference's tape hands to each
+of its three optimizers (sum and |sum| per parameter, a few in full), the drawn classes, the
+parameters after each step (sum / |sum| per parameter, a few in full) and the optimizer / controller
+variables.  tests/test_reference_golden.py holds the float64 oracle (and through it the HIP path)
+to these numbers.  Needs /root/reference: run here, commit the .npz.
+
+  python tests/golden/make_reference_golden.py [case ...]
+"""
+
+import importlib.util
+import io
+import contextlib
+import pathlib
+import sys
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+REF = pathlib.Path('/root/reference')
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+
+_spec = importlib.util.spec_from_file_location('make_golden', HERE / 'make_golden.py')
+mg = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(mg)
+
+from daydreamer_amd import synthetic  # noqa: E402
+from oracle import tf_on_torch as tft  # noqa: E402
+
+# case -> (make_golden case it shares problem and noise with, extra config overrides)
+CASES = dict(
+    debug=('debug', {}),
+    onehot=('onehot', {}),
+    resnet=('resnet', {}),
+    # weight decay on kernels, gradient clipping that bites, GAE returns
+    # (the debug block's `.*\.wd: 0.0` is a prefix match: it also turns wd_pattern into '0.0')
+    decay=('debug', {'model_opt.wd': 1e-2, 'actor_opt.wd': 1e-2, 'critic_opt.wd': 1e-2,
+                     'model_opt.wd_pattern': 'kernel', 'actor_opt.wd_pattern': 'kernel',
+                     'critic_opt.wd_pattern': 'kernel', 'model_opt.clip': 5.0, 'critic_return': 'gae',
+                     'actor_return': 'gae'}))
+FULL_GRADS = ('rssm/initial_deter', 'rssm/obs_stats/bias', 'reward/dist_out/out/kernel',
+              'rssm/gru_out/norm/scale', 'critic/dist_out/out/kernel', 'actor/dist_out/out/kernel',
+              'actor/dist_out/std/kernel')
+FULL_PARAMS = ('rssm/img_in/norm/scale', 'critic/dist_out/out/kernel', 'critic_target/dist_out/out/kernel',
+               'rssm/initial_deter', 'actor/dense0/norm/bias')
+
+
+def build(case):
+  base, over = CASES[case]
+  c = dict(mg.CONFIG)
+  pover, cover = mg.CASES[base]
+  import helpers
+  cfg = helpers.make_config(c.pop('blocks'), **c)
+  if cover:
+    cfg = cfg.update(cover)
+  if over:
+    cfg = cfg.update(over)
+  return base, helpers.make_problem(cfg, **{**mg.PROBLEM, **pover})
+
+
+def _flat(d, prefix=''):
+  out = {}
+  for k, v in d.items():
+    if isinstance(v, dict):
+      out.update(_flat(v, f'{prefix}{k}.'))
+    else:
+      out[prefix + k] = v
+  return out
+
+
+def reference_modules():
+  tft.install()
+  sys.argv[0] = str(REF / 'embodied/agents/dreamerv2plus/train.py')   # (agent.py reads configs.yaml next to it)
+  for p in (str(REF), str(REF / 'embodied/agents')):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  import embodied
+  import dreamerv2plus.agent as ref_agent
+  return embodied, ref_agent
+
+
+def reference_config(embodied, ref_agent, plain):
+  """The reference's `defaults` with every key this package's config also has set to our value."""
+  config = embodied.Config(ref_agent.Agent.configs['defaults'])
+  ours = {k: v for k, v in _flat({k: v for k, v in plain.items() if k != 'hip'}).items()}
+  known = config.flat
+  missing = sorted(k for k in ours if k not in known)
+  assert not missing, f'keys of our config the reference does not have: {missing}'
+  config = config.update({k: (list(v) if isinstance(v, tuple) else v) for k, v in ours.items()})
+  return config.update({'tf.platform': 'cpu', 'tf.precision': 'float32', 'tf.jit': False,
+                        'expl_behavior': 'None', 'task_behavior': 'Greedy'})
+
+
+def variable_map(agent):
+  """our parameter name -> the reference's tf.Variable, by walking its module tree."""
+  out = {}
+  def collect(module, prefix):
+    for name, child in module._modules.items():
+      if isinstance(child, tft.Variable):
+        assert f'{prefix}/{name}' not in out
+        out[f'{prefix}/{name}'] = child
+      else:
+        collect(child, f'{prefix}/{name}')
+    norm = module.__dict__.get('_norm')
+    if isinstance(norm, tft.SntModule):
+      collect(norm, f'{prefix}/norm')
+  wm = agent.wm
+  for net, prefix in ((wm.encoder, 'enc'), (wm.heads['decoder'], 'dec')):
+    for attr in ('_cnn', '_mlp'):
+      if attr in net.__dict__:
+        collect(net.__dict__[attr], f'{prefix}/{attr[1:]}')
+  collect(wm.rssm, 'rssm')
+  collect(wm.heads['reward'], 'reward')
+  collect(wm.heads['cont'], 'cont')
+  ac = agent.task_behavior.ac
+  collect(ac.actor, 'actor')
+  critic = ac.critics['extr']
+  collect(critic.net, 'critic')
+  collect(critic.target_net, 'critic_target')
+  return out
+
+
+def feed_items(noise, T, H, discrete):
+  items = []
+  for t in range(T):
+    items.append(('uniform', f'obs_prior/{t}', noise['u_obs_prior'][t]))
+    items.append(('uniform', f'obs_post/{t}', noise['u_obs_post'][t]))
+  act = (lambda t: ('uniform', f'act/{t}', noise['u_act'][t])) if discrete else \
+        (lambda t: ('normal', f'act/{t}', noise['eps_act'][t]))
+  items.append(act(0))
+  for h in range(H):
+    items.append(('uniform', f'img/{h}', noise['u_img'][h]))
+    items.append(act(h + 1))
+  return items
+
+
+def generate(case, verbose=True):
+  base, (plain, sp, shapes, params, data, B, T) = build(case)
+  H, G, A = plain['imag_horizon'], sp.groups, sp.act_dim
+  discrete = bool(mg.CASES[base][0].get('discrete', False))
+  embodied, ref_agent = reference_modules()
+  config = reference_config(embodied, ref_agent, plain)
+  obs, act = synthetic.make_spaces(mg.PROBLEM['image'], mg.PROBLEM['vector'],
+                                   mg.CASES[base][0].get('action', mg.PROBLEM['action']))
+  obs_space = {k: embodied.Space(v.dtype, v.shape) for k, v in obs.items()}
+  act_space = {'action': embodied.Space(np.float32, (A,), -1.0 if not discrete else 0.0, 1.0)}
+  act_space['action'].discrete = discrete
+  batch = {k: v for k, v in data.items() if k in obs_space or k == 'action'}
+
+  tft.VARIABLES.clear()
+  np.random.seed(0)
+  quiet = contextlib.redirect_stdout(io.StringIO()) if not verbose else contextlib.nullcontext()
+  with quiet:
+    agent = ref_agent.Agent(obs_space, act_space, embodied.Counter(), config)
+    # one throw-away call creates every variable (the reference builds them lazily) ...
+    tft.FEED.load(feed_items(mg.golden_noise(B, T, H, G, A, 99), T, H, discrete))
+    agent.train(batch, None)
+  assert not tft.FEED.items
+  # ... then every variable goes back to its initial value (optimizer steps and moments,
+  # AutoAdapt scales, Normalize moments, the slow critic's counter) and the trainable ones get
+  # this package's deterministic initial parameters
+  for v in tft.VARIABLES:
+    v.reset()
+  vmap = variable_map(agent.agent)
+  trainable = {id(v) for v in tft.VARIABLES if v.trainable and v.dtype.is_floating_point
+               and not v.name.split('/')[-1].startswith(('m_', 'v_'))}
+  mapped = {id(v) for v in vmap.values()}
+  stray = [v.name for v in tft.VARIABLES if id(v) in trainable - mapped
+           and not any(s in v.name for s in ('AutoAdapt', 'Normalize', 'Optimizer'))]
+  assert not stray, f'reference variables without a counterpart: {stray}'
+  assert set(vmap) == set(params), (sorted(set(vmap) ^ set(params)))
+  for name, var in vmap.items():
+    assert tuple(var.shape) == tuple(params[name].shape), (name, tuple(var.shape), params[name].shape)
+    var.assign(params[name])
+  names = {var.name: name for name, var in vmap.items()}
+
+  out = {}
+  state = None
+  for step in (1, 2):
+    noise = mg.golden_noise(B, T, H, G, A, step)
+    tft.FEED.load(feed_items(noise, T, H, discrete))
+    tft.FEED.draws.clear()
+    tft.GradientTape.LOG.clear()
+    with quiet:
+      _, state, mets = agent.train(batch, state)
+    # (a tf.GradientTape only records inside its `with` block: the state handed to the next call
+    # is a constant there; torch autograd is always on, so cut it here)
+    state = tft.nest_map(tft.stop_gradient, state)
+    assert not tft.FEED.items and len(tft.GradientTape.LOG) == 3
+    for k, v in mets.items():
+      out[f's{step}/metric/{k}'] = np.float64(v)
+    draws = dict(tft.FEED.draws)
+    out[f's{step}/idx_prior'] = np.stack([draws[f'obs_prior/{t}'].reshape(B, G) for t in range(T)])
+    out[f's{step}/idx_post'] = np.stack([draws[f'obs_post/{t}'].reshape(B, G) for t in range(T)])
+    out[f's{step}/idx_img'] = np.stack([draws[f'img/{h}'].reshape(B * T, G) for h in range(H)])
+    if discrete:
+      out[f's{step}/idx_act'] = np.stack([draws[f'act/{t}'].reshape(B * T) for t in range(H + 1)])
+    for log in tft.GradientTape.LOG:     # model, critic, actor - in the order the reference updates
+      for vname, g in log.items():
+        out[f's{step}/gradsum/{names[vname]}'] = np.array([g.sum(), np.abs(g).sum()])
+        if names[vname] in FULL_GRADS:
+          out[f's{step}/grad/{names[vname]}'] = g
+    for name, var in vmap.items():
+      p = var.numpy()
+      out[f's{step}/paramsum/{name}'] = np.array([p.sum(), np.abs(p).sum()])
+      if name in FULL_PARAMS:
+        out[f's{step}/param/{name}'] = p.copy()
+    for k, v in state.items():
+      out[f's{step}/state/{k}'] = np.array(v.numpy() if hasattr(v, 'numpy') else v)
+    ac = agent.agent.task_behavior.ac
+    # (np.array: .numpy() of a variable is a live view of its storage)
+    out[f's{step}/ctrl/wmkl_scale'] = np.array(agent.agent.wm.wmkl.scale().numpy())
+    out[f's{step}/ctrl/actent_scale'] = np.array(ac.actent.scale().numpy())
+    for nm, norm in (('advnorm', ac.advnorm), ('retnorm', ac.retnorms['extr']),
+                     ('scorenorm', ac.scorenorms['extr'])):
+      out[f's{step}/ctrl/{nm}'] = np.array([norm._mean.numpy(), norm._sqrs.numpy(), norm._step.numpy()],
+                                           np.float64)
+    out[f's{step}/ctrl/slow_updates'] = np.array(ac.critics['extr'].updates.numpy())
+  path = HERE / f'reference_{case}.npz'
+  np.savez_compressed(path, **out)
+  print('wrote', path, path.stat().st_size, 'bytes;', len(out), 'arrays; model_loss',
+        float(out['s1/metric/model_loss_mean']), float(out['s2/metric/model_loss_mean']))
+  return out
+
+
+if __name__ == '__main__':
+  assert REF.exists(), 'needs the reference checkout at /root/reference'
+  for case_ in (sys.argv[1:] or list(CASES)):
+    generate(case_, verbose=False)

@@ -45,8 +45,10 @@ def test_oracle_reproduces_golden(case):
       assert np.array_equal(ag.last['traj']['action'].argmax(-1).numpy(), GOLD[f's{step}/idx_act'])
 
 
-def check_learner(L, data, mtol, gtol, exact_idx, case='debug'):
-  GOLD = GOLDS[case]
+def check_learner(L, data, mtol, gtol, exact_idx, case='debug', gold=None):
+  """gold: another fixture with the same layout (tests/test_reference_golden.py: the vectors made
+  by running the reference's own sources)."""
+  GOLD = GOLDS[case] if gold is None else gold
   B, T, N, H, D, F, G, C = L.B, L.T, L.N, L.H, L.D, L.F, L.G, L.C
   for step in (1, 2):
     L.upload(data)

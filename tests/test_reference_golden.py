@@ -1,0 +1,169 @@
+"""The oracle against THE REFERENCE'S OWN SOURCES, executed.
+
+tests/golden/reference_*.npz were produced by importing the reference's agent.py / nets.py /
+tfutils.py / tfagent.py / behaviors.py unmodified from /root/reference and running two consecutive
+`Agent.train` calls on a TensorFlow stand-in (oracle/tf_on_torch.py: every tf / tfd / sonnet
+primitive the sources reach, written on torch from the TensorFlow documentation; float64; draws by
+inverse CDF from injected uniforms) - tests/golden/make_reference_golden.py, run in the container
+that holds the reference.  So every line the reference WROTE is in the loop here: module wiring,
+scan, stop-gradients, the straight-through sample, KL balance, loss scales, lambda-returns (gve and
+gae), Normalize, AutoAdapt, the hand-written Adam with clip / weight decay, the slow
+critic and the order of the three updates; what is not is the library underneath the primitives
+(pinned separately, without torch, in tests/test_oracle_pins.py and test_oracle_independent.py).
+
+Cases: continuous actions with the actor trained by backprop (`debug`), one-hot actions with
+REINFORCE (`onehot`), residual encoder / decoder (`resnet`), and `decay` = weight decay on kernels,
+a gradient clip that bites and GAE returns.  The float64 oracle
+(oracle/dreamer_ref.RefAgent) must reproduce, from the same initial parameters, data and noise:
+every metric the reference returned (1e-9), the classes it drew (exactly), the gradient its tape
+handed to each optimizer (1e-9 of the gradient's |sum|), the parameters after each of the two steps
+and the controller state (AutoAdapt scales, Normalize moments, slow-critic counter).  The HIP path
+is held to the oracle elsewhere (tests/test_golden.py, test_learner_gpu.py), and to these vectors
+directly in test_hip_path_matches_reference_run.
+"""
+
+import importlib.util
+import pathlib
+
+import numpy as np
+import pytest
+import torch
+
+HERE = pathlib.Path(__file__).parent
+_spec = importlib.util.spec_from_file_location('make_reference_golden', HERE / 'golden' / 'make_reference_golden.py')
+mrg = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(mrg)
+mg = mrg.mg
+from oracle import dreamer_ref  # noqa: E402
+
+CASES = list(mrg.CASES)
+GOLDS = {c: np.load(HERE / 'golden' / f'reference_{c}.npz') for c in CASES}
+# metrics of the reference's mixed-precision bookkeeping do not exist in float32 mode
+SKIP = ('_grad_scale', '_grad_overflow')
+
+
+def _oracle(case):
+  base, (plain, sp, shapes, params, data, B, T) = mrg.build(case)
+  discrete = bool(mg.CASES[base][0].get('discrete', False))
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64,
+                            act_discrete=discrete, ctrl_dtype=torch.float64)
+  return ag, plain, sp, data, B, T, discrete
+
+
+def _close(a, b, tol, what):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  assert a.shape == b.shape, (what, a.shape, b.shape)
+  if np.isnan(b).any():
+    assert np.array_equal(np.isnan(a), np.isnan(b)), what
+    a, b = np.nan_to_num(a), np.nan_to_num(b)
+  err = np.abs(a - b).max() if a.size else 0.0
+  assert err <= tol * max(1.0, np.abs(b).max() if b.size else 0.0), (what, float(err))
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_reproduces_the_reference_run(case):
+  GOLD = GOLDS[case]
+  ag, plain, sp, data, B, T, discrete = _oracle(case)
+  H, G, A = plain['imag_horizon'], sp.groups, sp.act_dim
+  dreamer_ref.SAMPLE_STATS.update(draws=0, adopted=0, max_gap=0.0)
+  state, n_metrics, n_grads = None, 0, 0
+  for step in (1, 2):
+    noise = mg.golden_noise(B, T, H, G, A, step)
+    forced = dict(obs_prior=GOLD[f's{step}/idx_prior'], obs_post=GOLD[f's{step}/idx_post'],
+                  img=GOLD[f's{step}/idx_img'])
+    if discrete:
+      forced['act'] = GOLD[f's{step}/idx_act']
+    _, state, mets = ag.train(data, noise, state, forced=forced)
+    # ---- the classes the reference drew
+    assert np.array_equal(ag.last['wm']['idxs']['prior'].numpy(), GOLD[f's{step}/idx_prior'])
+    assert np.array_equal(ag.last['wm']['idxs']['post'].numpy(), GOLD[f's{step}/idx_post'])
+    assert np.array_equal(ag.last['traj']['idx'].numpy(), GOLD[f's{step}/idx_img'])
+    if discrete:
+      assert np.array_equal(ag.last['traj']['action'].argmax(-1).numpy(), GOLD[f's{step}/idx_act'])
+    # ---- every metric the reference returned
+    ref_keys = [k[len(f's{step}/metric/'):] for k in GOLD.files if k.startswith(f's{step}/metric/')]
+    ref_keys = [k for k in ref_keys if not k.endswith(SKIP)]
+    missing = [k for k in ref_keys if k not in mets]
+    assert not missing, f'metrics the reference returns and the oracle does not: {missing}'
+    extra = [k for k in mets if k not in ref_keys]
+    assert not extra, f'metrics the oracle returns and the reference does not: {extra}'
+    for k in ref_keys:
+      _close(float(mets[k]), float(GOLD[f's{step}/metric/{k}']), 1e-9, (step, 'metric', k))
+      n_metrics += 1
+    # ---- the gradient the reference's tape handed to each optimizer
+    grads = ag.last['grads']
+    gkeys = [k[len(f's{step}/gradsum/'):] for k in GOLD.files if k.startswith(f's{step}/gradsum/')]
+    assert sorted(gkeys) == sorted(grads), sorted(set(gkeys) ^ set(grads))
+    for name in gkeys:
+      ref = GOLD[f's{step}/gradsum/{name}']
+      g = grads[name].numpy()
+      assert abs(g.sum() - ref[0]) <= 1e-9 * max(ref[1], 1e-30), (step, 'grad sum', name)
+      assert abs(np.abs(g).sum() - ref[1]) <= 1e-9 * max(ref[1], 1e-30), (step, 'grad |sum|', name)
+      n_grads += 1
+    for k in [k for k in GOLD.files if k.startswith(f's{step}/grad/')]:
+      name = k[len(f's{step}/grad/'):]
+      _close(grads[name].numpy(), GOLD[k], 1e-9, (step, 'grad', name))
+    # ---- parameters after the step (Adam, clip, decay, slow critic)
+    now = ag.export_params()
+    for k in [k for k in GOLD.files if k.startswith(f's{step}/paramsum/')]:
+      name = k[len(f's{step}/paramsum/'):]
+      p = np.asarray(now[name], np.float64)
+      assert abs(p.sum() - GOLD[k][0]) <= 1e-10 * max(GOLD[k][1], 1e-30), (step, 'param sum', name)
+      assert abs(np.abs(p).sum() - GOLD[k][1]) <= 1e-10 * max(GOLD[k][1], 1e-30), (step, 'param |sum|', name)
+    for k in [k for k in GOLD.files if k.startswith(f's{step}/param/')]:
+      _close(now[k[len(f's{step}/param/'):]], GOLD[k], 1e-11, (step, k))
+    # ---- the carried state and the controllers
+    for k in ('deter', 'stoch', 'logit'):
+      _close(state[k].detach().numpy(), GOLD[f's{step}/state/{k}'], 1e-9, (step, 'state', k))
+    _close(ag.wmkl.scale.numpy(), GOLD[f's{step}/ctrl/wmkl_scale'], 1e-12, (step, 'wmkl scale'))
+    _close(ag.actent.scale.numpy(), GOLD[f's{step}/ctrl/actent_scale'], 1e-12, (step, 'actent scale'))
+    for nm in ('advnorm', 'retnorm', 'scorenorm'):
+      n = getattr(ag, nm)
+      _close([float(n.mean), float(n.sqrs), float(n.step)], GOLD[f's{step}/ctrl/{nm}'], 1e-9, (step, nm))
+    assert int(ag.slow_updates) == int(GOLD[f's{step}/ctrl/slow_updates']), step
+  assert n_metrics >= 2 * 55 and n_grads >= 2 * 100, (n_metrics, n_grads)
+  # the draws are the oracle's own (same inverse-CDF rule on the same float64 probabilities):
+  # nothing had to be adopted from the reference run
+  assert dreamer_ref.SAMPLE_STATS['adopted'] == 0, dreamer_ref.SAMPLE_STATS
+
+
+def _learner(case, ops, device, dtype):
+  from daydreamer_amd import learner as LM
+  base, (plain, sp, shapes, params, data, B, T) = mrg.build(case)
+  L = LM.Learner(sp, ops, device, B, T, params=params, noise_seed=mg.NOISE_SEED, dtype=dtype)
+  return base, L, data
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_learner_host_logic_matches_the_reference_run(case):
+  """The product's learner (its phase orchestration, hoisting, deferred weight gradients, flat
+  optimizer arenas, device RNG) on the CPU restatement of the kernels in float64, against the
+  reference run: same draws, metrics and per-parameter gradients."""
+  from oracle import ref_ops
+  from test_golden import check_learner
+  base, L, data = _learner(case, ref_ops.RefOps('cpu'), 'cpu', torch.float64)
+  check_learner(L, data, 1e-6, 1e-6, True, base, gold=GOLDS[case])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CASES)
+def test_hip_path_matches_reference_run(hip, case):
+  """The HIP kernels (fp32 contractions on the split-bf16 matrix pipe) against the reference run:
+  every class drawn as the reference's sources drew it, metrics to 1e-3, gradients to 1e-3 of
+  their |sum|, over two learner steps."""
+  from test_golden import check_learner
+  base, L, data = _learner(case, hip, 'cuda:0', torch.float32)
+  check_learner(L, data, 1e-3, 1e-3, False, base, gold=GOLDS[case])
+
+
+def test_fixtures_cover_what_the_cases_claim():
+  """decay: the clip bites, decayed kernels shrink;
+  onehot: REINFORCE case has discrete action draws; gae / gve returns differ."""
+  d, g = GOLDS['decay'], GOLDS['debug']
+  assert float(d['s1/metric/model_grad_norm']) > 5.0            # model_opt.clip = 5 is active
+  assert float(d['s1/metric/model_grad_norm']) == pytest.approx(float(g['s1/metric/model_grad_norm']), rel=1e-12)
+  assert abs(float(d['s1/paramsum/rssm/img_in/kernel'][1]) - float(g['s1/paramsum/rssm/img_in/kernel'][1])) > 1e-9
+  assert float(d['s1/metric/extr_imag_return_mean']) != float(g['s1/metric/extr_imag_return_mean']) or \
+      float(d['s1/metric/extr_score_mean']) != float(g['s1/metric/extr_score_mean'])
+  assert 's1/idx_act' in GOLDS['onehot'].files and 's1/idx_act' not in g.files
+  assert int(g['s2/ctrl/slow_updates']) == 2 and float(g['s2/ctrl/advnorm'][2]) == 2.0
