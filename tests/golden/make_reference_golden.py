@@ -59,19 +59,6 @@ FULL_PARAMS = ('rssm/img_in/norm/scale', 'critic/dist_out/out/kernel', 'critic_t
                'rssm/initial_deter', 'actor/dense0/norm/bias')
 
 
-def build(case):
-  base, over = CASES[case]
-  c = dict(mg.CONFIG)
-  pover, cover = mg.CASES[base]
-  import helpers
-  cfg = helpers.make_config(c.pop('blocks'), **c)
-  if cover:
-    cfg = cfg.update(cover)
-  if over:
-    cfg = cfg.update(over)
-  return base, helpers.make_problem(cfg, **{**mg.PROBLEM, **pover})
-
-
 def _flat(d, prefix=''):
   out = {}
   for k, v in d.items():
@@ -148,8 +135,22 @@ def feed_items(noise, T, H, discrete):
   return items
 
 
-def generate(case, verbose=True):
-  base, (plain, sp, shapes, params, data, B, T) = build(case)
+def build(case, batch=None, length=None, extra=None):
+  base, over = CASES[case]
+  c = dict(mg.CONFIG)
+  pover, cover = mg.CASES[base]
+  import helpers
+  cfg = helpers.make_config(c.pop('blocks'), **c)
+  for o in (cover, over, extra):
+    if o:
+      cfg = cfg.update(o)
+  return base, helpers.make_problem(cfg, batch=batch, length=length, **{**mg.PROBLEM, **pover})
+
+
+def setup(case, problem, verbose=False):
+  """The reference agent for `case` with every variable created, all state reset and this
+  package's initial parameters assigned.  Returns (agent, variable map, batch, quiet context)."""
+  base, (plain, sp, shapes, params, data, B, T) = problem
   H, G, A = plain['imag_horizon'], sp.groups, sp.act_dim
   discrete = bool(mg.CASES[base][0].get('discrete', False))
   embodied, ref_agent = reference_modules()
@@ -163,8 +164,8 @@ def generate(case, verbose=True):
 
   tft.VARIABLES.clear()
   np.random.seed(0)
-  quiet = contextlib.redirect_stdout(io.StringIO()) if not verbose else contextlib.nullcontext()
-  with quiet:
+  quiet = (lambda: contextlib.redirect_stdout(io.StringIO())) if not verbose else contextlib.nullcontext
+  with quiet():
     agent = ref_agent.Agent(obs_space, act_space, embodied.Counter(), config)
     # one throw-away call creates every variable (the reference builds them lazily) ...
     tft.FEED.load(feed_items(mg.golden_noise(B, T, H, G, A, 99), T, H, discrete))
@@ -186,6 +187,14 @@ def generate(case, verbose=True):
   for name, var in vmap.items():
     assert tuple(var.shape) == tuple(params[name].shape), (name, tuple(var.shape), params[name].shape)
     var.assign(params[name])
+  return agent, vmap, batch, quiet, discrete
+
+
+def generate(case, verbose=True):
+  problem = build(case)
+  base, (plain, sp, shapes, params, data, B, T) = problem
+  H, G, A = plain['imag_horizon'], sp.groups, sp.act_dim
+  agent, vmap, batch, quiet, discrete = setup(case, problem, verbose)
   names = {var.name: name for name, var in vmap.items()}
 
   out = {}
@@ -195,7 +204,7 @@ def generate(case, verbose=True):
     tft.FEED.load(feed_items(noise, T, H, discrete))
     tft.FEED.draws.clear()
     tft.GradientTape.LOG.clear()
-    with quiet:
+    with quiet():
       _, state, mets = agent.train(batch, state)
     # (a tf.GradientTape only records inside its `with` block: the state handed to the next call
     # is a constant there; torch autograd is always on, so cut it here)
@@ -237,7 +246,115 @@ def generate(case, verbose=True):
   return out
 
 
+# ------------------------------------------------------------------ Agent.policy / Agent.report
+
+POLICY_MODES = ('train', 'explore', 'eval', 'train')
+POLICY_EXTRA = {'expl_noise': 0.2, 'eval_noise': 0.1}
+
+
+def policy_noise(n, G, A, discrete, call):
+  rng = np.random.RandomState(1000 + call)
+  noise = dict(u_prior=rng.rand(n, G), u_post=rng.rand(n, G))
+  if discrete:
+    noise.update(u_act=rng.rand(n), act_noise=rng.rand(n))
+  else:
+    noise.update(eps=rng.randn(n, A), act_noise=rng.randn(n, A))
+  return noise
+
+
+def generate_policy(case, verbose=False):
+  """reference Agent.policy (agent.py:42-65) called four times with the carried state: sampled /
+  explore / mode / sampled actions, then tfutils.action_noise with expl_noise / eval_noise."""
+  problem = build(case, batch=3, length=len(POLICY_MODES), extra=POLICY_EXTRA)
+  base, (plain, sp, shapes, params, data, B, T) = problem
+  G, A = sp.groups, sp.act_dim
+  agent, vmap, batch, quiet, discrete = setup(case, problem, verbose)
+  out, state = {}, None
+  for t, mode in enumerate(POLICY_MODES):
+    obs = {k: v[:, t] for k, v in batch.items() if k != 'action'}
+    noise = policy_noise(B, G, A, discrete, t)
+    items = [('uniform', 'prior', noise['u_prior']), ('uniform', 'post', noise['u_post'])]
+    kind = 'uniform' if discrete else 'normal'
+    if mode != 'eval':
+      items.append((kind, 'act', noise['u_act'] if discrete else noise['eps']))
+    items.append((kind, 'act_noise', noise['act_noise']))
+    tft.FEED.load(items)
+    tft.FEED.draws.clear()
+    with quiet():
+      outs, state = agent.policy(obs, state, mode)
+    assert not tft.FEED.items
+    latent = state[0]
+    out[f'c{t}/action'] = np.array(outs['action'])
+    for k in ('deter', 'stoch', 'logit'):
+      out[f'c{t}/latent/{k}'] = np.array(latent[k].numpy())
+    out[f'c{t}/idx_post'] = dict(tft.FEED.draws)['post'].reshape(B, G)
+  path = HERE / f'reference_policy_{case}.npz'
+  np.savez_compressed(path, **out)
+  print('wrote', path, path.stat().st_size, 'bytes;', len(out), 'arrays')
+
+
+REPORT_SHAPE = dict(batch=3, length=7)
+VIDEO_STRIDE = (1, 11, 13, 1)
+
+
+def report_noise(B, T, H, G, A, n):
+  rng = np.random.RandomState(2000)
+  return dict(u_obs_prior=rng.rand(T, B, G), u_obs_post=rng.rand(T, B, G), u_openl=rng.rand(T - 5, n, G),
+              u_img=rng.rand(H, n, G), eps_act=rng.randn(H + 1, n, A), u_act=rng.rand(H + 1, n))
+
+
+def video_digest(v):
+  """Per-frame sum and |sum| plus a strided sample of a [T, H, W, C] video grid."""
+  v = np.asarray(v, np.float64)
+  s = VIDEO_STRIDE
+  return dict(shape=np.array(v.shape), sums=v.sum((1, 2, 3)), abssums=np.abs(v).sum((1, 2, 3)),
+              sample=v[::s[0], ::s[1], ::s[2], ::s[3]].copy())
+
+
+def generate_report(case, verbose=False):
+  """reference Agent.report (agent.py:95-106): WorldModel.report (loss metrics without update,
+  reconstruction + open-loop video) and Greedy.report (imagined rollout video).  The reference
+  re-observes the first five steps twice with fresh samples; the same uniforms are fed again."""
+  problem = build(case, **REPORT_SHAPE)
+  base, (plain, sp, shapes, params, data, B, T) = problem
+  H, G, A = plain['imag_horizon'], sp.groups, sp.act_dim
+  agent, vmap, batch, quiet, discrete = setup(case, problem, verbose)
+  n, ctx = min(6, B), 5
+  noise = report_noise(B, T, H, G, A, n)
+  observe = lambda steps, rows: [x for t in range(steps) for x in (
+      ('uniform', f'obs_prior/{t}', noise['u_obs_prior'][t][:rows]),
+      ('uniform', f'obs_post/{t}', noise['u_obs_post'][t][:rows]))]
+  act = (lambda t: ('uniform', f'act/{t}', noise['u_act'][t])) if discrete else \
+        (lambda t: ('normal', f'act/{t}', noise['eps_act'][t]))
+  items = observe(T, B) + observe(ctx, n) + [('uniform', f'openl/{i}', noise['u_openl'][i]) for i in range(T - ctx)]
+  items += observe(ctx, n) + [act(0)]
+  for h in range(H):
+    items += [('uniform', f'img/{h}', noise['u_img'][h]), act(h + 1)]
+  tft.FEED.load(items)
+  with quiet():
+    rep = agent.report(batch)
+  assert not tft.FEED.items
+  out = {}
+  for k, v in rep.items():
+    v = np.asarray(v)
+    if v.ndim == 4:
+      for kk, vv in video_digest(v).items():
+        out[f'video/{k}/{kk}'] = vv
+    else:
+      out[f'metric/{k}'] = np.float64(v)
+  path = HERE / f'reference_report_{case}.npz'
+  np.savez_compressed(path, **out)
+  print('wrote', path, path.stat().st_size, 'bytes;', len(out), 'arrays;', sorted(k for k in out if k.startswith('video'))[:8])
+
+
 if __name__ == '__main__':
   assert REF.exists(), 'needs the reference checkout at /root/reference'
-  for case_ in (sys.argv[1:] or list(CASES)):
-    generate(case_, verbose=False)
+  want = sys.argv[1:]
+  for case_ in CASES:
+    if not want or case_ in want:
+      generate(case_, verbose=False)
+  for case_ in ('debug', 'onehot'):
+    if not want or f'policy_{case_}' in want:
+      generate_policy(case_)
+    if not want or f'report_{case_}' in want:
+      generate_report(case_)

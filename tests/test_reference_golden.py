@@ -156,6 +156,61 @@ def test_hip_path_matches_reference_run(hip, case):
   check_learner(L, data, 1e-3, 1e-3, False, base, gold=GOLDS[case])
 
 
+@pytest.mark.parametrize('case', ('debug', 'onehot'))
+def test_oracle_policy_reproduces_the_reference_run(case):
+  """reference Agent.policy (agent.py:42-65) called four times with the carried state - sampled,
+  explore, mode, sampled action, each followed by tfutils.action_noise (expl_noise 0.2 /
+  eval_noise 0.1) - against RefAgent.policy: actions and the carried latent at 1e-9."""
+  GOLD = np.load(HERE / 'golden' / f'reference_policy_{case}.npz')
+  base, (plain, sp, shapes, params, data, B, T) = mrg.build(
+      case, batch=3, length=len(mrg.POLICY_MODES), extra=mrg.POLICY_EXTRA)
+  discrete = bool(mg.CASES[base][0].get('discrete', False))
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64,
+                            act_discrete=discrete, ctrl_dtype=torch.float64)
+  state = None
+  for t, mode in enumerate(mrg.POLICY_MODES):
+    obs = {k: v[:, t] for k, v in data.items() if k not in ('action', 'reset')}
+    noise = mrg.policy_noise(B, sp.groups, sp.act_dim, discrete, t)
+    outs, state = ag.policy(obs, state, noise, mode)
+    _close(outs['action'].numpy(), GOLD[f'c{t}/action'], 1e-9, (t, mode, 'action'))
+    for k in ('deter', 'stoch', 'logit'):
+      _close(state[0][k].numpy(), GOLD[f'c{t}/latent/{k}'], 1e-9, (t, mode, k))
+    assert np.array_equal(state[0]['stoch'].argmax(-1).numpy(), GOLD[f'c{t}/idx_post'])
+  acts = np.stack([GOLD[f'c{t}/action'] for t in range(len(mrg.POLICY_MODES))])
+  assert np.abs(acts).max() <= 1.0
+  if discrete:
+    assert ((acts == 0) | (acts == 1)).all() and (acts.sum(-1) == 1).all()
+    assert len({tuple(a.argmax(-1)) for a in acts}) > 1
+  else:
+    assert len(np.unique(acts.round(6))) > 4
+
+
+@pytest.mark.parametrize('case', ('debug', 'onehot'))
+def test_oracle_report_reproduces_the_reference_run(case):
+  """reference Agent.report (agent.py:95-106, 266-282, behaviors.py:32-46) against
+  RefAgent.report: the loss metrics without update, the reconstruction / open-loop video and the
+  imagined-rollout video (per-frame sums and a strided sample of every grid) at 1e-9."""
+  GOLD = np.load(HERE / 'golden' / f'reference_report_{case}.npz')
+  base, (plain, sp, shapes, params, data, B, T) = mrg.build(case, **mrg.REPORT_SHAPE)
+  discrete = bool(mg.CASES[base][0].get('discrete', False))
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64,
+                            act_discrete=discrete, ctrl_dtype=torch.float64)
+  noise = mrg.report_noise(B, T, plain['imag_horizon'], sp.groups, sp.act_dim, min(6, B))
+  rep = ag.report({k: v for k, v in data.items() if k != 'reset'}, noise)
+  ref_metrics = [k[len('metric/'):] for k in GOLD.files if k.startswith('metric/')]
+  ref_videos = sorted({k.split('/')[1] for k in GOLD.files if k.startswith('video/')})
+  assert sorted(rep) == sorted(ref_metrics + ref_videos), sorted(set(rep) ^ set(ref_metrics + ref_videos))
+  assert ref_videos == ['openl_image', 'task_imag_image'] and len(ref_metrics) >= 30
+  for k in ref_metrics:
+    _close(float(rep[k]), float(GOLD[f'metric/{k}']), 1e-9, ('metric', k))
+  for k in ref_videos:
+    want = {kk: GOLD[f'video/{k}/{kk}'] for kk in ('shape', 'sums', 'abssums', 'sample')}
+    got = mrg.video_digest(rep[k].numpy())
+    assert np.array_equal(got['shape'], want['shape']), (k, got['shape'], want['shape'])
+    for kk in ('sums', 'abssums', 'sample'):
+      _close(got[kk], want[kk], 1e-9, (k, kk))
+
+
 def test_fixtures_cover_what_the_cases_claim():
   """decay: the clip bites, decayed kernels shrink;
   onehot: REINFORCE case has discrete action draws; gae / gve returns differ."""
