@@ -1599,9 +1599,19 @@ class Learner:
       self.slow_updates = 0
       mix = 1.0 if init else cfg['slow_target_fraction']
       src, dst = self.groups['critic'], self.groups['critic_target']
-      assert src.n == dst.n and mix == 1.0, 'slow_target_fraction < 1'
-      # both arenas have the same layout: one flat copy
-      self.ops.copy2d(src.flat.view(1, -1), dst.flat.view(1, -1))
+      assert src.n == dst.n
+      if mix == 1.0:
+        # both arenas have the same layout: one flat copy
+        self.ops.copy2d(src.flat.view(1, -1), dst.flat.view(1, -1))
+      else:
+        # d = mix * s + (1 - mix) * d (agent.py:452-453) over the flat arenas, through a copy of
+        # d (the elementwise kernel's operands must not alias)
+        tmp = self.b.get('slow_tmp')
+        if tmp is None:
+          tmp = self.b['slow_tmp'] = torch.empty_like(dst.flat)
+        self.ops.copy2d(dst.flat.view(1, -1), tmp.view(1, -1))
+        self.ops.axpy(tmp, 1.0 - mix, None, dst.flat, accumulate=False)
+        self.ops.axpy(src.flat, mix, None, dst.flat, accumulate=True)
     self.slow_updates += 1
 
   def phase_actor(self):

@@ -51,7 +51,18 @@ CASES = dict(
     decay=('debug', {'model_opt.wd': 1e-2, 'actor_opt.wd': 1e-2, 'critic_opt.wd': 1e-2,
                      'model_opt.wd_pattern': 'kernel', 'actor_opt.wd_pattern': 'kernel',
                      'critic_opt.wd_pattern': 'kernel', 'model_opt.clip': 5.0, 'critic_return': 'gae',
-                     'actor_return': 'gae'}))
+                     'actor_return': 'gae'}),
+    # option branches: no slow critic, AutoAdapt 'prop' / 'fixed', score normalisation, other
+    # balance / discount / lambda / loss scales, reward and cont heads behind a stop-gradient
+    options=('debug', {'slow_target': False, 'wmkl.impl': 'prop', 'actent.impl': 'fixed',
+                       'scorenorm.impl': 'std', 'retnorm.impl': 'std', 'wmkl_balance': 0.5,
+                       'discount': 0.95, 'return_lambda': 0.8, 'loss_scales.kl': 0.5,
+                       'loss_scales.reward': 2.0, 'grad_heads': ['decoder'], 'rssm.unimix': 0.05}),
+    # one-hot actions: soft slow-critic updates every step, AutoAdapt the other way round,
+    # unnormalised entropy, advantage normalisation off
+    options_onehot=('onehot', {'slow_target_update': 1, 'slow_target_fraction': 0.5,
+                               'wmkl.impl': 'fixed', 'actent.impl': 'prop', 'actent_norm': False,
+                               'advnorm.impl': 'off', 'actor.unimix': 0.1}))
 FULL_GRADS = ('rssm/initial_deter', 'rssm/obs_stats/bias', 'reward/dist_out/out/kernel',
               'rssm/gru_out/norm/scale', 'critic/dist_out/out/kernel', 'actor/dist_out/out/kernel',
               'actor/dist_out/std/kernel')
@@ -117,7 +128,8 @@ def variable_map(agent):
   collect(ac.actor, 'actor')
   critic = ac.critics['extr']
   collect(critic.net, 'critic')
-  collect(critic.target_net, 'critic_target')
+  if critic.target_net is not critic.net:     # (slow_target: False -> target_net IS net, agent.py:395-396)
+    collect(critic.target_net, 'critic_target')
   return out
 
 
@@ -183,7 +195,8 @@ def setup(case, problem, verbose=False):
   stray = [v.name for v in tft.VARIABLES if id(v) in trainable - mapped
            and not any(s in v.name for s in ('AutoAdapt', 'Normalize', 'Optimizer'))]
   assert not stray, f'reference variables without a counterpart: {stray}'
-  assert set(vmap) == set(params), (sorted(set(vmap) ^ set(params)))
+  used = {k for k in params if plain['slow_target'] or not k.startswith('critic_target/')}
+  assert set(vmap) == used, (sorted(set(vmap) ^ used))
   for name, var in vmap.items():
     assert tuple(var.shape) == tuple(params[name].shape), (name, tuple(var.shape), params[name].shape)
     var.assign(params[name])
@@ -238,7 +251,8 @@ def generate(case, verbose=True):
                      ('scorenorm', ac.scorenorms['extr'])):
       out[f's{step}/ctrl/{nm}'] = np.array([norm._mean.numpy(), norm._sqrs.numpy(), norm._step.numpy()],
                                            np.float64)
-    out[f's{step}/ctrl/slow_updates'] = np.array(ac.critics['extr'].updates.numpy())
+    upd = getattr(ac.critics['extr'], 'updates', None)
+    out[f's{step}/ctrl/slow_updates'] = np.array(-1 if upd is None else upd.numpy())
   path = HERE / f'reference_{case}.npz'
   np.savez_compressed(path, **out)
   print('wrote', path, path.stat().st_size, 'bytes;', len(out), 'arrays; model_loss',
