@@ -62,10 +62,16 @@ CASES = dict(
     # unnormalised entropy, advantage normalisation off
     options_onehot=('onehot', {'slow_target_update': 1, 'slow_target_fraction': 0.5,
                                'wmkl.impl': 'fixed', 'actent.impl': 'prop', 'actent_norm': False,
-                               'advnorm.impl': 'off', 'actor.unimix': 0.1}))
+                               'advnorm.impl': 'off', 'actor.unimix': 0.1}),
+    # BASELINE.json workloads at their full network widths (batch 2 x 3, horizon 2): proprio only;
+    # image + depth + five proprio keys with a one-hot 6-way action; two 128 x 128 cameras
+    a1=('named:a1', {}),
+    xarm=('named:xarm', {}),
+    ur5_multicam=('named:ur5_multicam', {}))
 FULL_GRADS = ('rssm/initial_deter', 'rssm/obs_stats/bias', 'reward/dist_out/out/kernel',
               'rssm/gru_out/norm/scale', 'critic/dist_out/out/kernel', 'actor/dist_out/out/kernel',
               'actor/dist_out/std/kernel')
+FULL_MAX = 1024   # arrays stored in full up to this size (the carried state: strided beyond it)
 FULL_PARAMS = ('rssm/img_in/norm/scale', 'critic/dist_out/out/kernel', 'critic_target/dist_out/out/kernel',
                'rssm/initial_deter', 'actor/dense0/norm/bias')
 
@@ -147,11 +153,27 @@ def feed_items(noise, T, H, discrete):
   return items
 
 
+def spaces_of(base):
+  """(observation spaces, action spaces, discrete?) of a make_golden case or a `named:` workload."""
+  if base.startswith('named:'):
+    obs, act = synthetic.config_spaces(base[6:])
+    return obs, act, bool(getattr(act['action'], 'discrete', False))
+  pover = mg.CASES[base][0]
+  obs, act = synthetic.make_spaces(mg.PROBLEM['image'], mg.PROBLEM['vector'],
+                                   pover.get('action', mg.PROBLEM['action']))
+  return obs, act, bool(pover.get('discrete', False))
+
+
 def build(case, batch=None, length=None, extra=None):
   base, over = CASES[case]
+  import helpers
+  if base.startswith('named:'):   # a BASELINE.json workload at its full network widths, tiny batch
+    B, T = batch or mg.CONFIG['batch_size'], length or mg.CONFIG['replay_chunk']
+    plain, sp, shapes, params, data = helpers.make_named_problem(
+        base[6:], B, T, terminals=0.2, horizon=mg.CONFIG['imag_horizon'], **{**over, **(extra or {})})
+    return base, (plain, sp, shapes, params, data, B, T)
   c = dict(mg.CONFIG)
   pover, cover = mg.CASES[base]
-  import helpers
   cfg = helpers.make_config(c.pop('blocks'), **c)
   for o in (cover, over, extra):
     if o:
@@ -164,11 +186,9 @@ def setup(case, problem, verbose=False):
   package's initial parameters assigned.  Returns (agent, variable map, batch, quiet context)."""
   base, (plain, sp, shapes, params, data, B, T) = problem
   H, G, A = plain['imag_horizon'], sp.groups, sp.act_dim
-  discrete = bool(mg.CASES[base][0].get('discrete', False))
+  obs, act, discrete = spaces_of(base)
   embodied, ref_agent = reference_modules()
   config = reference_config(embodied, ref_agent, plain)
-  obs, act = synthetic.make_spaces(mg.PROBLEM['image'], mg.PROBLEM['vector'],
-                                   mg.CASES[base][0].get('action', mg.PROBLEM['action']))
   obs_space = {k: embodied.Space(v.dtype, v.shape) for k, v in obs.items()}
   act_space = {'action': embodied.Space(np.float32, (A,), -1.0 if not discrete else 0.0, 1.0)}
   act_space['action'].discrete = discrete
@@ -234,15 +254,16 @@ def generate(case, verbose=True):
     for log in tft.GradientTape.LOG:     # model, critic, actor - in the order the reference updates
       for vname, g in log.items():
         out[f's{step}/gradsum/{names[vname]}'] = np.array([g.sum(), np.abs(g).sum()])
-        if names[vname] in FULL_GRADS:
+        if names[vname] in FULL_GRADS and g.size <= FULL_MAX:
           out[f's{step}/grad/{names[vname]}'] = g
     for name, var in vmap.items():
       p = var.numpy()
       out[f's{step}/paramsum/{name}'] = np.array([p.sum(), np.abs(p).sum()])
-      if name in FULL_PARAMS:
+      if name in FULL_PARAMS and p.size <= FULL_MAX:
         out[f's{step}/param/{name}'] = p.copy()
     for k, v in state.items():
-      out[f's{step}/state/{k}'] = np.array(v.numpy() if hasattr(v, 'numpy') else v)
+      v = np.array(v.numpy() if hasattr(v, 'numpy') else v)
+      out[f's{step}/state/{k}'] = v if v.size <= FULL_MAX else v.reshape(-1)[::max(1, v.size // FULL_MAX)]
     ac = agent.agent.task_behavior.ac
     # (np.array: .numpy() of a variable is a live view of its storage)
     out[f's{step}/ctrl/wmkl_scale'] = np.array(agent.agent.wm.wmkl.scale().numpy())

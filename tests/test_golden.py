@@ -45,10 +45,12 @@ def test_oracle_reproduces_golden(case):
       assert np.array_equal(ag.last['traj']['action'].argmax(-1).numpy(), GOLD[f's{step}/idx_act'])
 
 
-def check_learner(L, data, mtol, gtol, exact_idx, case='debug', gold=None):
+def check_learner(L, data, mtol, gtol, exact_idx, case='debug', gold=None, all_metrics=False):
   """gold: another fixture with the same layout (tests/test_reference_golden.py: the vectors made
-  by running the reference's own sources)."""
+  by running the reference's own sources); all_metrics: every metric the fixture and the learner
+  both hold instead of KEYS."""
   GOLD = GOLDS[case] if gold is None else gold
+  discrete = L.discrete
   B, T, N, H, D, F, G, C = L.B, L.T, L.N, L.H, L.D, L.F, L.G, L.C
   for step in (1, 2):
     L.upload(data)
@@ -56,7 +58,7 @@ def check_learner(L, data, mtol, gtol, exact_idx, case='debug', gold=None):
     mets = L.read_metrics()
     f = helpers.forced_from_learner(L)
     sites = [('obs_post', 'idx_post'), ('obs_prior', 'idx_prior'), ('img', 'idx_img')]
-    if case == 'onehot':
+    if discrete:
       sites.append(('act', 'idx_act'))
     for nm, key in sites:
       same = (f[nm].numpy() == GOLD[f's{step}/{key}'])
@@ -64,15 +66,24 @@ def check_learner(L, data, mtol, gtol, exact_idx, case='debug', gold=None):
         assert same.all(), (step, nm)
       else:
         assert same.mean() == 1.0, f'step {step}: {nm} draws differ from golden ({same.mean():.4f} equal)'
-    for k in KEYS:
+    keys = KEYS
+    if all_metrics:
+      keys = [k[len(f's{step}/metric/'):] for k in GOLD.files if k.startswith(f's{step}/metric/')]
+      keys = [k for k in keys if k in mets]
+      assert len(keys) >= 40, len(keys)
+    for k in keys:
       g = float(GOLD[f's{step}/metric/{k}'])
+      if np.isnan(g):
+        assert np.isnan(float(mets[k])), (step, k)
+        continue
       assert abs(float(mets[k]) - g) <= mtol * max(abs(g), 1e-2), (step, k, float(mets[k]), g)
     grads = L.export_grads()
     for name, g in grads.items():
       ref = GOLD[f's{step}/gradsum/{name}']
       assert abs(g.astype(np.float64).sum() - ref[0]) <= gtol * max(ref[1], 1e-12), (step, name)
-    for k in mg.grad_keys(case):
-      assert helpers.rel_err(grads[k], GOLD[f's{step}/grad/{k}']) < gtol * 10, (step, k)
+    for k in mg.grad_keys('onehot' if discrete else 'debug'):
+      if f's{step}/grad/{k}' in GOLD.files:
+        assert helpers.rel_err(grads[k], GOLD[f's{step}/grad/{k}']) < gtol * 10, (step, k)
 
 
 @pytest.mark.parametrize('case', CASES)
