@@ -295,6 +295,13 @@ __global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b,
   if (i < n) o[i] = a[i] - b[i];
 }
 
+// o = symexp(x): the mean of a SymlogDist head (tfutils.py:345-349), for the critic's own
+// prediction on the imagined states (metrics imag_critic_mean / _std, agent.py:411-412)
+__global__ void k_symexp(const float* __restrict__ x, float* __restrict__ o, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = symexpf_(x[i]);
+}
+
 // ---- one-hot (categorical) policy head, REINFORCE (agent.py:357-358, 372-377) ----
 // wave per row; logit [rows, A] are normalised log-probs (unimix already applied).
 // ent_out[row] = H(row) / ent_div.
@@ -486,6 +493,13 @@ extern "C" int dd_sub(const float* a, const float* b, float* o, long n, void* st
   if (n <= 0) return 0;
   k_sub<<<nblk(n), 256, 0, (hipStream_t)stream>>>(a, b, o, n);
   DD_CHECK_LAUNCH("dd_sub");
+  return 0;
+}
+
+extern "C" int dd_symexp(const float* x, float* o, long n, void* stream) {
+  if (n <= 0) return 0;
+  k_symexp<<<nblk(n), 256, 0, (hipStream_t)stream>>>(x, o, n);
+  DD_CHECK_LAUNCH("dd_symexp");
   return 0;
 }
 

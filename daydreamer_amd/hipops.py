@@ -69,6 +69,7 @@ _SIGS = {
     'dd_critic_loss': [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
     'dd_actor_seed': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
     'dd_sub': [c_p, c_p, c_p, c_l, c_p],
+    'dd_symexp': [c_p, c_p, c_l, c_p],
     'dd_onehot_entropy': [c_p, c_l, c_p, c_i, c_i, c_f, c_p],
     'dd_onehot_policy_grad': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p],
     'dd_philox': [c_p, c_l, c_l, c_i, c_l, c_l, c_ull, c_p, c_u, c_i, c_p],
@@ -106,7 +107,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
-ABI_VERSION = 4   # include/daydreamer_hip.h DD_ABI_VERSION
+ABI_VERSION = 5   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -673,6 +674,10 @@ class HipOps:
     self._check(self.lib.dd_sub(
         a.data_ptr(), b.data_ptr(), o.data_ptr(), o.numel(), self.stream),
         'dd_sub')
+
+  def symexp(self, x, o):
+    assert x.is_contiguous() and o.is_contiguous() and x.numel() == o.numel()
+    self._check(self.lib.dd_symexp(x.data_ptr(), o.data_ptr(), o.numel(), self.stream), 'dd_symexp')
 
   # ---- learner state ---------------------------------------------------------------
 

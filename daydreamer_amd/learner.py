@@ -505,7 +505,7 @@ class Learner:
       plt['img_in'] = (self.P['img_in'].W, i16(U, S + A))           # [S+A, U] -> K = U, n = S+A
     for k in ('value', 'cont', 'weight', 'value2', 'ent_row'):
       b['i_' + k] = z(M)
-    for k in ('reward', 'ret', 'ret2', 'diff', 'crit_loss', 'actor_loss',
+    for k in ('reward', 'ret', 'ret2', 'diff', 'crit_loss', 'critic', 'actor_loss',
               'dret', 'dbase'):
       b['i_' + k] = z(max(H * N, 1))
     b['dom'] = z(M, A)
@@ -1582,6 +1582,8 @@ class Learner:
                     self.acts_im['critic'][1][0].dout.view(-1), 1.0 / (H * self.Ng))
     self.head_bwd('critic', self.acts_im['critic'], feat[:HN])
     self.stat('critic_loss', b['i_crit_loss'][:HN])
+    ops.symexp(cout.view(-1), b['i_critic'][:HN])     # dist.mean() of the critic's own prediction
+    self.stat('imag_critic', b['i_critic'][:HN])
     self.stat('imag_reward', b['i_reward'][:HN])
     self.stat('imag_return', b['i_ret'][:HN])
     self.stat('imag_value', b['i_value'])
@@ -1958,7 +1960,7 @@ class Learner:
     sums, maxs = host['sums'], host['maxs']
     N, H, w = self.N, self.H, self.world
     counts = dict(imag_value=(H + 1) * N * w)
-    for k in ('critic_loss', 'imag_reward', 'imag_return', 'ret2', 'diff',
+    for k in ('critic_loss', 'imag_critic', 'imag_reward', 'imag_return', 'ret2', 'diff',
               'actor_loss_score', 'actor_loss_ent', 'actent'):
       counts[k] = H * N * w
     st = {}
@@ -2005,8 +2007,8 @@ class Learner:
         mets[f'{head}_rate'] = s_[4] / n_
         mets[f'{head}_avg'] = s_[5] / n_
         mets[f'{head}_pred'] = s_[6] / n_
-    if wm_only:
-      return {k: np.asarray(v, f) for k, v in mets.items()}
+    if wm_only:   # (`model_loss` itself is the optimizer's metric, tfutils.py:209: not part of a report)
+      return {k: np.asarray(v, f) for k, v in mets.items() if k != 'model_loss'}
     for gname, pre in (('model', ''), ('critic', 'extr_'), ('actor', '')):
       o = host[f'opt_{gname}']
       mets[f'{pre}{gname}_grad_norm'] = o[1]
@@ -2021,6 +2023,8 @@ class Learner:
     mets['extr_critic_loss'] = st['critic_loss']['mean']
     mets['extr_imag_reward_mean'] = st['imag_reward']['mean']
     mets['extr_imag_reward_std'] = st['imag_reward']['std']
+    mets['extr_imag_critic_mean'] = st['imag_critic']['mean']    # agent.py:411-412
+    mets['extr_imag_critic_std'] = st['imag_critic']['std']
     mets['extr_imag_return_mean'] = st['imag_return']['mean']
     mets['extr_imag_return_std'] = st['imag_return']['std']
     sc = host['sc']

@@ -27,8 +27,8 @@ extern "C" {
 /* ABI version.  1: rounds 1-2.  2 (round 3): dd_grad_norm gained `int mixed` in front of
  * `stream` and its opt_state grew from 3 to 5 doubles - a caller built against version 1 must
  * not call it.  3 (round 4): the version was bumped for that change.  4: dd_ln_act_bwd gained
- * `beta_ln` after `gamma` (out may then be NULL); dd_gemm_set_ws added. */
-#define DD_ABI_VERSION 4
+ * `beta_ln` after `gamma` (out may then be NULL); dd_gemm_set_ws added.  5: dd_symexp added. */
+#define DD_ABI_VERSION 5
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -321,6 +321,9 @@ int dd_actor_seed(const float* ret, const float* base, const float* w, const flo
                   const float* sc, float* loss, float* dret, float* dbase, long n, float coef,
                   void* stream);
 int dd_sub(const float* a, const float* b, float* o, long n, void* stream);
+/* o = symexp(x) = sign(x) * (exp(|x|) - 1): SymlogDist.mean() (tfutils.py:345-349) of the critic's
+ * own prediction on the imagined states, metrics imag_critic_mean / _std (agent.py:411-412). */
+int dd_symexp(const float* x, float* o, long n, void* stream);
 /* One-hot policy head (nets.py:480-491) trained by REINFORCE (agent.py:357-358):
  * normalised entropy per row, and d loss / d logit of -logp(a)*sg(score) plus the
  * entropy regulariser, with score = ((ret-base)*sc[0]-sc[1])*sc[2]. */

@@ -565,6 +565,9 @@ class RefOps:
     loss_pg[:n] = wv * (-lp * score)
     loss_ent[:n] = wv * (es * -(h[:, 0] / ent_div))
 
+  def symexp(self, x, o):
+    o.copy_(_symexp(x.reshape(-1)).reshape(o.shape))
+
   def sub(self, a, b, o):
     o.copy_((a.reshape(-1)[:o.numel()] - b.reshape(-1)[:o.numel()]
              ).reshape(o.shape))

@@ -69,6 +69,8 @@ def check_learner(L, data, mtol, gtol, exact_idx, case='debug', gold=None, all_m
     keys = KEYS
     if all_metrics:
       keys = [k[len(f's{step}/metric/'):] for k in GOLD.files if k.startswith(f's{step}/metric/')]
+      missing = [k for k in keys if k not in mets and not k.endswith(('_grad_scale', '_grad_overflow'))]
+      assert not missing, f'metrics the reference returns and the learner does not: {missing}'
       keys = [k for k in keys if k in mets]
       assert len(keys) >= 40, len(keys)
     for k in keys:

@@ -829,6 +829,14 @@ def test_native_fp32_mode(hip, ref):
     assert hip.lib.dd_gemm_set_mode(6) == 0
 
 
+def test_symexp(hip, ref):
+  x = rnd(5000, seed=3) * 4.0
+  x[:4] = torch.tensor([0.0, -0.0, 1e-8, -30.0])
+  res = both(hip, ref, lambda ops, x, o: ops.symexp(x, o), [x, torch.zeros(5000)], [1])
+  close(*res[0], rtol=2e-6, what='symexp')
+  assert float(res[0][0][0]) == 0.0 and float(res[0][0][3]) == pytest.approx(-(np.exp(30.0) - 1), rel=1e-5)
+
+
 def test_axpy_and_balance_stats(hip, ref):
   x, y, s = rnd(5000, seed=1), rnd(5000, seed=2), torch.tensor([0.37])
   def f1(ops, x, y, s):

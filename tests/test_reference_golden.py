@@ -214,6 +214,33 @@ def test_oracle_report_reproduces_the_reference_run(case):
       _close(got[kk], want[kk], 1e-9, (k, kk))
 
 
+@pytest.mark.parametrize('case', ('debug', 'onehot'))
+def test_agent_train_and_report_return_the_reference_key_sets(case):
+  """The product's Agent (CPU restatement of the kernels through the test-only backend seam):
+  `train` returns exactly the metric names the reference's train returned (minus its float16
+  loss-scale bookkeeping), `report` exactly the reference's report keys."""
+  import helpers
+  from daydreamer_amd import agent as agent_mod
+  from oracle import ref_ops
+  base, (plain, sp, shapes, params, data, B, T) = mrg.build(case, **mrg.REPORT_SHAPE)
+  obs, act, _ = mrg.spaces_of(base)
+  c = dict(mg.CONFIG)
+  cfg = helpers.make_config(c.pop('blocks'), **c)
+  ag = agent_mod.Agent(obs, act, None, cfg, _ops=ref_ops.RefOps('cpu'), _device='cpu', _dtype=torch.float64)
+  batch = {k: v for k, v in data.items() if k != 'reset'}
+  _, _, mets = ag.train(batch, None)
+  G = GOLDS[case]
+  want = {k[len('s1/metric/'):] for k in G.files if k.startswith('s1/metric/') and not k.endswith(SKIP)}
+  assert set(mets) == want, sorted(set(mets) ^ want)
+  rep = ag.report(batch)
+  R = np.load(HERE / 'golden' / f'reference_report_{case}.npz')
+  want = {k[len('metric/'):] for k in R.files if k.startswith('metric/')} | \
+         {k.split('/')[1] for k in R.files if k.startswith('video/')}
+  assert set(rep) == want, sorted(set(rep) ^ want)
+  for k in ('openl_image', 'task_imag_image'):
+    assert tuple(np.asarray(rep[k]).shape) == tuple(R[f'video/{k}/shape']), k
+
+
 def test_fixtures_cover_what_the_cases_claim():
   """decay: the clip bites, decayed kernels shrink;
   onehot: REINFORCE case has discrete action draws; gae / gve returns differ."""
