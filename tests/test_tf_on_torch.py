@@ -232,3 +232,43 @@ def test_committed_fixtures_are_what_the_reference_checkout_produces(what, tmp_p
   for k in old.files:
     assert new[k].shape == old[k].shape, k
     assert np.allclose(new[k], old[k], rtol=1e-12, atol=1e-14, equal_nan=True), k
+
+
+@pytest.mark.skipif(not REF.exists(), reason='reference checkout not present')
+def test_reference_q_critics_do_not_construct_as_shipped():
+  """DESIGN.md section 9 / SURVEY 8(f4): QFunction / TwinQFunction are not built because the
+  reference cannot construct them from its own config: its `qfunction` block does not even apply
+  to `defaults` (it sets `pengs_qlambda`, a key `defaults` does not have -> KeyError), and without
+  that key the critics trip their own assertions (agent.py:459-461: backprop for both action types
+  and an actor that takes the action as input, which no block sets).  Executed, not read."""
+  code = (
+      'import importlib.util, sys, traceback\n'
+      f'spec = importlib.util.spec_from_file_location("mrg", r"{HERE / "golden" / "make_reference_golden.py"}")\n'
+      'm = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n'
+      'import numpy as np\n'
+      'embodied, ref = m.reference_modules()\n'
+      'cfg = embodied.Config(ref.Agent.configs["defaults"])\n'
+      'block = dict(ref.Agent.configs["qfunction"])\n'
+      'try:\n'
+      '  cfg.update(block)\n'
+      '  print("block APPLIED")\n'
+      'except KeyError as e:\n'
+      '  print("block KeyError", e)\n'
+      'block.pop("pengs_qlambda")\n'
+      'for kind in ("qfunction", "qtwin"):\n'
+      '  c = cfg.update(block).update({"critic_type": kind, "tf.platform": "cpu", "tf.jit": False})\n'
+      '  obs = {"vector": embodied.Space(np.float32, (4,)), "reward": embodied.Space(np.float32), '
+      '"is_first": embodied.Space(bool), "is_last": embodied.Space(bool), "is_terminal": embodied.Space(bool)}\n'
+      '  act = {"action": embodied.Space(np.float32, (3,), -1.0, 1.0)}\n'
+      '  try:\n'
+      '    ref.Agent(obs, act, embodied.Counter(), c)\n'
+      '    print(kind, "CONSTRUCTED")\n'
+      '  except AssertionError as e:\n'
+      '    tb = traceback.extract_tb(e.__traceback__)[-1]\n'
+      '    print(kind, "AssertionError", tb.filename.split("/")[-1], tb.line)\n')
+  res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0, res.stderr[-2000:]
+  out = res.stdout.splitlines()
+  assert any(l.startswith('block KeyError') and 'pengs_qlambda' in l for l in out), out
+  lines = [l for l in out if l.startswith(('qfunction', 'qtwin'))]
+  assert len(lines) == 2 and all('AssertionError agent.py assert config.actor_grad_' in l for l in lines), lines
