@@ -249,7 +249,11 @@ class LazyMetrics(collections.abc.Mapping):
   looked at.  A loop that only collects the values (`metrics[key].append(value)`, run/train.py)
   and aggregates them at its log interval never waits inside train(); `float(mets[k])` right
   after the call waits for that step (and serialises the two streams).  At the latest it is
-  fetched when the call after the next one is enqueued (its snapshot slot is reused then)."""
+  fetched when the call after the next one is enqueued (its snapshot slot is reused then).
+  Data parallel: the fetch all-reduces the statistics over the ranks (on the read-out
+  communicator), so a call's metrics must be looked at EARLY on every rank or on none - a script
+  that aggregates on every rank and only prints on rank 0 does that; a look that only rank 0
+  takes before the next train call would wait for collectives the other ranks issue later."""
 
   def __init__(self, keys, fetch):
     self._keys, self._fetch, self._vals, self._error = tuple(keys), fetch, None, None
