@@ -229,7 +229,8 @@ def generate(case, verbose=True):
   H, G, A = plain['imag_horizon'], sp.groups, sp.act_dim
   agent, vmap, batch, quiet, discrete = setup(case, problem, verbose)
   names = {var.name: name for name, var in vmap.items()}
-
+  # replay keys ride along (agent.py:89-93: outs = {key, priority = criteria[config.priority]})
+  batch = {**batch, 'key': np.arange(B * T, dtype=np.uint64).reshape(B, T)}
   out = {}
   state = None
   for step in (1, 2):
@@ -238,7 +239,9 @@ def generate(case, verbose=True):
     tft.FEED.draws.clear()
     tft.GradientTape.LOG.clear()
     with quiet():
-      _, state, mets = agent.train(batch, state)
+      outs, state, mets = agent.train(batch, state)
+    assert np.array_equal(outs['key'], batch['key'])
+    out[f's{step}/priority'] = np.array(outs['priority'], np.float64)
     # (a tf.GradientTape only records inside its `with` block: the state handed to the next call
     # is a constant there; torch autograd is always on, so cut it here)
     state = tft.nest_map(tft.stop_gradient, state)

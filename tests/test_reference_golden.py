@@ -241,6 +241,36 @@ def test_agent_train_and_report_return_the_reference_key_sets(case):
     assert tuple(np.asarray(rep[k]).shape) == tuple(R[f'video/{k}/shape']), k
 
 
+@pytest.mark.parametrize('case', ('debug', 'xarm'))
+def test_agent_returns_the_reference_priorities(case):
+  """Prioritized replay (agent.py:89-93): a batch that carries replay keys comes back as
+  outs = {key, priority}, priority = the per-step loss `config.priority` names (reward_loss).
+  The product's Agent (CPU restatement of the kernels, float64, the device RNG's noise) against
+  the priorities the reference's train returned in its two calls."""
+  import helpers
+  from daydreamer_amd import agent as agent_mod, config as config_mod
+  from oracle import ref_ops
+  base, (plain, sp, shapes, params, data, B, T) = mrg.build(case)
+  obs, act, _ = mrg.spaces_of(base)
+  if base.startswith('named:'):
+    cfg = helpers.make_config((base[6:],), imag_horizon=mg.CONFIG['imag_horizon'])
+  else:
+    c = dict(mg.CONFIG)
+    cfg = helpers.make_config(c.pop('blocks'), **c)
+  cfg = cfg.update({'hip.noise_seed': mg.NOISE_SEED, 'batch_size': B, 'replay_chunk': T})
+  ag = agent_mod.Agent(obs, act, None, cfg, _ops=ref_ops.RefOps('cpu'), _device='cpu', _dtype=torch.float64)
+  for g in ag.groups.values():   # (this package's deterministic initial values, as in the reference run)
+    g.load(params)
+  keys = np.arange(B * T, dtype=np.uint64).reshape(B, T)
+  batch = {**{k: v for k, v in data.items() if k != 'reset'}, 'key': keys}
+  state = None
+  for step in (1, 2):
+    outs, state, mets = ag.train(batch, state)
+    assert np.array_equal(outs['key'], keys)
+    _close(outs['priority'], GOLDS[case][f's{step}/priority'], 1e-6, (step, 'priority'))
+    _close(float(mets['reward_loss_mean']), float(np.mean(GOLDS[case][f's{step}/priority'])), 1e-6, step)
+
+
 def test_fixtures_cover_what_the_cases_claim():
   """decay: the clip bites, decayed kernels shrink;
   onehot: REINFORCE case has discrete action draws; gae / gve returns differ."""
