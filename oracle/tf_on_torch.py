@@ -21,7 +21,7 @@ Two deliberate deviations, both so that the comparison with the float64 oracle i
   * randomness is injected: `tf.random.categorical` and `tfd.Normal.sample` draw from a queue of
     uniforms / standard normals the caller provides (`feed`), by the inverse-CDF rule of the oracle
     (oracle/dreamer_ref.sample_onehot) - the reference samples with seed=None, any exact sampler is
-    in-distribution - and every draw is recorded (`DRAWS`).
+    in-distribution - and every draw is recorded (`FEED.draws`).
 
 Only tests/golden/make_reference_golden.py imports this module.
 """
@@ -70,10 +70,9 @@ class Shape(tuple):
 
 
 def _convert(x):
-  if isinstance(x, torch.Tensor) and type(x) is not Tensor and not isinstance(x, Variable):
-    return x.as_subclass(Tensor)
-  if isinstance(x, Variable):
-    return x.as_subclass(Tensor)
+  """Results of torch functions become plain tf.Tensors (never Variables)."""
+  if isinstance(x, torch.Tensor):
+    return x if type(x) is Tensor else x.as_subclass(Tensor)
   if isinstance(x, (tuple, list)) and not isinstance(x, (torch.Size, Shape)):
     return type(x)(_convert(v) for v in x)
   return x
