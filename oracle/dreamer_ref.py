@@ -314,11 +314,19 @@ class Optimizer:
 
   def __init__(self, name, lr, opt='adam', eps=1e-5, clip=0.0, warmup=0,
                wd=0.0, wd_pattern='kernel'):
-    assert opt == 'adam' and not warmup
+    assert opt == 'adam'
     self.name, self.lr, self.eps, self.clip = name, lr, eps, clip
+    self.warmup = warmup
     self.wd, self.wd_pattern = wd, wd_pattern
     self.step = 0
     self.m, self.v = {}, {}
+
+  def _lr(self):
+    """:160-162: lr * clip(step / warmup, 0, 1) with the step count AT THE TIME OF THE CALL - the
+    decay (:254-256, before the increment) sees the old count, Adam (:260-261, after it) the new."""
+    if not self.warmup:
+      return self.lr
+    return self.lr * min(max(self.step / self.warmup, 0.0), 1.0)
 
   def __call__(self, loss, params, names, world_grads=None):
     """params: dict name->leaf tensor; names: which of them to train.
@@ -348,14 +356,14 @@ class Optimizer:
       if self.wd:  # :254-256, 285-301
         for n, p in zip(names, plist):
           if re.search(self.wd_pattern, self.name + '/' + n):
-            p.mul_(1 - self.wd * self.lr)
+            p.mul_(1 - self.wd * self._lr())
       self.step += 1  # :260
       t = float(self.step)
       for n, p, g in zip(names, plist, grads):  # :271-283
         if n not in self.m:
           self.m[n] = torch.zeros_like(p)
           self.v[n] = torch.zeros_like(p)
-        self.m[n], self.v[n] = adam_update(p, g, self.m[n], self.v[n], t, self.lr, self.eps)
+        self.m[n], self.v[n] = adam_update(p, g, self.m[n], self.v[n], t, self._lr(), self.eps)
     metrics[f'{self.name}_grad_steps'] = torch.tensor(self.step)
     return metrics, raw
 

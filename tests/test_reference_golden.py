@@ -137,7 +137,19 @@ def _learner(case, ops, device, dtype):
   return base, L, data
 
 
-@pytest.mark.parametrize('case', CASES)
+PRODUCT_CASES = [c for c in CASES if c not in mrg.ORACLE_ONLY]
+
+
+def test_product_rejects_what_only_the_oracle_restates():
+  from daydreamer_amd import learner as LM
+  from oracle import ref_ops
+  for case in mrg.ORACLE_ONLY:
+    base, (plain, sp, shapes, params, data, B, T) = mrg.build(case)
+    with pytest.raises(AssertionError):
+      LM.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params)
+
+
+@pytest.mark.parametrize('case', PRODUCT_CASES)
 def test_learner_host_logic_matches_the_reference_run(case):
   """The product's learner (its phase orchestration, hoisting, deferred weight gradients, flat
   optimizer arenas, device RNG) on the CPU restatement of the kernels in float64, against the
@@ -149,7 +161,7 @@ def test_learner_host_logic_matches_the_reference_run(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('case', PRODUCT_CASES)
 def test_hip_path_matches_reference_run(hip, case):
   """The HIP kernels (fp32 contractions on the split-bf16 matrix pipe) against the reference run:
   every class drawn as the reference's sources drew it, metrics to 1e-3, gradients to 1e-3 of
