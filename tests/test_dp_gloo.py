@@ -49,3 +49,30 @@ def test_two_ranks_equal_one(overlap):
   for k in ('model_loss', 'actor_loss', 'extr_critic_loss', 'model_grad_norm',
             'actent_scale_mean', 'wmkl_scale_mean', 'extr_score_std'):
     assert abs(float(got[f'metric/{k}']) - float(mets[k])) <= 1e-6 * max(1, abs(float(mets[k]))), k
+
+
+@pytest.mark.parametrize('case', ['debug', 'xarm'])
+def test_two_ranks_reproduce_the_reference_run(case):
+  """North star, data-parallel row: N ranks on their rows of the global batch == the reference on
+  the whole batch.  Directly against a run of the reference's own sources
+  (tests/golden/reference_*.npz, tests/test_reference_golden.py): 2 ranks x 1 row, gloo, float64,
+  early all-reduce on - every metric both sides hold and every parameter after each of two steps."""
+  import pathlib
+  gold = np.load(pathlib.Path(__file__).parent / 'golden' / f'reference_{case}.npz')
+  with tempfile.TemporaryDirectory() as d:
+    mp.spawn(dp_worker.run_reference_case, args=(2, free_port(), d, case), nprocs=2, join=True)
+    got = dict(np.load(f'{d}/dp_ref.npz'))
+  n = 0
+  for k, v in got.items():
+    if k not in gold.files:
+      continue
+    ref = gold[k]
+    if '/metric/' in k:
+      if np.isnan(ref):
+        assert np.isnan(v), k
+      else:
+        assert abs(float(v) - float(ref)) <= 1e-6 * max(abs(float(ref)), 1e-2), (k, float(v), float(ref))
+    else:
+      assert np.abs(v - ref).max() <= 1e-9 * max(ref[1], 1e-30), k
+    n += 1
+  assert n >= 2 * (50 + 100), n
