@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""One-off / on-demand fuzz of the option space: random combinations of the learner's option
+branches, each run (a) through the reference's own sources on the TensorFlow stand-in
+(tests/golden/make_reference_golden.py machinery, needs /root/reference), (b) through the float64
+oracle and (c) through the product's learner on the CPU restatement of the kernels; two train steps,
+every metric / gradient sum / parameter sum compared.  Not part of the test suite (a combination
+takes ~5 s); the fixed cases of tests/test_reference_golden.py are the regression net.
+
+  python tools/fuzz_reference.py [n_combinations] [seed]
+"""
+import contextlib
+import importlib.util
+import io
+import pathlib
+import sys
+
+import numpy as np
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+spec = importlib.util.spec_from_file_location('mrg', ROOT / 'tests/golden/make_reference_golden.py')
+mrg = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mrg)
+mg, tft = mrg.mg, mrg.tft
+from oracle import dreamer_ref, ref_ops  # noqa: E402
+from daydreamer_amd import learner as LM  # noqa: E402
+
+
+def draw(rng):
+  pick = lambda *xs: xs[rng.randint(len(xs))]
+  over = {
+      'critic_return': pick('gve', 'gae'), 'actor_return': pick('gve', 'gae'),
+      'slow_target': pick(True, True, False), 'slow_target_update': pick(1, 2, 100),
+      'slow_target_fraction': pick(1.0, 0.5, 0.1),
+      'wmkl.impl': pick('mult', 'prop', 'fixed'), 'actent.impl': pick('mult', 'prop', 'fixed'),
+      'retnorm.impl': pick('off', 'std', 'mean_std'), 'scorenorm.impl': pick('off', 'std'),
+      'advnorm.impl': pick('off', 'std', 'mean_std'), 'actent_norm': pick(True, False),
+      'rssm.unimix': pick(0.0, 0.01, 0.1), 'actor.unimix': pick(0.0, 0.01, 0.1),
+      'wmkl_balance': pick(0.8, 0.5, 1.0), 'discount': pick(0.998, 0.9), 'return_lambda': pick(0.95, 0.5, 1.0),
+      'loss_scales.kl': pick(1.0, 0.3), 'loss_scales.cont': pick(1.0, 5.0),
+      'grad_heads': pick(['decoder', 'reward', 'cont'], ['decoder'], ['reward', 'cont']),
+      'model_opt.clip': pick(100.0, 3.0), 'model_opt.wd': pick(0.0, 1e-2), 'model_opt.wd_pattern': 'kernel',
+      'actor_opt.eps': pick(1e-6, 1e-3), 'critic_opt.lr': pick(1e-4, 1e-2),
+      'wmkl.target': pick(3.5, 1.0), 'actent.target': pick(0.5, 0.1), 'actor.minstd': pick(0.03, 0.1),
+      'rssm.prior_layers': pick(3, 1),
+  }
+  return pick('debug', 'onehot'), over
+
+
+def run(base, over, idx):
+  name = f'fuzz{idx}'
+  mrg.CASES[name] = (base, over)
+  out = {}
+  keep = mrg.HERE
+  import tempfile
+  with tempfile.TemporaryDirectory() as d:
+    mrg.HERE = pathlib.Path(d)
+    with contextlib.redirect_stdout(io.StringIO()):
+      gold = mrg.generate(name, verbose=False)
+    mrg.HERE = keep
+  problems = []
+  b, (plain, sp, shapes, params, data, B, T) = mrg.build(name)
+  discrete = mrg.spaces_of(b)[2]
+  H, G, A = plain['imag_horizon'], sp.groups, sp.act_dim
+  ag = dreamer_ref.RefAgent(plain, shapes, sp.act_dim, params, torch.float64, act_discrete=discrete,
+                            ctrl_dtype=torch.float64)
+  try:
+    L = LM.Learner(sp, ref_ops.RefOps('cpu'), 'cpu', B, T, params=params, noise_seed=mg.NOISE_SEED,
+                   dtype=torch.float64)
+  except AssertionError as e:
+    L = None
+    problems.append(f'learner rejects: {e}')
+  state = None
+  for step in (1, 2):
+    noise = mg.golden_noise(B, T, H, G, A, step)
+    forced = dict(obs_prior=gold[f's{step}/idx_prior'], obs_post=gold[f's{step}/idx_post'], img=gold[f's{step}/idx_img'])
+    if discrete:
+      forced['act'] = gold[f's{step}/idx_act']
+    _, state, mets = ag.train(data, noise, state, forced=forced)
+    lm = None
+    if L is not None:
+      L.upload(data)
+      L.train_step_device(use_carry=(step > 1))
+      lm = L.read_metrics()
+    for k in [k for k in gold if k.startswith(f's{step}/metric/')]:
+      m = k.split('/metric/')[1]
+      if m.endswith(('_grad_scale', '_grad_overflow')):
+        continue
+      r = float(gold[k])
+      # (the learner reports float32 metric slabs also in float64 mode: 1e-6 relative, 1e-7 absolute)
+      for who, got, tol in (('oracle', mets, 1e-9), ('learner', lm, 1e-6)):
+        if got is None:
+          continue
+        if m not in got:
+          problems.append(f'{who} misses {m}')
+          continue
+        v = float(got[m])
+        if np.isnan(r) != np.isnan(v) or (not np.isnan(r) and abs(v - r) > tol * max(abs(r), 0.1 if who == 'learner' else 1.0)):
+          problems.append(f's{step} {who} {m}: {v} vs {r}')
+    now = ag.export_params()
+    lp = L.export_params() if L is not None else None
+    for k in [k for k in gold if k.startswith(f's{step}/paramsum/')]:
+      n = k.split('/paramsum/')[1]
+      ref = gold[k]
+      for who, got, tol in (('oracle', now, 1e-10), ('learner', lp, 1e-8)):
+        if got is None:
+          continue
+        p = np.asarray(got[n], np.float64)
+        if abs(p.sum() - ref[0]) > tol * max(ref[1], 1e-30) or abs(np.abs(p).sum() - ref[1]) > tol * max(ref[1], 1e-30):
+          problems.append(f's{step} {who} param {n}')
+  return problems
+
+
+if __name__ == '__main__':
+  n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+  rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+  bad = 0
+  for i in range(n):
+    base, over = draw(rng)
+    try:
+      problems = run(base, over, i)
+    except Exception as e:  # noqa: BLE001
+      problems = [f'EXCEPTION {type(e).__name__}: {str(e)[:300]}']
+    status = 'ok' if not problems else f'{len(problems)} PROBLEMS'
+    print(f'[{i}] {base} {status}', flush=True)
+    if problems:
+      bad += 1
+      print('    options:', over)
+      for p in problems[:12]:
+        print('    ', p)
+  print(f'{n - bad} of {n} combinations agree (reference sources == oracle == learner host logic)')
