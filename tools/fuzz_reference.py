@@ -45,6 +45,8 @@ def draw(rng):
       'actor_opt.eps': pick(1e-6, 1e-3), 'critic_opt.lr': pick(1e-4, 1e-2),
       'wmkl.target': pick(3.5, 1.0), 'actent.target': pick(0.5, 0.1), 'actor.minstd': pick(0.03, 0.1),
       'rssm.prior_layers': pick(3, 1),
+      'batch_size': pick(2, 3, 4), 'replay_chunk': pick(3, 5), 'imag_horizon': pick(1, 2, 4),
+      'rssm.stoch': pick(8, 4), 'rssm.classes': pick(8, 16),
   }
   return pick('debug', 'onehot'), over
 
