@@ -7,6 +7,8 @@ every metric / gradient sum / parameter sum compared.  Not part of the test suit
 takes ~5 s); the fixed cases of tests/test_reference_golden.py are the regression net.
 
   python tools/fuzz_reference.py [n_combinations] [seed]
+  python tools/fuzz_reference.py --emit DIR n seed     (here: also keep the fixtures + cases.json)
+  python tools/fuzz_reference.py --hip DIR             (on the MI355X: the HIP path against them)
 """
 import contextlib
 import importlib.util
@@ -51,14 +53,14 @@ def draw(rng):
   return pick('debug', 'onehot'), over
 
 
-def run(base, over, idx):
+def run(base, over, idx, emit=None):
   name = f'fuzz{idx}'
   mrg.CASES[name] = (base, over)
   out = {}
   keep = mrg.HERE
   import tempfile
   with tempfile.TemporaryDirectory() as d:
-    mrg.HERE = pathlib.Path(d)
+    mrg.HERE = pathlib.Path(emit or d)
     with contextlib.redirect_stdout(io.StringIO()):
       gold = mrg.generate(name, verbose=False)
     mrg.HERE = keep
@@ -115,14 +117,46 @@ def run(base, over, idx):
   return problems
 
 
+def hip(directory):
+  """The HIP path against emitted fixtures (no reference checkout needed)."""
+  import json
+  from daydreamer_amd import hipops
+  from test_golden import check_learner
+  ops = hipops.HipOps('cuda:0')
+  cases = json.load(open(pathlib.Path(directory) / 'cases.json'))
+  bad = 0
+  for name, base, over in cases:
+    mrg.CASES[name] = (base, over)
+    b, (plain, sp, shapes, params, data, B, T) = mrg.build(name)
+    gold = np.load(pathlib.Path(directory) / f'reference_{name}.npz')
+    try:
+      L = LM.Learner(sp, ops, 'cuda:0', B, T, params=params, noise_seed=mg.NOISE_SEED)
+      check_learner(L, data, 1e-3, 1e-3, False, b, gold=gold, all_metrics=True)
+      print(f'[{name}] {base} ok', flush=True)
+    except AssertionError as e:
+      bad += 1
+      print(f'[{name}] {base} FAILED {str(e)[:300]}\n    options: {over}', flush=True)
+  print(f'{len(cases) - bad} of {len(cases)} combinations: HIP path == reference sources (metrics 1e-3, gradients 1e-3)')
+
+
 if __name__ == '__main__':
+  if len(sys.argv) > 1 and sys.argv[1] == '--hip':
+    hip(sys.argv[2])
+    sys.exit(0)
+  emit = None
+  if len(sys.argv) > 1 and sys.argv[1] == '--emit':
+    emit = sys.argv[2]
+    pathlib.Path(emit).mkdir(parents=True, exist_ok=True)
+    del sys.argv[1:3]
   n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
   rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
   bad = 0
+  cases = []
   for i in range(n):
     base, over = draw(rng)
+    cases.append((f'fuzz{i}', base, over))
     try:
-      problems = run(base, over, i)
+      problems = run(base, over, i, emit)
     except Exception as e:  # noqa: BLE001
       problems = [f'EXCEPTION {type(e).__name__}: {str(e)[:300]}']
     status = 'ok' if not problems else f'{len(problems)} PROBLEMS'
@@ -133,3 +167,6 @@ if __name__ == '__main__':
       for p in problems[:12]:
         print('    ', p)
   print(f'{n - bad} of {n} combinations agree (reference sources == oracle == learner host logic)')
+  if emit:
+    import json
+    json.dump(cases, open(pathlib.Path(emit) / 'cases.json', 'w'))
