@@ -77,6 +77,7 @@ FULL_GRADS = ('rssm/initial_deter', 'rssm/obs_stats/bias', 'reward/dist_out/out/
               'rssm/gru_out/norm/scale', 'critic/dist_out/out/kernel', 'actor/dist_out/out/kernel',
               'actor/dist_out/std/kernel')
 ORACLE_ONLY = ('warmup',)   # options the product rejects at construction
+STEPS = (1, 2)      # train calls recorded per case (tools/fuzz_reference.py --steps N runs more)
 FULL_MAX = 1024   # arrays stored in full up to this size (the carried state: strided beyond it)
 FULL_PARAMS = ('rssm/img_in/norm/scale', 'critic/dist_out/out/kernel', 'critic_target/dist_out/out/kernel',
                'rssm/initial_deter', 'actor/dense0/norm/bias')
@@ -239,7 +240,7 @@ def generate(case, verbose=True):
   batch = {**batch, 'key': np.arange(B * T, dtype=np.uint64).reshape(B, T)}
   out = {}
   state = None
-  for step in (1, 2):
+  for step in STEPS:
     noise = mg.golden_noise(B, T, H, G, A, step)
     tft.FEED.load(feed_items(noise, T, H, discrete))
     tft.FEED.draws.clear()

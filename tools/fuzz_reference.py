@@ -6,7 +6,7 @@ oracle and (c) through the product's learner on the CPU restatement of the kerne
 every metric / gradient sum / parameter sum compared.  Not part of the test suite (a combination
 takes ~5 s); the fixed cases of tests/test_reference_golden.py are the regression net.
 
-  python tools/fuzz_reference.py [n_combinations] [seed]
+  python tools/fuzz_reference.py [--steps N] [n_combinations] [seed]
   python tools/fuzz_reference.py --emit DIR n seed     (here: also keep the fixtures + cases.json)
   python tools/fuzz_reference.py --hip DIR             (on the MI355X: the HIP path against them)
 """
@@ -77,7 +77,7 @@ def run(base, over, idx, emit=None):
     L = None
     problems.append(f'learner rejects: {e}')
   state = None
-  for step in (1, 2):
+  for step in mrg.STEPS:
     noise = mg.golden_noise(B, T, H, G, A, step)
     forced = dict(obs_prior=gold[f's{step}/idx_prior'], obs_post=gold[f's{step}/idx_post'], img=gold[f's{step}/idx_img'])
     if discrete:
@@ -144,6 +144,9 @@ if __name__ == '__main__':
     hip(sys.argv[2])
     sys.exit(0)
   emit = None
+  if len(sys.argv) > 2 and sys.argv[1] == '--steps':    # more train calls per combination
+    mrg.STEPS = tuple(range(1, int(sys.argv[2]) + 1))
+    del sys.argv[1:3]
   if len(sys.argv) > 1 and sys.argv[1] == '--emit':
     emit = sys.argv[2]
     pathlib.Path(emit).mkdir(parents=True, exist_ok=True)
