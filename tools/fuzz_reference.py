@@ -6,7 +6,7 @@ oracle and (c) through the product's learner on the CPU restatement of the kerne
 every metric / gradient sum / parameter sum compared.  Not part of the test suite (a combination
 takes ~5 s); the fixed cases of tests/test_reference_golden.py are the regression net.
 
-  python tools/fuzz_reference.py [--steps N] [n_combinations] [seed]
+  python tools/fuzz_reference.py [--policy-report] [--steps N] [n_combinations] [seed]
   python tools/fuzz_reference.py --emit DIR n seed     (here: also keep the fixtures + cases.json)
   python tools/fuzz_reference.py --hip DIR             (on the MI355X: the HIP path against them)
 """
@@ -117,6 +117,57 @@ def run(base, over, idx, emit=None):
   return problems
 
 
+def run_policy_report(base, over, idx):
+  """Agent.policy x4 and Agent.report of the reference's sources against the oracle (1e-9)."""
+  import tempfile
+  name = f'fuzzpr{idx}'
+  over = {k: v for k, v in over.items() if k not in ('batch_size', 'replay_chunk')}
+  mrg.CASES[name] = (base, over)
+  problems = []
+  def close(a, b, what, tol=1e-9):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.shape != b.shape or np.abs(a - b).max() > tol * max(1.0, np.abs(b).max()):
+      problems.append(what)
+  keep = mrg.HERE
+  with tempfile.TemporaryDirectory() as d:
+    mrg.HERE = pathlib.Path(d)
+    try:
+      with contextlib.redirect_stdout(io.StringIO()):
+        mrg.generate_policy(name)
+        mrg.generate_report(name)
+      pol = dict(np.load(pathlib.Path(d) / f'reference_policy_{name}.npz'))
+      rep_gold = dict(np.load(pathlib.Path(d) / f'reference_report_{name}.npz'))
+    finally:
+      mrg.HERE = keep
+  discrete = mrg.spaces_of(base)[2]
+  mk = lambda plain, shapes, sp, params: dreamer_ref.RefAgent(
+      plain, shapes, sp.act_dim, params, torch.float64, act_discrete=discrete, ctrl_dtype=torch.float64)
+  b, (plain, sp, shapes, params, data, B, T) = mrg.build(name, batch=3, length=len(mrg.POLICY_MODES), extra=mrg.POLICY_EXTRA)
+  ag, state = mk(plain, shapes, sp, params), None
+  for t, mode in enumerate(mrg.POLICY_MODES):
+    obs = {k: v[:, t] for k, v in data.items() if k not in ('action', 'reset')}
+    outs, state = ag.policy(obs, state, mrg.policy_noise(B, sp.groups, sp.act_dim, discrete, t), mode)
+    close(outs['action'].numpy(), pol[f'c{t}/action'], f'policy call {t} ({mode}) action')
+    for k in ('deter', 'stoch', 'logit'):
+      close(state[0][k].numpy(), pol[f'c{t}/latent/{k}'], f'policy call {t} latent {k}')
+  b, (plain, sp, shapes, params, data, B, T) = mrg.build(name, **mrg.REPORT_SHAPE)
+  ag = mk(plain, shapes, sp, params)
+  noise = mrg.report_noise(B, T, plain['imag_horizon'], sp.groups, sp.act_dim, min(6, B))
+  rep = ag.report({k: v for k, v in data.items() if k != 'reset'}, noise)
+  for k, v in rep_gold.items():
+    if k.startswith('metric/'):
+      m = k[len('metric/'):]
+      if m not in rep:
+        problems.append(f'report misses {m}')
+      else:
+        close(float(rep[m]), float(v), f'report metric {m}')
+  for vid in sorted({k.split('/')[1] for k in rep_gold if k.startswith('video/')}):
+    got = mrg.video_digest(rep[vid].numpy())
+    for kk in ('sums', 'abssums', 'sample'):
+      close(got[kk], rep_gold[f'video/{vid}/{kk}'], f'report video {vid} {kk}')
+  return problems
+
+
 def hip(directory):
   """The HIP path against emitted fixtures (no reference checkout needed)."""
   import json
@@ -144,6 +195,9 @@ if __name__ == '__main__':
     hip(sys.argv[2])
     sys.exit(0)
   emit = None
+  policy_report = '--policy-report' in sys.argv    # also Agent.policy x4 and Agent.report (oracle)
+  if policy_report:
+    sys.argv.remove('--policy-report')
   if len(sys.argv) > 2 and sys.argv[1] == '--steps':    # more train calls per combination
     mrg.STEPS = tuple(range(1, int(sys.argv[2]) + 1))
     del sys.argv[1:3]
@@ -160,6 +214,8 @@ if __name__ == '__main__':
     cases.append((f'fuzz{i}', base, over))
     try:
       problems = run(base, over, i, emit)
+      if policy_report:
+        problems += run_policy_report(base, over, i)
     except Exception as e:  # noqa: BLE001
       problems = [f'EXCEPTION {type(e).__name__}: {str(e)[:300]}']
     status = 'ok' if not problems else f'{len(problems)} PROBLEMS'
