@@ -256,19 +256,27 @@ k_norm_finalize(const double* __restrict__ partial, int P, double* __restrict__ 
 
 // p *= (1 - wd*lr) for i < n_decay, then Adam with bias correction
 // (tfutils.py:271-283), gradient scaled by clip / max(norm, clip).
+// warmup > 0 (tfutils.py:160-162): lr * clip(step / warmup, 0, 1) with the step count at the time
+// of use - the decay runs before the count advances (:254-256 then :260), Adam after it; st[0] is
+// the advanced count here (dd_grad_norm advanced it).
 __global__ void __launch_bounds__(256)
 k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
        float* __restrict__ v, long n, long n_decay, const double* __restrict__ st,
-       float lr, float wd, float eps, float b1, float b2, float clip) {
+       float lr, float wd, float eps, float b1, float b2, float clip, float warmup) {
   if (st[2] == 0.0) return;  // non-finite gradient norm: skip, host raises
   const float norm = (float)st[1];
   const float gs = clip > 0.f ? clip / fmaxf(norm, clip) : 1.f;
   const float t = (float)st[0];
   const float c1 = 1.f / (1.f - powf(b1, t)), c2 = 1.f / (1.f - powf(b2, t));
+  float lr_wd = lr;
+  if (warmup > 0.f) {
+    lr_wd = lr * fminf(fmaxf((t - 1.f) / warmup, 0.f), 1.f);
+    lr = lr * fminf(fmaxf(t / warmup, 0.f), 1.f);
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float gi = g[i] * gs;
     float pi = p[i];
-    if (i < n_decay) pi *= (1.f - wd * lr);
+    if (i < n_decay) pi *= (1.f - wd * lr_wd);
     float mi = b1 * m[i] + (1.f - b1) * gi;
     float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
@@ -444,9 +452,9 @@ extern "C" int dd_grad_norm(const float* g, long n, double* opt_state, double* w
 
 extern "C" int dd_adam_step(float* p, const float* g, float* m, float* v, long n, long n_decay,
                             const double* opt_state, float lr, float wd, float eps, float b1,
-                            float b2, float clip, void* stream) {
+                            float b2, float clip, float warmup, void* stream) {
   if (n <= 0) return 0;
-  k_adam<<<gsz(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, n_decay, opt_state, lr, wd, eps, b1, b2, clip);
+  k_adam<<<gsz(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, n_decay, opt_state, lr, wd, eps, b1, b2, clip, warmup);
   DD_CHECK_LAUNCH("dd_adam_step");
   return 0;
 }

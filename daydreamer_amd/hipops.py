@@ -79,7 +79,7 @@ _SIGS = {
     'dd_normalize_update': [c_p, c_p, c_d, c_p, c_d, c_d, c_i, c_i, c_p, c_p],
     'dd_scalar_mul': [c_p, c_p, c_p, c_f, c_i, c_p],
     'dd_grad_norm': [c_p, c_l, c_p, c_p, c_z, c_i, c_p],
-    'dd_adam_step': [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
+    'dd_adam_step': [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
     'dd_fill': [c_p, c_l, c_f, c_p],
     'dd_reset_mask2': [c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_l, c_p],
     'dd_reset_mask_bwd2': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p],
@@ -107,7 +107,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
-ABI_VERSION = 5   # include/daydreamer_hip.h DD_ABI_VERSION
+ABI_VERSION = 6   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -735,10 +735,10 @@ class HipOps:
         self.ws_bytes, int(bool(mixed)), self.stream), 'dd_grad_norm')
 
   def adam_step(self, p, g, m, v, n_decay, opt_state, lr, wd, eps, b1, b2,
-                clip):
+                clip, warmup=0):
     self._check(self.lib.dd_adam_step(
         p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
-        n_decay, opt_state.data_ptr(), lr, wd, eps, b1, b2, clip, self.stream),
+        n_decay, opt_state.data_ptr(), lr, wd, eps, b1, b2, clip, float(warmup), self.stream),
         'dd_adam_step')
 
   def fill(self, t, v=0.0):

@@ -195,7 +195,7 @@ class Learner:
     assert cfg['actor_return'] in ('gve', 'gae') and cfg['critic_return'] in ('gve', 'gae')
     assert cfg['scorenorm']['impl'] in ('off', 'std')
     for k in ('model_opt', 'actor_opt', 'critic_opt'):
-      assert cfg[k]['opt'] == 'adam' and not cfg[k]['warmup']
+      assert cfg[k]['opt'] == 'adam'
     # ---- parameters
     if groups is not None:
       self.groups = groups  # shared with another Learner (policy runner)
@@ -1242,7 +1242,7 @@ class Learner:
       self.allreduce(g.gflat)
     self.ops.grad_norm(g.gflat, g.opt_state, self.mixed)
     self.ops.adam_step(g.flat, g.gflat, g.m, g.v, g.n_decay, g.opt_state,
-                       c['lr'], c['wd'], c['eps'], 0.9, 0.999, c['clip'])
+                       c['lr'], c['wd'], c['eps'], 0.9, 0.999, c['clip'], c.get('warmup', 0))
 
   # ------------------------------------------------------------------ phases
 

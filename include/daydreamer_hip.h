@@ -27,8 +27,9 @@ extern "C" {
 /* ABI version.  1: rounds 1-2.  2 (round 3): dd_grad_norm gained `int mixed` in front of
  * `stream` and its opt_state grew from 3 to 5 doubles - a caller built against version 1 must
  * not call it.  3 (round 4): the version was bumped for that change.  4: dd_ln_act_bwd gained
- * `beta_ln` after `gamma` (out may then be NULL); dd_gemm_set_ws added.  5: dd_symexp added. */
-#define DD_ABI_VERSION 5
+ * `beta_ln` after `gamma` (out may then be NULL); dd_gemm_set_ws added.  5: dd_symexp added.
+ * 6: dd_adam_step gained `float warmup` in front of `stream`. */
+#define DD_ABI_VERSION 6
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -359,10 +360,13 @@ int dd_scalar_mul(float* dst, const float* a, const float* b, float c, int n, vo
  * overflow halves the scale, 1000 good steps double it, clip [1e-4, 1e4]). */
 int dd_grad_norm(const float* g, long n, double* opt_state, double* ws, size_t ws_bytes,
                  int mixed, void* stream);
-/* clip + weight decay (first n_decay elements) + Adam, tfutils.py:244-283. */
+/* clip + weight decay (first n_decay elements) + Adam, tfutils.py:244-283.  warmup > 0
+ * (ABI 6, tfutils.py:160-162): the learning rate is lr * clip(step / warmup, 0, 1) with the step
+ * count at the time of use - the decay sees the count before this step's increment, Adam the one
+ * after it (opt_state[0], advanced by dd_grad_norm); 0 = off. */
 int dd_adam_step(float* p, const float* g, float* m, float* v, long n, long n_decay,
                  const double* opt_state, float lr, float wd, float eps, float b1,
-                 float b2, float clip, void* stream);
+                 float b2, float clip, float warmup, void* stream);
 int dd_fill(float* p, long n, float v, void* stream);
 /* y = (accumulate ? y : 0) + alpha * (alpha_dev ? alpha_dev[0] : 1) * x: the summed, scaled
  * world-model loss map of agent.py:186-190 (its mean / std are metrics). */

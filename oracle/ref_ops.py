@@ -667,14 +667,18 @@ class RefOps:
       opt_state[4] = good
 
   def adam_step(self, p, g, m, v, n_decay, opt_state, lr, wd, eps, b1, b2,
-                clip):
+                clip, warmup=0):
     if float(opt_state[2]) == 0.0:
       return
     norm = float(opt_state[1])
     gs = clip / max(norm, clip) if clip > 0 else 1.0
     t = float(opt_state[0])
+    lr_wd = lr
+    if warmup:   # tfutils.py:160-162: the decay sees the step count before the increment
+      lr_wd = lr * min(max((t - 1.0) / warmup, 0.0), 1.0)
+      lr = lr * min(max(t / warmup, 0.0), 1.0)
     gi = g * gs
-    p[:n_decay] *= (1 - wd * lr)
+    p[:n_decay] *= (1 - wd * lr_wd)
     m.copy_(b1 * m + (1 - b1) * gi)
     v.copy_(b2 * v + (1 - b2) * gi * gi)
     c1 = 1.0 / (1.0 - b1 ** t)

@@ -63,8 +63,8 @@ CASES = dict(
     options_onehot=('onehot', {'slow_target_update': 1, 'slow_target_fraction': 0.5,
                                'wmkl.impl': 'fixed', 'actent.impl': 'prop', 'actent_norm': False,
                                'advnorm.impl': 'off', 'actor.unimix': 0.1}),
-    # learning-rate warm-up (with decay): the product rejects it, the oracle restates it - this case
-    # pins the oracle only (ORACLE_ONLY)
+    # learning-rate warm-up (with decay): the decay sees the step count before the increment, Adam
+    # the one after it
     warmup=('debug', {'model_opt.warmup': 4, 'actor_opt.warmup': 3, 'critic_opt.warmup': 1,
                       'model_opt.wd': 1e-2, 'model_opt.wd_pattern': 'kernel', 'actor_opt.wd': 1e-2,
                       'actor_opt.wd_pattern': 'kernel'}),
@@ -76,7 +76,7 @@ CASES = dict(
 FULL_GRADS = ('rssm/initial_deter', 'rssm/obs_stats/bias', 'reward/dist_out/out/kernel',
               'rssm/gru_out/norm/scale', 'critic/dist_out/out/kernel', 'actor/dist_out/out/kernel',
               'actor/dist_out/std/kernel')
-ORACLE_ONLY = ('warmup',)   # options the product rejects at construction
+ORACLE_ONLY = ()   # cases with options the product rejects at construction (none at present)
 STEPS = (1, 2)      # train calls recorded per case (tools/fuzz_reference.py --steps N runs more)
 FULL_MAX = 1024   # arrays stored in full up to this size (the carried state: strided beyond it)
 FULL_PARAMS = ('rssm/img_in/norm/scale', 'critic/dist_out/out/kernel', 'critic_target/dist_out/out/kernel',

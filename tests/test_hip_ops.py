@@ -642,6 +642,23 @@ def test_state_kernels(hip, ref):
   res = both(hip, ref, fn, [p, g, m, v, st], [0, 2, 3, 4])
   for (a, b), nm in zip(res, ['p', 'm', 'v', 'state']):
     close(a, b, rtol=1e-5, what=f'adam {nm}')
+  # learning-rate warm-up (tfutils.py:160-162): the advanced step count is 4 -> Adam at 4/10 of
+  # lr, the decay at 3/10; past the warm-up (count 4 of 2) nothing changes
+  for warm in (10, 2):
+    st = torch.tensor([3.0, 0.0, 0.0, 1e4, 7.0], dtype=torch.float64)
+    def fnw(ops, p, g, m, v, st):
+      ops.grad_norm(g, st)
+      ops.adam_step(p, g, m, v, nd, st, 1e-1, 1e-1, 1e-6, 0.9, 0.999, 100.0, warm)
+    resw = both(hip, ref, fnw, [p, g, m, v, st], [0, 2, 3])
+    for (a, b), nm in zip(resw, ['p', 'm', 'v']):
+      close(a, b, rtol=1e-5, what=f'adam warmup {warm} {nm}')
+    if warm == 2:
+      def fn0(ops, p, g, m, v, st):
+        ops.grad_norm(g, st)
+        ops.adam_step(p, g, m, v, nd, st, 1e-1, 1e-1, 1e-6, 0.9, 0.999, 100.0)
+      st0 = torch.tensor([3.0, 0.0, 0.0, 1e4, 7.0], dtype=torch.float64)
+      res0 = both(hip, ref, fn0, [p, g, m, v, st0], [0])
+      assert torch.equal(resw[0][0].cpu(), res0[0][0].cpu())
   # reduced-precision mode's loss-scale controller (tfutils.py:225-240): good step counts up,
   # 1000 good steps double the scale (clipped at 1e4), an overflow halves it, resets the count,
   # leaves the step number and the parameters alone
