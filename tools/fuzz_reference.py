@@ -49,6 +49,7 @@ def draw(rng):
       'rssm.prior_layers': pick(3, 1),
       'batch_size': pick(2, 3, 4), 'replay_chunk': pick(3, 5), 'imag_horizon': pick(1, 2, 4),
       'rssm.stoch': pick(8, 4), 'rssm.classes': pick(8, 16),
+      'model_opt.warmup': pick(0, 0, 3), 'actor_opt.warmup': pick(0, 2), 'critic_opt.warmup': pick(0, 10),
   }
   return pick('debug', 'onehot'), over
 
