@@ -13,16 +13,23 @@ random-init weights, fp32 arithmetic.  Other workloads: --config xarm | ur5_mult
 a1_scaled | a1 (spaces: daydreamer_amd/synthetic.config_spaces).
 
 Scaling over N GPUs (one process per GPU, gradients + controller statistics summed over RCCL):
-  --scaling weak    (default) every rank trains on its own batch-B shard of a global batch B*N;
-                    configs[1]'s batch 50 does not divide by 4 or 8, so it can only be weak-scaled
+  --scaling auto    (default) strong where the workload's global batch divides by N - the metric
+                    is defined at a fixed global batch: configs[1]'s batch 50 over
+                    2 GPUs is 25 + 25, BASELINE configs[2]'s own split - weak where it does not
+                    (50 does not divide by 4 or 8: batch 50 per GPU); the JSON line's `scaling`
+                    and `metric` say which one ran
   --scaling strong  the global batch is the config's (or --batch) and every rank takes B/N rows,
-                    e.g.  --config a1_scaled --scaling strong  (batch 256) or --batch 48.
+                    e.g.  --config a1_scaled --scaling strong  (batch 256) or --batch 48
+  --scaling weak    every rank trains on its own batch-B shard of a global batch B*N.
 On a box with fewer GPUs than ranks the ranks share devices and the collectives fall back to
 gloo on device tensors (a plumbing check, not a measurement; the JSON line says so).
 
-`value` is measured on the SHIPPED DEFAULT schedule (`hip.pipeline: false`: train() returns this
-call's metrics, the reference's contract); the opt-in two-stream pipeline of consecutive steps is
-reported next to it under `pipelined` (single GPU) or selected with --pipeline 1.
+`value` is measured on the SHIPPED DEFAULT schedule (`hip.pipeline: auto`): on one GPU the
+two-stream pipeline of consecutive steps with its cached stream pair - every call's own metrics,
+read from the device when looked at, at the latest inside the next call; the timed region ends
+with a drain, so every step's metrics are fetched inside it - under data parallelism the
+sequential schedule.  The other schedule is reported next to it (`sequential_default` /
+`pipelined`, single GPU); --pipeline 0 | 1 forces one.
 
 One JSON line on rank 0 with `roofline` (dominant kernel family: the MFMA contraction kernels,
 timed live with HIP events on their launch streams; `peak` is the roof of the instruction stream
@@ -131,7 +138,7 @@ def pmc_live(argv_tail, timeout=170):
     cmd = [exe, '--pmc', counter, '--kernel-trace', '-d', out, '-o', 'b', '--output-format', 'csv', '--',
            sys.executable, os.path.abspath(__file__), '--child', '--steps', '2', '--warmup', '3',
            '--no-cpu-baseline', '--pmc', 'off'] + argv_tail
-    env = dict(os.environ, TMPDIR='/tmp', DD_PIPE_TUNE='0', PYTHONPATH=ROOT)
+    env = dict(os.environ, TMPDIR='/tmp', PYTHONPATH=ROOT)
     try:
       subprocess.run(cmd, env=env, cwd='/tmp', timeout=timeout, check=True,
                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -186,16 +193,17 @@ def main():
   ap.add_argument('--batch', type=int, default=0, help='override the config batch size')
   ap.add_argument('--length', type=int, default=0, help='override the config sequence length')
   ap.add_argument('--horizon', type=int, default=0, help='override the config imagination horizon')
-  ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+  ap.add_argument('--scaling', choices=('auto', 'weak', 'strong'), default='auto')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cnn', choices=('simple', 'resnet'), default='simple',
                   help='image encoder / decoder family (reference encoder.cnn / decoder.cnn); the BASELINE '
                        'configs use simple')
   ap.add_argument('--precision', choices=('float32', 'bfloat16'), default='float32',
                   help='hip.precision; bfloat16 is the opt-in reduced-precision mode (not the parity mode)')
-  ap.add_argument('--pipeline', type=int, default=0,
-                  help='hip.pipeline for the headline value (default 0 = the shipped default schedule; '
-                       'with 0 on one GPU the opt-in pipeline is measured too and reported under `pipelined`)')
+  ap.add_argument('--pipeline', type=int, default=-1,
+                  help='hip.pipeline for the headline value: -1 (default) = the shipped default `auto` (pipeline on '
+                       'one GPU, sequential under data parallelism), 0 / 1 force the sequential / pipelined schedule; '
+                       'on one GPU the other schedule is measured too and reported beside it')
   ap.add_argument('--pmc', choices=('auto', 'on', 'off'), default='auto',
                   help='HBM traffic of the contraction kernels: auto/on = two rocprofv3 --pmc passes over a '
                        'short child run of this script (single GPU, rocprofv3 on PATH); off = committed record')
@@ -210,8 +218,6 @@ def main():
   assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
   ndev = torch.cuda.device_count()
   shared_devices = ndev < world
-  if shared_devices:  # plumbing check only: skip the pipeline's stream-pair measurement
-    os.environ['DD_PIPE_TUNE'] = '0'
   local = local % max(ndev, 1)
   os.environ['LOCAL_RANK'] = str(local)
   torch.cuda.set_device(local)
@@ -236,8 +242,9 @@ def main():
           f'{backend}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}',
           file=sys.stderr, flush=True)
 
-  cfg = make_config(args.config).update({'hip.pipeline': bool(args.pipeline),
-                                         'hip.precision': args.precision})
+  cfg = make_config(args.config).update({'hip.precision': args.precision})
+  if args.pipeline >= 0:
+    cfg = cfg.update({'hip.pipeline': bool(args.pipeline)})
   if args.cnn != 'simple':
     cfg = cfg.update({'encoder.cnn': args.cnn, 'decoder.cnn': args.cnn})
   if args.batch:
@@ -248,7 +255,10 @@ def main():
     cfg = cfg.update({'imag_horizon': args.horizon})
   plain = config_mod.to_plain(cfg)
   T, H = plain['replay_chunk'], plain['imag_horizon']
-  if args.scaling == 'strong':
+  scaling = args.scaling
+  if scaling == 'auto':
+    scaling = 'strong' if plain['batch_size'] % world == 0 else 'weak'
+  if scaling == 'strong':
     Bg = plain['batch_size']
     assert Bg % world == 0, f'global batch {Bg} does not divide over {world} GPUs (use --batch)'
   else:
@@ -287,8 +297,6 @@ def main():
     _, box['state'], box['mets'] = agent.train(data, box['state'])
   for _ in range(max(args.warmup, 3)):
     train_call()
-  if args.pipeline:  # finish the one-time stream-pair selection now (real train steps, untimed)
-    box['state'] = agent.tune_pipeline(data, box['state'])
   L, plan = agent.learner, agent._plan
   pipelined = isinstance(plan, agent_mod.Pipeline)
 
@@ -320,8 +328,6 @@ def main():
       _, obox['state'], _ = other.train(mine, obox['state'])
     for _ in range(3):
       other_call()
-    if not pipelined:
-      obox['state'] = other.tune_pipeline(mine, obox['state'])
     def timed_other(n):
       barrier()
       t0 = time.perf_counter()
@@ -330,7 +336,7 @@ def main():
       other.flush()
       barrier()
       return (time.perf_counter() - t0) / n
-    dt_other = timed_other(args.steps if not pipelined else n_extra)
+    dt_other = timed_other(args.steps)
     other.flush()
     del other
   dt_seq = dt_other if pipelined else None
@@ -440,10 +446,11 @@ def main():
     def rate(d, b=Bg):
       return None if d is None else dict(value=round(b * T * H / d, 1), ms_per_step=round(1e3 * d, 3))
     out = dict(
-        metric='imagined env-steps/sec (learner)',
+        metric='imagined env-steps/sec (learner)' + (
+            f' [weak scaling: batch {B} per GPU, global batch {Bg}]' if scaling == 'weak' and world > 1 else ''),
         value=round(value, 1), unit='imagined_env_steps/s', n_gpus=world,
         steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3),
-        higher_is_better=True, scaling=args.scaling, vs_baseline=None,
+        higher_is_better=True, scaling=scaling, vs_baseline=None,
         dtype='f32' if args.precision == 'float32' else 'bf16 inputs, f32 accumulate (opt-in reduced precision)',
         data='synthetic',
         config=dict(
@@ -452,19 +459,25 @@ def main():
                       f'horizon {H}; Agent.train with host minibatch in (PCIe upload timed), all three '
                       'optimizers stepped, numpy metrics out'),
             global_batch=Bg, per_gpu_batch=B, seq_len=T, horizon=H, parallelism=f'dp{world}',
-            scaling_note=('weak: batch per GPU fixed (configs[1] batch 50 does not divide by 4 or 8); '
-                          'strong scaling: --config a1_scaled --scaling strong (batch 256) or --batch 48'),
+            scaling_note=('--scaling auto: strong (fixed global batch, the metric\'s definition) where the batch '
+                          'divides by the GPU count, weak (batch per GPU fixed) where it does not - configs[1] batch 50 '
+                          'does not divide by 4 or 8; --config a1_scaled (batch 256) or --batch 48 divide by 1, 2, 4, 8'),
             collectives=None if backend is None else dict(
                 backend='RCCL (nccl)' if backend == 'nccl' else backend, world_size=world,
                 ranks_share_devices=shared_devices),
             hip_graphs=plan.n_graphs,
-            schedule=('opt-in hip.pipeline: behaviour phase of step k overlaps world-model phase '
-                      'of step k+1, bit-identical parameters, each call\'s own metrics returned lazily'
-                      if pipelined else 'shipped default (hip.pipeline off): train() returns this call\'s metrics')),
+            schedule=(('shipped default (hip.pipeline: auto -> on for one process)' if args.pipeline < 0 else 'hip.pipeline: true')
+                      + ': behaviour phase of step k next to the world-model phase of step k+1 on the cached stream pair '
+                      + f'{plan.pair}, bit-identical parameters, each call\'s own metrics read when looked at, at the '
+                      'latest inside the next call (all inside the timed region: it ends with a drain)'
+                      if pipelined else
+                      ('shipped default (hip.pipeline: auto -> off under data parallelism)' if args.pipeline < 0 and world > 1
+                       else 'hip.pipeline: false') + ': sequential schedule, train() returns this call\'s metrics as host values')),
         resident=rate(dt_res),
         pipelined=None if dt_pipe is None else dict(
-            **rate(dt_pipe), note='opt-in hip.pipeline: true - bit-identical parameters, each call\'s own metrics returned lazily (LazyMetrics)'),
-        sequential_default=rate(dt_seq),
+            **rate(dt_pipe), note='hip.pipeline: true - bit-identical parameters, each call\'s own metrics returned lazily (LazyMetrics)'),
+        sequential_default=None if dt_seq is None else dict(
+            **rate(dt_seq), note='hip.pipeline: false - the sequential schedule (the shipped default until round 4): train() returns host values'),
         replay_inclusive=None if dt_replay is None else dict(
             **rate(dt_replay), note='DeviceReplay.sample_batch (dd_replay_gather from the HBM '
             'episode ring) + Agent.train per step, numpy metrics out'),

@@ -237,10 +237,22 @@ class LazyScalar:
   def __rtruediv__(self, o): return o / self._value()
   def __neg__(self): return -self._value()
   def __abs__(self): return abs(self._value())
+  def __floordiv__(self, o): return self._value() // o
+  def __rfloordiv__(self, o): return o // self._value()
+  def __mod__(self, o): return self._value() % o
+  def __rmod__(self, o): return o % self._value()
+  def __pow__(self, o): return self._value() ** o
+  def __rpow__(self, o): return o ** self._value()
+  def __pos__(self): return +self._value()
   def __lt__(self, o): return self._value() < o
   def __le__(self, o): return self._value() <= o
   def __gt__(self, o): return self._value() > o
   def __ge__(self, o): return self._value() >= o
+  # value equality like the numpy scalar it stands for (the default would compare identities
+  # and `mets[k] == 0.0` would silently be False); unhashable like any object with value __eq__
+  def __eq__(self, o): return self._value() == (o._value() if isinstance(o, LazyScalar) else o)
+  def __ne__(self, o): return self._value() != (o._value() if isinstance(o, LazyScalar) else o)
+  __hash__ = None
 
 
 class LazyMetrics(collections.abc.Mapping):
@@ -274,6 +286,11 @@ class LazyMetrics(collections.abc.Mapping):
   def resolved(self):
     return self._vals is not None
 
+  @property
+  def failed(self):
+    """The fetch raised (and whoever looked has been handed the exception)."""
+    return self._error is not None
+
   def __getitem__(self, key):
     if self._vals is not None:
       return self._vals[key]
@@ -289,7 +306,7 @@ class LazyMetrics(collections.abc.Mapping):
 
 
 class Pipeline:
-  """Two-stream software pipeline of the train step (hip.pipeline: true).
+  """Two-stream software pipeline of the train step (hip.pipeline; the shipped default on one GPU).
 
   A step is  A1 (world-model forward + backward)  ->  A2 (world-model optimizer,
   hand-over copies)  ->  B (imagination, critic and actor updates).  B(k) only reads
@@ -301,28 +318,31 @@ class Pipeline:
   of the sequential step (parameters after n steps are bit-identical,
   tests/test_learner_gpu.py).  Every call returns ITS OWN metrics as a `LazyMetrics`: they are
   copied out of the per-step snapshot when first looked at, or when the next call has been
-  enqueued, whichever comes first.
+  enqueued, whichever comes first.  A non-finite loss / gradient norm of step k therefore raises
+  (FloatingPointError, the check_numerics contract of tfutils.py:207,249) when step k's metrics
+  are looked at, at the latest inside train call k + 1; the update that produced it was skipped
+  on the device either way (k_adam), exactly as in the sequential schedule.
+
+  Streams.  Both phases run on dedicated library-owned streams (work queued on the default
+  stream does not run next to other streams; equal priorities: a high-priority stream for either
+  phase was measured at 62 / 99 instead of 43.5 ms per step).  Which two matters: ROCm multiplexes
+  HIP streams onto a few hardware queues in creation order, and the steady-state step time falls
+  into three classes by the pair the phases (and their graphs' internal branches) land on -
+  29.4 / 31.1 / 33.5 ms at configs[1] (profiles/r05_pipe_pairs.txt, two boxes).  The pair is a
+  CACHED CHOICE: DEFAULT_PAIR of a pool of four streams created together, in the fast class on
+  every box measured (DD_PIPE_PAIR=a,b overrides it).  `tune()` re-measures all twelve ordered
+  pairs at steady state (explicit, ~100 train steps; Agent.tune_pipeline) for a process whose
+  other streams shift the queue assignment, e.g. after initialising an RCCL group.
   """
+
+  DEFAULT_PAIR = (1, 3)
+  POOLS = {}  # device -> ([4 phase streams], read-out stream)
+  BEST = {}   # device -> pair selected by tune() in this process
 
   def __init__(self, learner, device, comm=None):
     self.L = learner
     self.device = device
     self.comm = comm  # data-parallel: communicator of the metric read-out
-    # Dedicated streams for both phases (work queued on the default stream does not run
-    # next to other streams; equal priorities: a high-priority stream for either phase was
-    # measured at 62 / 99 instead of 43.5 ms per step).  Which two streams matters: ROCm
-    # multiplexes HIP streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) in
-    # creation order, and the step time swings between 38 and 48 ms with the queues the
-    # two phases (and the graphs' internal branches) land on - it flipped from one to the
-    # other merely by initialising an RCCL process group.  So the pair can be chosen by
-    # measurement: tune() cycles through the ordered pairs of a small pool (3 real train
-    # steps each, timed by device events, each pair with its own captured graphs) and
-    # keeps the fastest.  It is an explicit call (bench.py, tools/train_c2.py); without it
-    # the first pair is used.
-    # The pool and the selected pair are per process and device (Pipeline.POOLS / BEST): every
-    # agent of the process runs on the same streams, the selection is measured once (by the
-    # first pipelined agent, inside its first train calls - `tune`) and reused, and no
-    # candidate's graphs are destroyed while their owner is alive.
     key = str(torch.device(device))
     if key not in Pipeline.POOLS:
       Pipeline.POOLS[key] = ([graphs.stream(device, f'pipe{i}') for i in range(4)],
@@ -331,12 +351,16 @@ class Pipeline:
     self.pool, self.s3 = Pipeline.POOLS[key]          # s3: metric read-out
     self.cands = [(a, b) for a in range(4) for b in range(4) if a != b]
     self.periods = {}
-    self.ticks = []
     # one set of captured graphs per stream pair: a graph executable is only ever
     # launched on one stream (relaunching it on another one crashes the runtime)
     self.plans = {}
-    self.tuned = key in Pipeline.BEST or os.environ.get('DD_PIPE_TUNE', '1') != '1'
-    self._use_pair(*Pipeline.BEST.get(key, (0, 1)))
+    pair = Pipeline.BEST.get(key)
+    if pair is None:
+      env = os.environ.get('DD_PIPE_PAIR')
+      pair = tuple(int(x) for x in env.split(',')) if env else Pipeline.DEFAULT_PAIR
+      assert pair in self.cands, pair
+    self.pair = None
+    self._use_pair(*pair)
     self.ev_in = torch.cuda.Event()
     self.ev_a = torch.cuda.Event()
     self.ev_b = [torch.cuda.Event(), torch.cuda.Event()]
@@ -348,67 +372,33 @@ class Pipeline:
     self.handle = None   # its LazyMetrics
     self.keys = ()       # metric names (those of the eager first step)
 
-  POOLS = {}  # device -> ([4 phase streams], read-out stream)
-  BEST = {}   # device -> selected (world-model stream, behaviour stream) indices
-
   def _use_pair(self, a, b):
+    """Switch to streams (a, b) of the pool; the caller has drained the pipeline."""
     if (a, b) not in self.plans:
       torch.cuda.synchronize(self.device)
       self.plans[(a, b)] = self.L.capture_pipeline()
     self.pa1, self.pa2, self.pb = self.plans[(a, b)]
     self.s1, self.s2 = self.pool[a], self.pool[b]
+    self.pair = (a, b)
 
   @property
   def n_graphs(self):
     return self.pa1.n_graphs + self.pa2.n_graphs + self.pb.n_graphs
 
-  def _publish(self, pub, stream):
+  def _publish(self, pub, stream, clear=False):
     with torch.cuda.stream(stream):
       for k, v in self.L.metric_tensors().items():
         pub[k].copy_(v)
-
-  TRIAL = 3  # steps per candidate pair while tuning; the last period of a trial counts
-
-  def _tune(self):
-    """Pick the streams of step self.k; called before it is enqueued."""
-    c, r = divmod(self.k, self.TRIAL)
-    if r == 0 and c > 0 and (c - 1) < len(self.cands):
-      # the previous trial's last two ticks are complete once step k-2 has been read;
-      # tick of step k-1 may still be in flight: wait for it (tuning only)
-      t0, t1 = self.ticks[self.k - 2], self.ticks[self.k - 1]
-      t1.synchronize()
-      self.periods[self.cands[c - 1]] = t0.elapsed_time(t1)
-    if c < len(self.cands):
-      a, b = self.cands[c]
-    else:
-      a, b = min(self.periods, key=self.periods.get)
-      if self.comm is not None:
-        # data parallel: every rank measured its own periods in lock-step; all of them run the
-        # pair rank 0 chose (different pairs per rank = different skew at every collective)
-        pick = torch.tensor([a, b], dtype=torch.int64, device=self.device)
-        self.comm.dist.broadcast(pick, src=0, group=self.comm.group)
-        a, b = int(pick[0]), int(pick[1])
-      self.tuned = True
-      self.ticks = []
-      Pipeline.BEST[self.key] = (a, b)
-    if (self.pool[a], self.pool[b]) != (self.s1, self.s2):
-      self.s1.synchronize()
-      self.s2.synchronize()
-      self._use_pair(a, b)
-    if self.tuned:
-      # the losing pairs' graphs (3 plans x 11 pairs) are not needed again: retire them (they are
-      # destroyed by a later capture, after a device-wide synchronize - graphs.py)
-      for key in [k for k in self.plans if k != (a, b)]:
-        for plan in self.plans.pop(key):
-          plan.release()
+      if clear and getattr(self.L, 'scan_sync', None) is not None:
+        # the persistent scans' sticky error word belongs to the step whose snapshot took it:
+        # cleared here, in stream order, so that the next step's snapshot holds its own errors only
+        self.L.scan_sync[1:2].zero_()
 
   def step(self):
     """Enqueue one step; returns its metrics as a LazyMetrics.  The previous step's metrics
     are fetched here (after this step's world-model phase has been enqueued), if the caller has
     not looked at them yet.  The caller's current stream holds the uploaded inputs."""
     cur = torch.cuda.current_stream(self.device)
-    if not self.tuned:
-      self._tune()   # (first pipelined agent of the process: measure the stream pairs)
     s1, s2 = self.s1, self.s2
     par = self.k & 1
     s1.wait_stream(cur)                    # inputs / carry reset issued by the caller
@@ -425,7 +415,7 @@ class Pipeline:
     if self.pending is not None:
       s1.wait_event(self.ev_b[par ^ 1])
     self.pa2.replay_on(s1, start=last)
-    self._publish(self.pub_a[par], s1)
+    self._publish(self.pub_a[par], s1, clear=True)
     self.ev_a.record(s1)
     s2.wait_event(self.ev_a)
     if self.pending is not None:
@@ -433,64 +423,109 @@ class Pipeline:
     self.pb.replay_on(s2)
     self._publish(self.pub_b[par], s2)
     self.ev_b[par].record(s2)
-    if not self.tuned:
-      tick = torch.cuda.Event(enable_timing=True)
-      tick.record(s2)
-      self.ticks.append(tick)
     cur.wait_event(self.ev_in)             # the next upload must not overtake A1's reads
+    # this step's handle is in place BEFORE the previous one is resolved: if that raises (a loss
+    # of step k - 1 is not finite) the step just enqueued keeps its metrics and the pipeline its
+    # bookkeeping - the next call, flush(), save() ... go on from a consistent state
     prev, self.pending = self.handle, par
     self.k += 1
-    if prev is not None:
-      prev.resolve()   # (its snapshot slot is the one the NEXT step publishes into)
     self.handle = LazyMetrics(self.keys, lambda: self._read(par))
+    if prev is not None and not prev.failed:
+      prev.resolve()   # (its snapshot slot is the one the NEXT step publishes into)
     return self.handle
 
+  WARM, TIMED = 2, 6  # steps per candidate pair of tune(): untimed, timed
+
   def tune(self, run_step, force=False):
-    """Finish the stream-pair selection now (instead of inside the next train calls):
-    run_step() must perform one train step (through step()); 12 candidate pairs x 3 steps.
-    No-op once a pair has been selected in this process, unless `force` re-measures."""
-    if os.environ.get('DD_PIPE_TUNE', '1') != '1':
+    """Choose the stream pair by measurement: every ordered pair of the pool runs WARM + TIMED
+    real train steps (run_step() performs one, through step()) between two drains of the
+    pipeline, the wall time of the TIMED ones (steady state: both phases of consecutive steps
+    in flight) is its period; the fastest pair is kept for every pipelined agent of the process
+    and the losing pairs' graphs are retired.  No-op once a pair has been measured in this
+    process, unless `force`."""
+    if self.key in Pipeline.BEST and not force:
       return
-    if force:
+    self.periods = {}
+    for a, b in self.cands:
       self.flush()
-      self.k, self.periods, self.ticks, self.tuned = 0, {}, [], False
-    while not self.tuned:
-      run_step()
+      self._use_pair(a, b)
+      for _ in range(self.WARM):
+        run_step()
+      self.flush()
+      t0 = time.perf_counter()
+      for _ in range(self.TIMED):
+        run_step()
+      self.flush()
+      self.periods[(a, b)] = 1e3 * (time.perf_counter() - t0) / self.TIMED
+    a, b = min(self.periods, key=self.periods.get)
+    if self.comm is not None:
+      # data parallel: every rank measured its own periods in lock-step; all of them run the
+      # pair rank 0 chose (different pairs per rank = different skew at every collective)
+      pick = torch.tensor([a, b], dtype=torch.int64, device=self.device)
+      self.comm.dist.broadcast(pick, src=0, group=self.comm.group)
+      a, b = int(pick[0]), int(pick[1])
+    Pipeline.BEST[self.key] = (a, b)
+    self._use_pair(a, b)
+    # the losing pairs' graphs (3 plans x 11 pairs) are not needed again: retire them (they are
+    # destroyed by a later capture, after a device-wide synchronize - graphs.py)
+    for key in [k for k in self.plans if k != (a, b)]:
+      for plan in self.plans.pop(key):
+        plan.release()
 
   def _read(self, par):
+    """Fetch the metrics of the step with parity `par` (its snapshot slots).  May run on
+    whichever thread first looks at a LazyMetrics (a logger thread): the device part holds
+    graphs.API_LOCK like every other runtime call of the package."""
     L = self.L
-    with torch.cuda.stream(self.s3):
-      self.s3.wait_event(self.ev_b[par])
-      a, b = self.pub_a[par], self.pub_b[par]
-      rows = sorted(L.stat_b_slots)
-      merged = dict(a)
-      for k in L.METRIC_B:
-        if k in b:
-          merged[k] = b[k]
-      for k in ('sums', 'maxs'):
-        merged[k] = a[k].clone()
-        merged[k][rows] = b[k][rows]
-      if self.comm is not None:
-        self.comm.allreduce_sum(merged['sums'])
-        self.comm.allreduce_max(merged['maxs'])
-        merged['bal'] = merged['bal'].clone()
-        self.comm.allreduce_sum(merged['bal'])
-        for k in L.stat_prereduced:  # identical on every rank already
-          merged['sums'][k] /= L.world
-      host = {k: v.cpu().numpy() for k, v in merged.items()}
+    with graphs.API_LOCK:
+      with torch.cuda.stream(self.s3):
+        self.s3.wait_event(self.ev_b[par])
+        a, b = self.pub_a[par], self.pub_b[par]
+        rows = sorted(L.stat_b_slots)
+        merged = dict(a)
+        for k in L.METRIC_B:
+          if k in b:
+            merged[k] = b[k]
+        for k in ('sums', 'maxs'):
+          merged[k] = a[k].clone()
+          merged[k][rows] = b[k][rows]
+        if self.comm is not None:
+          self.comm.allreduce_sum(merged['sums'])
+          self.comm.allreduce_max(merged['maxs'])
+          merged['bal'] = merged['bal'].clone()
+          self.comm.allreduce_sum(merged['bal'])
+          for k in L.stat_prereduced:  # identical on every rank already
+            merged['sums'][k] /= L.world
+        host = {k: v.cpu().numpy() for k, v in merged.items()}
     return L.read_metrics(host)
 
   def flush(self):
-    """Wait for everything in flight; returns the last step's metrics (or None)."""
-    mets = None
-    if self.pending is not None:
-      mets = self.handle.resolve()
+    """Wait for everything in flight; returns the last step's metrics (or None).  An error of
+    the last step (non-finite loss) is raised once, here; the pipeline is drained either way."""
+    try:
+      # (a failure the caller has already been handed - it looked at the metrics - is not raised again)
+      mets = self.handle.resolve() if self.pending is not None and not self.handle.failed else None
+    finally:
       self.pending = self.handle = None
-    cur = torch.cuda.current_stream(self.device)
-    cur.wait_stream(self.s1)
-    cur.wait_stream(self.s2)
-    self.s2.synchronize()
+      cur = torch.cuda.current_stream(self.device)
+      cur.wait_stream(self.s1)
+      cur.wait_stream(self.s2)
+      self.s2.synchronize()
     return mets
+
+
+def pipeline_mode(value, world, graph=True):
+  """hip.pipeline -> bool.  'auto' (the shipped default): on for a single process (world size
+  1), where the two-stream schedule is 16 % faster and differs from the sequential one only in
+  WHEN a call's metrics are read; off under data parallelism, where the sequential schedule
+  overlaps its early all-reduce with the encoder backward and the pipeline's three communicators
+  have never run on RCCL with more than one rank.  true / false force it (Config.update turns a
+  bool into 'True' / 'False' once the key holds a string)."""
+  v = str(value).strip().lower()
+  assert v in ('auto', 'true', 'false', '1', '0', 'on', 'off'), f'hip.pipeline: {value!r}'
+  if not graph:
+    return False
+  return world == 1 if v == 'auto' else v in ('true', '1', 'on')
 
 
 class TrainState:
@@ -559,8 +594,9 @@ class Agent:
       # side context of the behaviour phase (heads of finished time chunks next to the
       # imagination rollout, learner.phase_imagine)
       hipc = self.cfg.get('hip', {})
+      piped = pipeline_mode(hipc.get('pipeline', 'auto'), self.world, bool(hipc.get('graph', True)))
       self.ops_b2 = (hipops.HipOps(self.device, ws_bytes=1024 << 20)
-                     if hipc.get('overlap_heads', True) and not hipc.get('pipeline', False) else None)
+                     if hipc.get('overlap_heads', True) and not piped else None)
     else:
       self.ops = _ops
       self.ops2 = None
@@ -571,8 +607,8 @@ class Agent:
     hip = self.cfg.get('hip', {})
     self._use_graph = bool(hip.get('graph', True)) and self.device.type == 'cuda'
     self._noise_seed = int(hip.get('noise_seed', 0))
-    # two-stream pipeline of consecutive steps (class Pipeline); single process only
-    self._pipeline = bool(hip.get('pipeline', False)) and self._use_graph
+    # two-stream pipeline of consecutive steps (class Pipeline): 'auto' = on for world size 1
+    self._pipeline = pipeline_mode(hip.get('pipeline', 'auto'), self.world, self._use_graph)
     # rank-sharded prefetch: every rank assembles and uploads only its own rows
     self._shard_dataset = bool(hip.get('shard_dataset', True))
     self.comm_b = self.comm_m = None
@@ -727,16 +763,19 @@ class Agent:
 
   train_step = train  # BASELINE.json names the learner step `train_step`
 
-  def tune_pipeline(self, data, state=None):
-    """Optional, once: choose the pipeline's stream pair by measurement (36 real train
-    steps on `data`; see Pipeline).  Returns the recurrent state to continue from."""
+  def tune_pipeline(self, data, state=None, force=False):
+    """Optional: re-measure the pipeline's stream pair (12 pairs x 8 real train steps on `data`;
+    see Pipeline.tune) instead of using the cached default.  Returns the recurrent state to
+    continue from.  No-op with the sequential schedule."""
     box = [state]
+    if not self._pipeline:
+      return state
     for _ in range(2 if self._pipe is None else 0):   # eager step + pipeline creation
       _, box[0], _ = self.train(data, box[0])
     if self._pipe is not None:
       def run():
         _, box[0], _ = self.train(data, box[0])
-      self._pipe.tune(run)
+      self._pipe.tune(run, force=force)
     return box[0]
 
   def flush(self):
@@ -797,68 +836,93 @@ class Agent:
         sequences, tfutils.video_grid layout [T, 3H, 6W, C];
       * `task_imag_<key>`: the decoded imagined rollout of the policy from the 6 states after
         the 5 context steps, [horizon + 1, H, 6W, C].
-    `data` may hold numpy arrays or device tensors (Agent.dataset yields the latter)."""
+    `data` may hold numpy arrays or device tensors (Agent.dataset yields the latter).
+    The device work of a report - world-model forward, open-loop rollout, imagination, decoding,
+    the sigmoid and the grid layout of the videos (dd_video_grid) - is one launch sequence without
+    host decisions: the first report of a batch shape runs it eagerly (buffers and statistics
+    slots come into being), every later one replays it from a HIP graph; what crosses PCIe is
+    the minibatch in and the metric slabs and finished float32 grids out."""
     data = {k: (v if isinstance(v, torch.Tensor) else np.asarray(v))
             for k, v in data.items() if not k.startswith('log_')}
     B, T = data['is_first'].shape[:2]
     self.flush()
     self._ensure_params()
     key = ('report', B, T)
-    R = self._policies.get(key)
-    if R is None:
-      R = learner_mod.Learner(
-          self.spec, self.ops, self.device, B, T, groups=self.groups,
-          noise_seed=self._noise_seed + 2, dtype=self._dtype)
-      self._policies[key] = R
+    rep = self._policies.get(key)
+    if rep is None:
+      rep = self._policies[key] = self._build_report(B, T)
+    R = rep['R']
     R.wmkl_scale.copy_(self.learner.wmkl_scale)
     R.upload(data)
-    R.reset_carry()
-    R.phase_prep()
-    R.phase_prep_b()  # prior-sample noise of the open-loop rollout
-    R.phase_wm_fwd(True, training=False)
+    if rep['plan'] is not None:
+      rep['plan'].replay()
+    else:
+      rep['run']()
+      if self._use_graph and rep['calls'] >= 1:   # (second call: every lazily created buffer exists)
+        plan = graphs.GraphPlan(self.device)
+        learners = [R] + list(rep['imag'] or ())
+        for L in learners:
+          L.plan = plan
+        try:
+          plan.capture(rep['run'])
+        finally:
+          for L in learners:
+            L.plan = graphs.EagerPlan()
+        rep['plan'] = plan
+    rep['calls'] += 1
     out = dict(R.read_metrics(wm_only=True))
-    nseq, ctx = min(self.REPORT_SEQS, B), self.REPORT_CTX
-    if not self.spec.dec_convs or T <= ctx:
-      return out
-    def host(x):
-      return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x
-    def grid(video):   # tfutils.video_grid, tfutils.py:390-392
-      b_, t_, h_, w_, c_ = video.shape
-      return video.transpose(1, 2, 0, 3, 4).reshape(t_, h_, b_ * w_, c_).astype(np.float32)
-    def split(model):  # per image key channel slices of the decoder output
-      c0 = 0
-      for k, shp in self.spec.dec_cnn_keys.items():
-        yield k, model[..., c0:c0 + shp[2]]
-        c0 += shp[2]
-    if R.H * R.N >= (T - ctx) * B:
-      z = host(R.openloop_device(ctx))[:nseq]
-      model = 1.0 / (1.0 + np.exp(-z.astype(np.float64)))
-      for k, m in split(model):
-        truth = host(data[k][:nseq]).astype(np.float64) / 255.0
-        error = (m - truth + 1) / 2
-        out[f'openl_{k}'] = grid(np.concatenate([truth, m, error], 2))
-    # Greedy.report: imagine with the policy from the states after the context steps
-    H = R.H
-    key = ('imag', nseq)
-    I = self._policies.get(key)
-    if I is None:
-      I = (learner_mod.Learner(self.spec, self.ops, self.device, nseq, 1, groups=self.groups,
-                               noise_seed=self._noise_seed + 3, dtype=self._dtype),
-           learner_mod.Learner(self.spec, self.ops, self.device, H + 1, nseq, groups=self.groups,
-                               noise_seed=self._noise_seed + 3, dtype=self._dtype))
-      self._policies[key] = I
-    roll, dec = I
-    post = R.b['post'].view(B, T, R.F)
-    self.ops.copy2d(post[:nseq, ctx - 1], roll.b['traj'][0][:, :R.F])
-    roll.phase_prep_b()
-    roll.imagine_rollout()
-    dec.decoder_fwd(roll.b['traj'].view(-1, R.TW)[:, :R.F])
-    z = host(dec.dec_act[-1]['z'])
-    z = z.reshape((H + 1, nseq) + z.shape[1:])
-    model = 1.0 / (1.0 + np.exp(-z.astype(np.float64)))
-    for k, m in split(model):
-      out[f'task_imag_{k}'] = grid(m.transpose(1, 0, 2, 3, 4))
+    for name, grid in rep['grids'].items():
+      out[name] = grid.cpu().numpy()
     return out
+
+  def _build_report(self, B, T):
+    """The learners, device buffers and launch sequence of Agent.report for a [B, T] batch."""
+    R = learner_mod.Learner(
+        self.spec, self.ops, self.device, B, T, groups=self.groups,
+        noise_seed=self._noise_seed + 2, dtype=self._dtype)
+    nseq, ctx = min(self.REPORT_SEQS, B), self.REPORT_CTX
+    video = bool(self.spec.dec_convs) and T > ctx
+    openl = video and R.H * R.N >= (T - ctx) * B
+    H = R.H
+    roll = dec = None
+    if video:
+      # Greedy.report: imagine with the policy from the states after the context steps
+      roll = learner_mod.Learner(self.spec, self.ops, self.device, nseq, 1, groups=self.groups,
+                                 noise_seed=self._noise_seed + 3, dtype=self._dtype)
+      dec = learner_mod.Learner(self.spec, self.ops, self.device, H + 1, nseq, groups=self.groups,
+                                noise_seed=self._noise_seed + 3, dtype=self._dtype)
+    grids = {}
+    hw = self.spec.image_hw if video else 0
+    chans = []   # per image key: channel slice of the decoder output / the uint8 input image
+    c0 = 0
+    for k, shp in (self.spec.dec_cnn_keys.items() if video else ()):
+      chans.append((k, c0, c0 + shp[2]))
+      c0 += shp[2]
+      if openl:
+        grids[f'openl_{k}'] = torch.zeros(T, 3 * hw, nseq * hw, shp[2], dtype=torch.float32, device=self.device)
+      grids[f'task_imag_{k}'] = torch.zeros(H + 1, hw, nseq * hw, shp[2], dtype=torch.float32, device=self.device)
+
+    def run():
+      R.reset_carry()
+      R.phase_prep()
+      R.phase_prep_b()  # prior-sample noise of the open-loop rollout
+      R.phase_wm_fwd(True, training=False)
+      if not video:
+        return
+      post = R.b['post'].view(B, T, R.F)
+      if openl:
+        z = R.openloop_device(ctx)          # [B, T, h, w, C] pre-sigmoid, batch-major
+        for k, a, b in chans:
+          self.ops.video_grid(z, R.b['image'], grids[f'openl_{k}'], nseq, T, a, b, T, 1)
+      self.ops.copy2d(post[:nseq, ctx - 1], roll.b['traj'][0][:, :R.F])
+      roll.phase_prep_b()
+      roll.imagine_rollout()
+      dec.decoder_fwd(roll.b['traj'].view(-1, R.TW)[:, :R.F])
+      zi = dec.dec_act[-1]['z']             # [(H + 1) * nseq, h, w, C], time-major
+      for k, a, b in chans:
+        self.ops.video_grid(zi, None, grids[f'task_imag_{k}'], nseq, H + 1, a, b, 1, nseq)
+
+    return dict(R=R, imag=(roll, dec) if video else None, run=run, grids=grids, plan=None, calls=0)
 
   # ------------------------------------------------------------- checkpointing
 

@@ -38,6 +38,38 @@ k_image_loss(const float* __restrict__ z, const unsigned char* __restrict__ img,
   if (threadIdx.x == 0) loss[row] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Agent.report's video grids on the device (tfutils.video_grid tfutils.py:390-392 of
+// WorldModel.report agent.py:266-282 / Greedy.report behaviors.py:32-46): one thread per element of
+// the model section, out[t][sec * H + h][b * W + w][c - c0]; with the uint8 truth image three
+// sections (truth / 255 | model = sigmoid(z) | error = (model - truth + 1) / 2), else the model.
+__global__ void __launch_bounds__(256)
+k_video_grid(const float* __restrict__ z, const unsigned char* __restrict__ img, float* __restrict__ out,
+             int nb, int nt, int H, int W, int ctot, int c0, int c1, long zsb, long zst) {
+  const int cn = c1 - c0;
+  const long total = (long)nb * nt * H * W * cn;
+  const int secs = img ? 3 : 1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long r = i;
+    const int c = (int)(r % cn); r /= cn;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H); r /= H;
+    const int b = (int)(r % nb);
+    const int t = (int)(r / nb);
+    const long src = ((b * zsb + t * zst) * H * W + (long)h * W + w) * ctot + c0 + c;
+    const float m = sigmoidf_(z[src]);
+    const long row = (long)nb * W * cn;                       // floats per output row
+    float* o = out + (((long)t * secs * H + h) * row) + ((long)b * W + w) * cn + c;
+    if (img) {
+      const float tr = (float)img[src] * (1.f / 255.f);
+      o[0] = tr;
+      o[(long)H * row] = m;
+      o[2l * H * row] = (m - tr + 1.f) * 0.5f;
+    } else {
+      o[0] = m;
+    }
+  }
+}
+
 // wave per row: loss[row] = sum_d (pred - target)^2 ; dpred = coef*2*(pred-target)
 __global__ void __launch_bounds__(256)
 k_mse_loss(const float* __restrict__ pred, long ldp, const float* __restrict__ tgt, long ldt,
@@ -382,6 +414,17 @@ extern "C" int dd_image_loss(const float* z, const unsigned char* img, float* lo
   if (rows <= 0) return 0;
   k_image_loss<<<rows, 256, 0, (hipStream_t)stream>>>(z, img, loss, dz, P, ctot, c0, c1, coef);
   DD_CHECK_LAUNCH("dd_image_loss");
+  return 0;
+}
+
+extern "C" int dd_video_grid(const float* z, const unsigned char* img, float* out, int nb, int nt,
+                             int H, int W, int ctot, int c0, int c1, long zsb, long zst, void* stream) {
+  if (nb <= 0 || nt <= 0) return 0;
+  DD_REQUIRE(0 <= c0 && c0 < c1 && c1 <= ctot && H >= 1 && W >= 1, "dd_video_grid: channel range");
+  const long total = (long)nb * nt * H * W * (c1 - c0);
+  k_video_grid<<<nblk(total > (1l << 22) ? (1l << 22) : total), 256, 0, (hipStream_t)stream>>>(
+      z, img, out, nb, nt, H, W, ctot, c0, c1, zsb, zst);
+  DD_CHECK_LAUNCH("dd_video_grid");
   return 0;
 }
 

@@ -58,6 +58,7 @@ _SIGS = {
     'dd_cat_kl_fwd': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     'dd_cat_kl_bwd': [c_p, c_l, c_p, c_l, c_p, c_f, c_f, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     'dd_image_loss': [c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_i, c_f, c_p],
+    'dd_video_grid': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_p],
     'dd_mse_loss': [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     'dd_scalar_loss': [c_p, c_p, c_p, c_p, c_l, c_f, c_i, c_p],
     'dd_normal_head_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_f, c_p],
@@ -107,7 +108,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
-ABI_VERSION = 6   # include/daydreamer_hip.h DD_ABI_VERSION
+ABI_VERSION = 7   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -172,8 +173,17 @@ def onehot_sample_host(x, u, G, C, unimix, mode=0):
   return idx, stoch, logit
 
 
+# int32 words of the fused observe scans' `sync2` buffer (csrc/scan.hip: the launches memset 512
+# row-block counters at word 576)
+SCAN_SYNC_WORDS = 576 + 512
+
+
 class Slabs:
-  """Deferred split-K partial sums sitting in a HipOps workspace (dd_gemm_f32 `deferred`)."""
+  """Deferred split-K partial sums sitting in a HipOps workspace (dd_gemm_f32 `deferred`).
+  `beta` / `bias` are what the CONSUMER must apply to C together with the sum.  They are the
+  caller's values except on HipOps.gemm's K-peel path (ragged contraction axis): there the
+  remainder call has already folded beta * C (and the bulk call carries the bias), so the handle
+  says beta = 1.0 whatever the caller passed."""
 
   def __init__(self, n, M, N, beta, bias):
     self.n, self.M, self.N, self.beta, self.bias = n, M, N, beta, bias
@@ -182,6 +192,7 @@ class Slabs:
 class HipOps:
 
   name = 'hip'
+  SCAN_SYNC_WORDS = SCAN_SYNC_WORDS
 
   def __init__(self, device='cuda:0', ws_bytes=2048 << 20):
     if not torch.cuda.is_available():
@@ -435,6 +446,9 @@ class HipOps:
     post, zo, xo, st3, xq, post_logit (all contiguous, rows b*T + t)."""
     for t in bufs:
       assert t.is_contiguous()
+    # barrier words: counter, error word, debug stamps at [0, 576), 512 row-block counters behind
+    # them - the launch clears the latter (ABI 6: the buffer grew from 2 words)
+    assert sync2.dtype == torch.int32 and sync2.numel() >= SCAN_SYNC_WORDS, sync2.shape
     self._check(self.lib.dd_observe_scan_fwd(
         B, T, D, U, G, C, A, int(use_carry), unimix, first.data_ptr(), _ptr(carry),
         init_deter.data_ptr(), init_stoch.data_ptr(), u_post.data_ptr(),
@@ -459,6 +473,7 @@ class HipOps:
     dz1, dxs (all contiguous, rows b*T + t)."""
     for t in list(acts) + list(grads) + [dlogit]:
       assert t.is_contiguous()
+    assert sync2.dtype == torch.int32 and sync2.numel() >= SCAN_SYNC_WORDS, sync2.shape
     self._check(self.lib.dd_observe_scan_bwd(
         B, T, D, U, G, C, int(flags), unimix, first.data_ptr(), *[t.data_ptr() for t in acts],
         dlogit.data_ptr(), *[w.data_ptr() for w in wts], *[v.data_ptr() for v in vecs],
@@ -570,6 +585,20 @@ class HipOps:
     self._check(self.lib.dd_image_loss(
         z.data_ptr(), img.data_ptr(), loss.data_ptr(), dz.data_ptr(), rows, P,
         ctot, c0, c1, coef, self.stream), 'dd_image_loss')
+
+  def video_grid(self, z, img, out, nb, nt, c0, c1, zsb, zst):
+    """Report videos (dd_video_grid): z [images, H, W, ctot] pre-sigmoid, image (b, t) = number
+    b * zsb + t * zst; img: uint8 truth in the same layout or None; out [nt, (3 | 1) * H, nb * W,
+    c1 - c0] float32."""
+    H, W, ctot = z.shape[-3:]
+    secs = 3 if img is not None else 1
+    assert z.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32
+    assert tuple(out.shape) == (nt, secs * H, nb * W, c1 - c0), (out.shape, nt, secs, H, nb, W, c0, c1)
+    assert img is None or (img.is_contiguous() and img.dtype == torch.uint8 and img.shape[-3:] == z.shape[-3:])
+    last = (nb - 1) * zsb + (nt - 1) * zst
+    assert last < z.numel() // (H * W * ctot) and (img is None or last < img.numel() // (H * W * ctot))
+    self._check(self.lib.dd_video_grid(z.data_ptr(), _ptr(img), out.data_ptr(), nb, nt, H, W, ctot,
+                                       c0, c1, zsb, zst, self.stream), 'dd_video_grid')
 
   def mse_loss(self, pred, tgt, loss, dpred, coef):
     rows, D = pred.shape

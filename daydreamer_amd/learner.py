@@ -402,7 +402,8 @@ class Learner:
                              self.ops.observe_scan_bwd_supported(B, D, U, G, self.C))
       self.scan_wb = [(self.P['obs_stats'].W, i16(3 * U * S)), (self.P['obs_out_h'].W, i16(3 * D * U)),
                       (self.P['gru'].W, i16(3 * (D + U) * 3 * D)), (self.P['img_in_s'].W, i16(3 * S * U))]
-      self.scan_sync = torch.zeros(64 + 2 * 4 * 64 + 512, dtype=torch.int32, device=self.device)   # counter, error word, debug stamps, row-block counters
+      self.scan_sync = torch.zeros(getattr(self.ops, 'SCAN_SYNC_WORDS', 1088),
+                                   dtype=torch.int32, device=self.device)   # counter, error word, debug stamps, row-block counters
       self.scan_idx = torch.zeros((N + B + 1) * G, dtype=torch.int32, device=self.device)
     # World-model forward as two batch halves, software-pipelined (opt-in, hip.split_fwd /
     # DD_SPLIT_FWD=1): the latency-bound observe scan of one half (64 workgroups) on the main
@@ -1386,6 +1387,7 @@ class Learner:
 
   def phase_wm_bwd(self):
     ops, b, cfg = self.ops, self.b, self.cfg
+    self._early = None   # (a step that aborted between allreduce_early and opt_step left it set)
     feat, dfeat = b['post'], b['dfeat']
     gh = cfg['grad_heads']
     # Heads / decoder: the data-gradient chain (-> dfeat) runs first on the main
@@ -1405,7 +1407,9 @@ class Learner:
     else:
       if beta == 0.0:
         ops.fill(dfeat, 0.0)
-      tmp = self.b.setdefault('dfeat_sink', self.zeros(self.N, self.F))
+      tmp = self.b.get('dfeat_sink')
+      if tmp is None:   # (first eager step: never allocated inside a captured segment)
+        tmp = self.b['dfeat_sink'] = self.zeros(self.N, self.F)
       self.decoder_bwd(feat, tmp, 0.0, defer)
     ops.kl_bwd(b['post_logit'], b['prior_logit'], self.wmkl_scale,
                cfg['loss_scales'].get('kl', 1.0) / self.Ng, cfg['wmkl_balance'],
@@ -1797,7 +1801,9 @@ class Learner:
     B, T, D, S, A, F = self.B, self.T, self.D, self.S, self.A, self.F
     assert self.H * self.N >= (T - ctx) * B and self.spec.dec_convs
     post = b['post'].view(B, T, F)
-    feat = b.setdefault('report_feat', self.zeros(B, T, F))
+    feat = b.get('report_feat')
+    if feat is None:   # (first eager report: never allocated inside a captured segment)
+      feat = b['report_feat'] = self.zeros(B, T, F)
     ops.copy2d(b['post'], feat.view(B * T, F))
     act = b['action'].view(B, T, A)
     tr = b['traj'].view(-1, self.TW)          # scratch rows: [deter | stoch | action]
@@ -1852,7 +1858,9 @@ class Learner:
       ops.normal_head_fwd(om, os_, b['eps'][0] if sample else None, t0[:, F:F + A],
                           ca['minstd'], ca['maxstd'])
     if noise:  # tfutils.py:85-93
-      nz = b.setdefault('act_noise', self.zeros(B, A))
+      nz = b.get('act_noise')
+      if nz is None:
+        nz = b['act_noise'] = self.zeros(B, A)
       ops.philox(nz, 1, B, A, B, 0, self.noise_seed, self.step_ctr, SITE_POLICY + 3,
                  0 if self.discrete else 1)
       ops.action_noise(t0[:, F:F + A], nz, float(noise), self.discrete)
@@ -1935,6 +1943,7 @@ class Learner:
     (the pipelined agent snapshots them per phase).  wm_only: the world-model loss metrics
     alone (WorldModel.loss's metrics dict, what Agent.report starts from, agent.py:268)."""
     cfg = self.cfg
+    direct = host is None
     if host is None:
       sums = self.stat_sums.clone()
       maxs = self.stat_maxs.clone()
@@ -1954,7 +1963,8 @@ class Learner:
       # that was not one-hot (bit 1): its outputs are garbage.  Raise like check_numerics
       # (tfutils.py:207,249) instead of training on them; the word is cleared for the next step.
       code = int(host['scan_err'][0])
-      self.scan_sync[1:2].zero_()
+      if direct:   # (a pipelined agent's per-step snapshot clears the live word itself, in stream order)
+        self.scan_sync[1:2].zero_()
       raise RuntimeError(f'fused observe scan failed (error word {code}: '
                          f'{"grid-barrier timeout" if code & 1 else "carried stoch not one-hot"})')
     sums, maxs = host['sums'], host['maxs']

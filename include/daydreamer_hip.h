@@ -28,8 +28,11 @@ extern "C" {
  * `stream` and its opt_state grew from 3 to 5 doubles - a caller built against version 1 must
  * not call it.  3 (round 4): the version was bumped for that change.  4: dd_ln_act_bwd gained
  * `beta_ln` after `gamma` (out may then be NULL); dd_gemm_set_ws added.  5: dd_symexp added.
- * 6: dd_adam_step gained `float warmup` in front of `stream`. */
-#define DD_ABI_VERSION 6
+ * 6: dd_adam_step gained `float warmup` in front of `stream`; the `sync2` buffer of
+ * dd_observe_scan_fwd / _bwd grew from 2 to 1088 words (the launches clear 512 row-block counters
+ * at word 576: a caller with the old 2-word buffer gets an out-of-bounds device write).
+ * 7 (round 5): dd_video_grid added. */
+#define DD_ABI_VERSION 7
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -280,6 +283,14 @@ int dd_cat_kl_bwd(const float* post, long ldp, const float* prior, long ldq,
  * decoder output (nets.py:274-277). */
 int dd_image_loss(const float* z, const unsigned char* img, float* loss, float* dz,
                   int rows, long P, int ctot, int c0, int c1, float coef, void* stream);
+/* Agent.report's videos assembled on the device (tfutils.video_grid, tfutils.py:390-392, of
+ * WorldModel.report agent.py:266-282 and Greedy.report behaviors.py:32-46).  z: pre-sigmoid decoder
+ * output, images of H x W x ctot floats; image (b, t) is image number b * zsb + t * zst; channels
+ * [c0, c1) are one image key.  img = the uint8 truth in the same layout: out [nt, 3H, nb*W, c1-c0]
+ * = truth / 255 | sigmoid(z) | (model - truth + 1) / 2 stacked on the height axis; img = NULL:
+ * out [nt, H, nb*W, c1-c0] = sigmoid(z).  (ABI 7.) */
+int dd_video_grid(const float* z, const unsigned char* img, float* out, int nb, int nt,
+                  int H, int W, int ctot, int c0, int c1, long zsb, long zst, void* stream);
 int dd_mse_loss(const float* pred, long ldp, const float* tgt, long ldt, float* loss,
                 float* dpred, long lddp, int rows, int D, float coef, void* stream);
 /* kind 0 SymlogDist tfutils.py:347-356; kind 1 Bernoulli(logits) nets.py:469-471 */

@@ -414,6 +414,19 @@ class RefOps:
     loss.copy_((d * d).reshape(rows, -1).sum(-1))
     dz[..., c0:c1] = coef * 2 * d * s * (1 - s)
 
+  def video_grid(self, z, img, out, nb, nt, c0, c1, zsb, zst):
+    """dd_video_grid: tfutils.video_grid (tfutils.py:390-392) of [truth | model | error]
+    (agent.py:276-281) or of the model alone (behaviors.py:44-45)."""
+    H, W, ctot = z.shape[-3:]
+    idx = (torch.arange(nb)[:, None] * zsb + torch.arange(nt)[None, :] * zst).reshape(-1)
+    m = torch.sigmoid(z.reshape(-1, H, W, ctot)[idx][..., c0:c1]).reshape(nb, nt, H, W, c1 - c0)
+    secs = [m]
+    if img is not None:
+      tr = img.reshape(-1, H, W, ctot)[idx][..., c0:c1].reshape(nb, nt, H, W, c1 - c0).to(z.dtype) / 255.0
+      secs = [tr, m, (m - tr + 1) / 2]
+    video = torch.cat(secs, 2)                                  # [nb, nt, secs * H, W, c]
+    out.copy_(video.permute(1, 2, 0, 3, 4).reshape(out.shape))
+
   def mse_loss(self, pred, tgt, loss, dpred, coef):
     e = pred - tgt
     loss.copy_((e * e).sum(-1))

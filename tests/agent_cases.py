@@ -91,9 +91,11 @@ def policy_parity(backend, discrete, tol, noise_amount=0.0, cnn='simple'):
   return ag
 
 
-def report_parity(backend, discrete, tol, device_batch=False, cameras=1, cnn='simple'):
+def report_parity(backend, discrete, tol, device_batch=False, cameras=1, cnn='simple', calls=1):
   """Agent.report against RefAgent.report: world-model loss metrics, open-loop grids and the
-  Greedy behaviour's imagined-rollout grids; nothing in the agent's state may change."""
+  Greedy behaviour's imagined-rollout grids; nothing in the agent's state may change.
+  calls: consecutive reports (GPU: the first runs eagerly, the second also captures the launch
+  sequence into a HIP graph, later ones replay it); the last one is compared."""
   dreamer_ref.SAMPLE_TOL[0] = tol['sample']
   dreamer_ref.SAMPLE_STATS.update(draws=0, adopted=0)
   cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=7, replay_chunk=8, imag_horizon=3)
@@ -113,12 +115,15 @@ def report_parity(backend, discrete, tol, device_batch=False, cameras=1, cnn='si
   feed = data
   if device_batch:  # what Agent.dataset yields on the GPU
     feed = {k: torch.from_numpy(v).to(ag.device) for k, v in data.items()}
-  rep = ag.report(feed)
+  for _ in range(calls):
+    rep = ag.report(feed)
   after = ag.save()
   for k in before:
     assert np.array_equal(np.asarray(before[k]), np.asarray(after[k])), k
-  R = ag._policies[('report', B, T)]
-  roll, _ = ag._policies[('imag', 6)]
+  built = ag._policies[('report', B, T)]
+  assert (built['plan'] is not None) == (backend is None and calls >= 2)   # replayed from a HIP graph
+  R = built['R']
+  roll, _ = built['imag']
   G, C, D, F = R.G, R.C, R.D, R.F
   ctx, n = 5, 6
   u_img = R.b['u_img'].reshape(-1, G)

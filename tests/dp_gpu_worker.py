@@ -44,19 +44,32 @@ def main():
   batches = [synthetic.make_batch(obs, act, BG, 8, seed=s, smooth_images=True, terminals=0.1)
              for s in range(3)]
   res = {}
-  # DD_DP_TUNE=1: enough pipelined calls for the stream-pair measurement (12 pairs x 3 steps) to
-  # finish inside the run; every rank must then run the pair rank 0 chose
-  steps = 45 if os.environ.get('DD_DP_TUNE') == '1' else 6
+  # DD_DP_TUNE=1: the pipelined agent re-measures its stream pair (Pipeline.tune: every ordered
+  # pair of the pool, real train steps of the same sequence the sequential agent runs); every
+  # rank must then run the pair rank 0 chose
+  tune = os.environ.get('DD_DP_TUNE') == '1'
+  if tune:
+    agent_mod.Pipeline.WARM, agent_mod.Pipeline.TIMED = 1, 2
+  steps = 6 + (12 * 3 if tune else 0)
   for mode in (False, True):
     ag = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': mode}))
     assert ag.world == world and ag.rank == rank and ag.ops.name == 'hip'
-    state = None
-    for i in range(steps):
+    box = dict(state=None, i=0, m=None)
+    def step():
+      i = box['i']
       batch = batches[i % 3]
       if i >= 3:  # rank-sharded minibatches, as a sharded Agent.dataset yields them
         per = BG // world
         batch = agent_mod.ShardedBatch({k: v[rank * per:(rank + 1) * per] for k, v in batch.items()})
-      _, state, m = ag.train(batch, state)
+      _, box['state'], box['m'] = ag.train(batch, box['state'])
+      box['i'] = i + 1
+    while box['i'] < steps:
+      if tune and mode and box['i'] == 3:
+        ag._pipe.tune(step, force=True)
+      else:
+        step()
+    assert box['i'] == steps, box['i']
+    m = box['m']
     last = ag.flush()
     res[mode] = (ag.save(), last if mode else m)
   if os.environ.get('DD_DP_TUNE') == '1':

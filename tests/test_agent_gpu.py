@@ -21,7 +21,7 @@ def test_policy_matches_oracle(hip, discrete, noise):
 
 @pytest.mark.parametrize('discrete,device_batch', [(False, False), (False, True), (True, True)])
 def test_report_matches_oracle(hip, discrete, device_batch):
-  adopted, draws = agent_cases.report_parity(None, discrete, TOL, device_batch=device_batch)
+  adopted, draws = agent_cases.report_parity(None, discrete, TOL, device_batch=device_batch, calls=3)
   print(f'report: {adopted} of {draws} draws adopted from the device')
   assert adopted <= max(1, draws // 5000)
 
@@ -30,7 +30,7 @@ def test_policy_and_report_match_oracle_resnet(hip):
   """`cnn: resnet`: the residual encoder inside Agent.policy, the residual decoder inside
   Agent.report (open-loop and imagined grids), device minibatch in."""
   agent_cases.policy_parity(None, False, TOL, 0.3, cnn='resnet')
-  adopted, draws = agent_cases.report_parity(None, False, TOL, device_batch=True, cnn='resnet')
+  adopted, draws = agent_cases.report_parity(None, False, TOL, device_batch=True, cnn='resnet', calls=3)
   assert adopted <= max(1, draws // 5000)
 
 

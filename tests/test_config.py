@@ -1,4 +1,5 @@
 import numpy as np
+import pytest
 
 from daydreamer_amd import config, spec, synthetic
 
@@ -81,3 +82,42 @@ def test_config_blocks_mirror_the_reference():
     x, y = flat(ref[block]), flat(ours[block])
     drop = lambda d: {k: v for k, v in d.items() if k != 'train.log_keys_video'}
     assert drop(x) == drop(y), block
+
+
+def test_every_documented_hip_knob_is_settable():
+  """Every `hip.<knob>` that INTEGRATION.md / README.md / DESIGN.md name exists in configs.yaml's
+  `hip:` block and can be set through Config.update (round-4 review: `hip.fused_imag` was
+  documented but `update` raised KeyError), and every key of the block is documented in
+  INTEGRATION.md."""
+  import pathlib
+  import re
+  root = pathlib.Path(__file__).resolve().parents[1]
+  cfg = config.Config(config.load_configs()['defaults'])
+  block = dict(cfg['hip'])
+  named = set()
+  for doc in ('INTEGRATION.md', 'README.md', 'DESIGN.md'):
+    named |= set(re.findall(r'hip\.([a-z_0-9]+)\b', (root / doc).read_text()))
+  named -= {'h', 'so', 'hip'}   # (daydreamer_hip.h, libdaydreamer_hip.so)
+  assert named, 'no knob found in the documents'
+  for knob in sorted(named):
+    assert knob in block, f'hip.{knob} is documented but not in configs.yaml'
+    old = block[knob]
+    new = (not old) if isinstance(old, bool) else old
+    assert cfg.update({f'hip.{knob}': new})['hip'][knob] == new
+  text = (root / 'INTEGRATION.md').read_text()
+  for knob in block:
+    assert f'hip.{knob}' in text, f'hip.{knob} is in configs.yaml but not documented in INTEGRATION.md'
+
+
+def test_pipeline_mode():
+  """hip.pipeline: auto (default) = on for one process, off under data parallelism; a bool set
+  through Config.update arrives as 'True' / 'False'."""
+  from daydreamer_amd.agent import pipeline_mode
+  cfg = config.Config(config.load_configs()['defaults'])
+  assert cfg['hip']['pipeline'] == 'auto'
+  assert pipeline_mode('auto', 1) and not pipeline_mode('auto', 2) and not pipeline_mode('auto', 1, graph=False)
+  for v, want in ((True, True), (False, False), ('true', True), ('false', False)):
+    got = cfg.update({'hip.pipeline': v})['hip']['pipeline']
+    assert pipeline_mode(got, 1) is want and pipeline_mode(got, 4) is want, (v, got)
+  with pytest.raises(AssertionError):
+    pipeline_mode('sometimes', 1)

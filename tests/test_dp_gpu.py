@@ -38,7 +38,7 @@ def free_port():
 def launch(tmp_path, backend, tune=False, ranks=2, batch=6):
   distinct = torch.cuda.device_count() >= ranks
   env = dict(os.environ, DD_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0',
-             DD_PIPE_TUNE='1' if tune else '0', DD_DP_TUNE='1' if tune else '0',
+             DD_DP_TUNE='1' if tune else '0',
              DD_DP_DISTINCT='1' if distinct else '0', DD_DP_BATCH=str(batch))
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks),
          '--master-addr', '127.0.0.1', '--master-port', str(free_port()),

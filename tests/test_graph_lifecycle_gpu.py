@@ -161,7 +161,17 @@ def test_scan_error_word_is_sticky_and_raises(hip):
   assert int(L.scan_sync[1]) == 0
   L.scan_sync[1] = 1                       # what a timed-out spin leaves behind
   with pytest.raises(RuntimeError, match='grid-barrier timeout'):
-    ag.train(data, state)                  # launches reset the counter only: the word survives
-  assert int(L.scan_sync[1]) == 0          # cleared by the read-out
-  _, state, mets = ag.train(data, state)
+    _, _, m = ag.train(data, state)        # launches reset the counter only: the word survives
+    float(m['model_loss'])                 # (pipelined schedule: raised when the call's metrics are looked at)
+  ag.flush()
+  assert int(L.scan_sync[1]) == 0          # cleared by the read-out / the step's snapshot
+  _, state, mets = ag.train(data, None)
   assert helpers.metrics_finite(mets)
+  # nobody looks: it surfaces inside the next call, once - the step enqueued by that call is clean
+  ag.flush()
+  L.scan_sync[1] = 1
+  _, state, m = ag.train(data, state)
+  if isinstance(m, agent_mod.LazyMetrics):
+    with pytest.raises(RuntimeError, match='grid-barrier timeout'):
+      ag.train(data, state)
+    assert helpers.metrics_finite(ag.flush())

@@ -536,6 +536,61 @@ def test_losses(hip, ref):
       close(g, c, rtol=1e-5, what=f'scalar_loss {kind}')
 
 
+@pytest.mark.parametrize('M,N,K', [(300, 512, 1030), (64, 256, 1031), (2500, 512, 1030)])
+def test_gemm_deferred_on_a_ragged_contraction_axis(hip, M, N, K):
+  """HipOps.gemm(..., defer=True) with K % 4 != 0 takes the K-peel path (remainder
+  call into C, then the aligned bulk with beta = 1 and the deferred split-K sum); its Slabs handle
+  fed to ln_act_fwd `pre=` must give what the complete product followed by the same LayerNorm
+  gives, also with a caller beta."""
+  x, W = rnd(M, K, seed=1).cuda(), rnd(K, N, seed=2).cuda()
+  gamma, beta_ln = (1 + 0.1 * rnd(N, seed=3)).cuda(), (0.1 * rnd(N, seed=4)).cuda()
+  c0 = rnd(M, N, seed=5).cuda()
+  for beta in (0.0, 1.0):
+    za, zb = c0.clone(), c0.clone()
+    oa, ob = torch.zeros(M, N, device='cuda'), torch.zeros(M, N, device='cuda')
+    sa, sb = torch.zeros(M, 2, device='cuda'), torch.zeros(M, 2, device='cuda')
+    assert hip.gemm(x, W, za, beta=beta) is None
+    hip.ln_act_fwd(za, gamma, beta_ln, oa, sa, True)
+    pre = hip.gemm(x, W, zb, beta=beta, defer=True)
+    hip.ln_act_fwd(zb, gamma, beta_ln, ob, sb, True, pre=pre)
+    torch.cuda.synchronize()
+    # (pre may be None when the bulk did not split K: then zb is complete like za)
+    close(zb, za.cpu(), rtol=1e-6, what=f'deferred z beta{beta} (pre {"set" if pre is not None else "none"})')
+    close(ob, oa.cpu(), rtol=1e-5, what=f'deferred LayerNorm output beta{beta}')
+    close(sb, sa.cpu(), rtol=1e-5, what=f'deferred LayerNorm statistics beta{beta}')
+
+
+def test_video_grid(hip, ref):
+  """dd_video_grid vs its restatement and vs the host form Agent.report used before (numpy,
+  float64: agent.py:266-282 / tfutils.video_grid tfutils.py:390-392): batch-major and time-major
+  image order, a channel slice of a two-camera tensor, with and without the truth sections."""
+  B, T, hw, ct = 5, 4, 8, 6
+  z = rnd(B * T, hw, hw, ct, seed=1, scale=2.0)
+  img = torch.randint(0, 256, (B * T, hw, hw, ct), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+  nb = 3
+  for c0, c1 in ((0, 6), (3, 6)):
+    cn = c1 - c0
+    for truth in (True, False):
+      for zsb, zst, order in ((T, 1, 'bt'), (1, B, 'tb')):
+        out = torch.zeros(T, (3 if truth else 1) * hw, nb * hw, cn)
+        res = both(hip, ref, lambda ops, z, img, out: ops.video_grid(z, img if truth else None, out, nb, T, c0, c1, zsb, zst),
+                   [z, img, out], [2])
+        for g, c in res:
+          close(g, c, rtol=1e-6, what=f'video_grid {order} truth={truth} channels {c0}:{c1}')
+        zz = z.numpy().astype(np.float64).reshape((B, T) if order == 'bt' else (T, B), hw, hw, ct)
+        ii = img.numpy().reshape(zz.shape)
+        if order == 'tb':
+          zz, ii = zz.transpose(1, 0, 2, 3, 4), ii.transpose(1, 0, 2, 3, 4)
+        m = 1.0 / (1.0 + np.exp(-zz[:nb, ..., c0:c1]))
+        video = m
+        if truth:
+          tr = ii[:nb, ..., c0:c1].astype(np.float64) / 255.0
+          video = np.concatenate([tr, m, (m - tr + 1) / 2], 2)
+        b_, t_, h_, w_, c_ = video.shape
+        want = video.transpose(1, 2, 0, 3, 4).reshape(t_, h_, b_ * w_, c_)
+        assert np.abs(res[0][0].cpu().numpy() - want).max() < 1e-6
+
+
 def test_normal_head(hip, ref):
   rows, A, rows_ent = 400, 16, 300
   om, os, eps = rnd(rows, A, seed=1), rnd(rows, A, seed=2), rnd(rows, A, seed=3)

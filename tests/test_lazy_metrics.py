@@ -62,3 +62,77 @@ def test_fetch_error_surfaces_at_the_look():
   v = m['model_loss']                                                  # collecting is free ...
   with pytest.raises(FloatingPointError):
     float(v)                                                           # ... looking is not
+
+
+def test_value_equality_and_remaining_arithmetic():
+  """A LazyScalar compares by VALUE like the numpy scalar it stands for (the default identity
+  comparison would make `mets[k] == 0.0` silently False) and is unhashable like one."""
+  m = _lazy({'a': np.float32(1.5), 'z': 0.0}, [])
+  a, z = m['a'], LazyScalar(m, 'z')
+  assert isinstance(a, LazyScalar)
+  assert (z == 0.0) and not (z != 0.0) and (a == 1.5) and (a != 2) and (a == LazyScalar(m, 'a'))
+  assert a // 1 == 1.0 and 4 // a == 2.0 and a % 1 == 0.5 and 4 % a == 1.0 and a ** 2 == 2.25 and 2 ** z == 1.0
+  assert +a == 1.5
+  with pytest.raises(TypeError):
+    hash(a)
+
+
+class _FakeStream:
+  def wait_stream(self, s): pass
+  def wait_event(self, e): pass
+  def synchronize(self): pass
+
+
+def test_pipeline_bookkeeping_survives_a_failed_fetch(monkeypatch):
+  """Pipeline.step (agent.py): the handle of the step just enqueued is in place BEFORE the previous
+  step's metrics are resolved, so a FloatingPointError of step k - 1 (raised inside train call k)
+  neither loses step k's metrics nor leaves a stale handle behind; flush() raises a stored error
+  once and leaves the pipeline drained."""
+  import daydreamer_amd.agent as A
+  p = A.Pipeline.__new__(A.Pipeline)   # the host bookkeeping only: no device, no graphs
+  fake = _FakeStream()
+  class Plan:
+    items = [('graph', 1)]
+    def replay_on(self, *a, **k): pass
+  class Ev:
+    def record(self, s): pass
+  p.device, p.s1, p.s2 = 'cpu', fake, fake
+  p.pa1 = p.pa2 = p.pb = Plan()
+  p.ev_in, p.ev_a, p.ev_b = Ev(), Ev(), [Ev(), Ev()]
+  p.pub_a = p.pub_b = [None, None]
+  p.k, p.pending, p.handle, p.keys = 0, None, None, ('model_loss',)
+  monkeypatch.setattr(A.torch.cuda, 'current_stream', lambda d=None: fake)
+  p._publish = lambda pub, stream, clear=False: None
+  bad = {1}
+  def make_read(step):
+    def fn(par):
+      if step in bad:
+        raise FloatingPointError(f'model_norm is not finite (step {step})')
+      return {'model_loss': np.float32(step)}
+    return fn
+  handles = []
+  for step in range(4):
+    p._read = make_read(step)
+    # (the lambda inside step() calls self._read at resolve time: bind this step's reader now)
+    reader = p._read
+    try:
+      h = p.step()
+      h._fetch = (lambda r=reader, par=p.pending: r(par))
+      handles.append(h)
+    except FloatingPointError:
+      # raised by the resolve of step 1 inside call 2: call 2's handle must be the current one
+      assert step == 2 and p.k == 3 and p.pending is not None
+      p.handle._fetch = (lambda r=reader, par=p.pending: r(par))
+      handles.append(p.handle)
+  assert [float(h['model_loss']) for i, h in enumerate(handles) if i != 1] == [0.0, 2.0, 3.0]
+  with pytest.raises(FloatingPointError):
+    handles[1].resolve()
+  # flush: resolves the newest handle, clears the bookkeeping
+  assert float(p.flush()['model_loss']) == 3.0 and p.pending is None and p.handle is None
+  # a failing last step: flush raises once and still drains
+  p._read = make_read(1)
+  h = p.step()
+  h._fetch = (lambda: make_read(1)(0))
+  with pytest.raises(FloatingPointError):
+    p.flush()
+  assert p.pending is None and p.handle is None and p.flush() is None

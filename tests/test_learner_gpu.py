@@ -691,3 +691,62 @@ def test_dataset_stages_minibatches_on_device(hip):
         assert np.array_equal(batch[k][0].cpu().numpy(), v), k
     _, state, mets = ag.train(batch, state)
     assert helpers.metrics_finite(mets)
+
+
+@pytest.mark.parametrize('pipeline', [False, True])
+def test_non_finite_gradient_raises_and_skips_the_update(hip, pipeline):
+  """The check_numerics contract (reference tfutils.py:207,249; SURVEY 8b "Errors") on the HIP path,
+  in both schedules: a non-finite weight makes every gradient norm non-finite; dd_grad_norm's
+  device-side flag makes dd_adam_step skip the update (parameters, Adam moments and step counts
+  untouched) and the host raises FloatingPointError - inside the train call (sequential schedule)
+  or when the call's metrics are looked at, at the latest inside the NEXT train call (pipelined
+  schedule).  Afterwards the agent still checkpoints and trains on."""
+  import numpy as np
+  from daydreamer_amd import agent as agent_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=6, imag_horizon=3)
+  cfg = cfg.update({'hip.pipeline': pipeline})
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  ag = agent_mod.Agent(obs, act, None, cfg)
+  data = synthetic.make_batch(obs, act, 4, 6, seed=3, smooth_images=True)
+  state = None
+  for _ in range(3):
+    _, state, mets = ag.train(data, state)
+  ag.flush()
+  assert isinstance(ag._plan, agent_mod.Pipeline) == pipeline
+  before = ag.save()
+  w = ag.groups['model'].p['reward/dense0/kernel']
+  keep = w[0, 0].clone()
+  w[0, 0] = float('nan')
+  torch.cuda.synchronize()
+  if pipeline:
+    _, state, m1 = ag.train(data, None)          # enqueued; nobody looks at its metrics
+    assert isinstance(m1, agent_mod.LazyMetrics)
+    with pytest.raises(FloatingPointError):
+      ag.train(data, None)                       # ... so it surfaces while the next call is enqueued
+    with pytest.raises(FloatingPointError):
+      float(m1['model_loss'])                    # (and again for whoever looks at that call's metrics)
+    with pytest.raises(FloatingPointError):
+      ag.flush()                                 # the step enqueued by the raising call is non-finite too
+    assert ag.flush() is None                    # raised once; the pipeline is drained
+  else:
+    with pytest.raises(FloatingPointError):
+      ag.train(data, None)
+  after = ag.save()                              # (checkpointing still works)
+  assert before.keys() == after.keys()
+  for k in before:
+    a, b = np.asarray(before[k]), np.asarray(after[k])
+    if k == 'params/reward/dense0/kernel':
+      assert np.isnan(b[0, 0]) and np.array_equal(a.reshape(-1)[1:], b.reshape(-1)[1:])
+    elif k != 'state/noise_step':
+      # parameters, Adam moments, optimizer step counts, the slow critic: untouched.  (The
+      # controllers that are updated before the optimizer - AutoAdapt, Normalize - hold what
+      # the non-finite batch statistics made of them, as in the reference's graph.)
+      if k.startswith(('params/', 'opt/')):
+        assert np.array_equal(a, b, equal_nan=True), k
+  # repair the weight and the controllers, train on from the initial state
+  w[0, 0] = keep
+  ag.load(before)
+  for _ in range(3):
+    _, state, mets = ag.train(data, None if _ == 0 else state)
+    assert helpers.metrics_finite(mets)
+  ag.flush()

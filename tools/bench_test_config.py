@@ -65,6 +65,15 @@ def main():
     float(mets['model_loss'])
   n, warm = (1, 1) if cpu else (50, 5)
   t_train = timed(train, n, warm)
+  mets_box = []
+  def train_lazy():
+    out = ag.train(batch, box[0])
+    box[0] = out[1]
+    mets_box.append(out[2])
+  t_lazy = None
+  if not cpu:
+    t_lazy = timed(lambda: (train_lazy(), mets_box.__delitem__(slice(0, -2))), n, warm)
+    ag.flush()
   o = {k: v[:, 0] for k, v in batch.items() if k not in ('action', 'reset')}
   pst = [None]
   def policy():
@@ -79,7 +88,11 @@ def main():
   print(f'TEST_CONFIG (batch {B} x chunk {T}, horizon {H}, one-hot 5-way action, units 128, cnn_depth 16, '
         f'deter 1024, stoch 32x32){" on the CPU kernels" if cpu else " on the MI355X"}:')
   print(f'  agent.train   {t_train:8.3f} ms  = {B * T * H / t_train * 1e3:9.0f} imagined env-steps/s   '
-        f'(reference test bound <= 26 ms, >= 36.9 k steps/s; tests.py:70-71)')
+        f'(reference test bound <= 26 ms, >= 36.9 k steps/s; tests.py:70-71; the metrics of every call looked at '
+        f'before the next call)')
+  if t_lazy is not None:
+    print(f'  agent.train   {t_lazy:8.3f} ms  = {B * T * H / t_lazy * 1e3:9.0f} imagined env-steps/s   '
+          f'(metrics collected per call, looked at later: run/train.py:77-85)')
   print(f'  agent.policy  {t_policy:8.3f} ms  (batch {B}; reference test bound <= 9.1 ms; tests.py:88-89)')
   print(f'  agent.report  {t_report:8.3f} ms  (reference test bound <= 13 ms; tests.py:105-106)')
 

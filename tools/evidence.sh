@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 K=10; W=3
 for mode in 0 1; do
   rm -rf /tmp/prof$mode
-  DD_PIPE_TUNE=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof$mode -o b -- python $GRAFT_REPO_ROOT/bench.py --child --steps $K --warmup $W --no-cpu-baseline --pmc off --pipeline $mode > /tmp/prof$mode.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof$mode -o b -- python $GRAFT_REPO_ROOT/bench.py --child --steps $K --warmup $W --no-cpu-baseline --pmc off --pipeline $mode > /tmp/prof$mode.log 2>&1
   DB=$(ls /tmp/prof$mode/*/*.db /tmp/prof$mode/*.db 2>/dev/null | head -1)
   # (the child run makes max(W, 3) + K train calls and nothing else)
   python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $DB $((K + W)) > $GRAFT_REPO_ROOT/gpurun_out/${tag}_rocprof_kernel_stats_pipeline$mode.csv 2>> /tmp/prof$mode.log
