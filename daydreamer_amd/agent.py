@@ -328,18 +328,24 @@ class Pipeline:
   phase was measured at 62 / 99 instead of 43.5 ms per step).  Which two matters: ROCm multiplexes
   HIP streams onto a few hardware queues in creation order, and the steady-state step time falls
   into three classes by the pair the phases (and their graphs' internal branches) land on -
-  29.4 / 31.1 / 33.5 ms at configs[1] (profiles/r05_pipe_pairs.txt, two boxes).  The pair is a
-  CACHED CHOICE: DEFAULT_PAIR of a pool of four streams created together, in the fast class on
-  every box measured (DD_PIPE_PAIR=a,b overrides it).  `tune()` re-measures all twelve ordered
-  pairs at steady state (explicit, ~100 train steps; Agent.tune_pipeline) for a process whose
-  other streams shift the queue assignment, e.g. after initialising an RCCL group.
+  29.4 / 31.1 / 33.5 ms at configs[1] - and which pairs are in the fast class differs from
+  process to process (profiles/r05_pipe_pairs.txt).  So the pair is MEASURED, once per process
+  and device, inside the first pipelined train calls of the first pipelined agent: every ordered
+  pair of a pool of four streams runs TRIAL consecutive real train steps, the time between the
+  behaviour-phase ends of its last steps (device events: steady state, both phases of consecutive
+  steps in flight) is its period, the fastest pair is kept for every later agent (BEST) and the
+  other pairs' graphs are retired.  12 pairs x 4 steps; parameters stay bit-identical through the
+  switches.  `hip.tune_pipeline: false` (or DD_PIPE_TUNE=0) skips it and runs DEFAULT_PAIR (or
+  DD_PIPE_PAIR=a,b).  (Rounds 2-4 measured three-step trials from their first tick: the transient
+  after a switch, not the period - their choice was noise.)
   """
 
   DEFAULT_PAIR = (1, 3)
   POOLS = {}  # device -> ([4 phase streams], read-out stream)
-  BEST = {}   # device -> pair selected by tune() in this process
+  BEST = {}   # device -> pair measured in this process
+  TRIAL = 4   # train steps per candidate pair: one after the switch, one more, two measured periods
 
-  def __init__(self, learner, device, comm=None):
+  def __init__(self, learner, device, comm=None, tune=True):
     self.L = learner
     self.device = device
     self.comm = comm  # data-parallel: communicator of the metric read-out
@@ -361,6 +367,9 @@ class Pipeline:
       assert pair in self.cands, pair
     self.pair = None
     self._use_pair(*pair)
+    self.tuned = (key in Pipeline.BEST or not tune or os.environ.get('DD_PIPE_TUNE', '1') == '0'
+                  or 'DD_PIPE_PAIR' in os.environ)
+    self.k_tune, self.ticks = 0, []
     self.ev_in = torch.cuda.Event()
     self.ev_a = torch.cuda.Event()
     self.ev_b = [torch.cuda.Event(), torch.cuda.Event()]
@@ -399,6 +408,8 @@ class Pipeline:
     are fetched here (after this step's world-model phase has been enqueued), if the caller has
     not looked at them yet.  The caller's current stream holds the uploaded inputs."""
     cur = torch.cuda.current_stream(self.device)
+    if not self.tuned:
+      self._tune_step()   # (first pipelined agent of the process: this step's stream pair)
     s1, s2 = self.s1, self.s2
     par = self.k & 1
     s1.wait_stream(cur)                    # inputs / carry reset issued by the caller
@@ -423,6 +434,10 @@ class Pipeline:
     self.pb.replay_on(s2)
     self._publish(self.pub_b[par], s2)
     self.ev_b[par].record(s2)
+    if not self.tuned:
+      tick = torch.cuda.Event(enable_timing=True)
+      tick.record(s2)
+      self.ticks.append(tick)
     cur.wait_event(self.ev_in)             # the next upload must not overtake A1's reads
     # this step's handle is in place BEFORE the previous one is resolved: if that raises (a loss
     # of step k - 1 is not finite) the step just enqueued keeps its metrics and the pipeline its
@@ -434,43 +449,52 @@ class Pipeline:
       prev.resolve()   # (its snapshot slot is the one the NEXT step publishes into)
     return self.handle
 
-  WARM, TIMED = 2, 6  # steps per candidate pair of tune(): untimed, timed
+  def _tune_step(self):
+    """Stream pair of the step about to be enqueued while the selection is being measured."""
+    c, r = divmod(self.k_tune, self.TRIAL)
+    self.k_tune += 1
+    if r != 0:
+      return
+    if c > 0:
+      # the trial that just ended: two periods between the behaviour-phase ends of its steps
+      # 1 .. 3 (step 0 ran next to the previous pair's last behaviour phase)
+      t0, t1 = self.ticks[-3], self.ticks[-1]
+      t1.synchronize()
+      self.periods[self.cands[c - 1]] = t0.elapsed_time(t1) / 2
+    self.ticks = []
+    if c < len(self.cands):
+      a, b = self.cands[c]
+    else:
+      a, b = min(self.periods, key=self.periods.get)
+      if self.comm is not None:
+        # data parallel: every rank measured its own periods in lock-step; all of them run the
+        # pair rank 0 chose (different pairs per rank = different skew at every collective)
+        pick = torch.tensor([a, b], dtype=torch.int64, device=self.device)
+        self.comm.dist.broadcast(pick, src=0, group=self.comm.group)
+        a, b = int(pick[0]), int(pick[1])
+      Pipeline.BEST[self.key] = (a, b)
+      self.tuned = True
+    if (a, b) != self.pair:
+      # (steps on different pairs are ordered by events, ev_a / ev_b; the host only waits here
+      # because a first use of a pair captures its graphs)
+      self.s1.synchronize()
+      self.s2.synchronize()
+      self._use_pair(a, b)
+    if self.tuned:
+      # the losing pairs' graphs (3 plans x 11 pairs) are not needed again: retire them (they are
+      # destroyed by a later capture, after a device-wide synchronize - graphs.py)
+      for key in [k for k in self.plans if k != (a, b)]:
+        for plan in self.plans.pop(key):
+          plan.release()
 
   def tune(self, run_step, force=False):
-    """Choose the stream pair by measurement: every ordered pair of the pool runs WARM + TIMED
-    real train steps (run_step() performs one, through step()) between two drains of the
-    pipeline, the wall time of the TIMED ones (steady state: both phases of consecutive steps
-    in flight) is its period; the fastest pair is kept for every pipelined agent of the process
-    and the losing pairs' graphs are retired.  No-op once a pair has been measured in this
-    process, unless `force`."""
-    if self.key in Pipeline.BEST and not force:
-      return
-    self.periods = {}
-    for a, b in self.cands:
-      self.flush()
-      self._use_pair(a, b)
-      for _ in range(self.WARM):
-        run_step()
-      self.flush()
-      t0 = time.perf_counter()
-      for _ in range(self.TIMED):
-        run_step()
-      self.flush()
-      self.periods[(a, b)] = 1e3 * (time.perf_counter() - t0) / self.TIMED
-    a, b = min(self.periods, key=self.periods.get)
-    if self.comm is not None:
-      # data parallel: every rank measured its own periods in lock-step; all of them run the
-      # pair rank 0 chose (different pairs per rank = different skew at every collective)
-      pick = torch.tensor([a, b], dtype=torch.int64, device=self.device)
-      self.comm.dist.broadcast(pick, src=0, group=self.comm.group)
-      a, b = int(pick[0]), int(pick[1])
-    Pipeline.BEST[self.key] = (a, b)
-    self._use_pair(a, b)
-    # the losing pairs' graphs (3 plans x 11 pairs) are not needed again: retire them (they are
-    # destroyed by a later capture, after a device-wide synchronize - graphs.py)
-    for key in [k for k in self.plans if k != (a, b)]:
-      for plan in self.plans.pop(key):
-        plan.release()
+    """Finish the stream-pair measurement now instead of inside the next train calls: run_step()
+    must perform one train step (through step()).  No-op once a pair has been measured in this
+    process, unless `force` (measure again, e.g. after the process created other streams)."""
+    if force:
+      self.k_tune, self.periods, self.ticks, self.tuned = 0, {}, [], False
+    while not self.tuned:
+      run_step()
 
   def _read(self, par):
     """Fetch the metrics of the step with parity `par` (its snapshot slots).  May run on
@@ -734,7 +758,8 @@ class Agent:
       L.reset_carry()
     if self._pipeline and self._train_calls >= 1 and 'key' not in data:
       if self._pipe is None:
-        self._pipe = Pipeline(L, self.device, self.comm_m)
+        self._pipe = Pipeline(L, self.device, self.comm_m,
+                              tune=bool(self.cfg.get('hip', {}).get('tune_pipeline', True)))
         self._pipe.keys = tuple(self._last_metrics)   # (the first call of a learner is eager)
         self._plan = self._pipe
       metrics = self._last_metrics = self._pipe.step()   # this call's metrics, fetched lazily
@@ -764,9 +789,9 @@ class Agent:
   train_step = train  # BASELINE.json names the learner step `train_step`
 
   def tune_pipeline(self, data, state=None, force=False):
-    """Optional: re-measure the pipeline's stream pair (12 pairs x 8 real train steps on `data`;
-    see Pipeline.tune) instead of using the cached default.  Returns the recurrent state to
-    continue from.  No-op with the sequential schedule."""
+    """Optional: finish (force: repeat) the pipeline's stream-pair measurement now, with train
+    steps on `data` (12 pairs x 4 steps; see Pipeline), instead of inside the next train calls.
+    Returns the recurrent state to continue from.  No-op with the sequential schedule."""
     box = [state]
     if not self._pipeline:
       return state

@@ -4,6 +4,11 @@ import pathlib
 
 import pytest
 
+# the pipelined agent's stream-pair measurement (its first 48 pipelined train calls switch pairs
+# and capture each pair's graphs) is off in the tests, which build many short-lived agents; the
+# tests of the measurement itself force it (tests/test_learner_gpu.py, tests/test_dp_gpu.py)
+os.environ.setdefault('DD_PIPE_TUNE', '0')
+
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 if str(ROOT) not in sys.path:
   sys.path.insert(0, str(ROOT))

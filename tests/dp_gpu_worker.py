@@ -48,9 +48,7 @@ def main():
   # pair of the pool, real train steps of the same sequence the sequential agent runs); every
   # rank must then run the pair rank 0 chose
   tune = os.environ.get('DD_DP_TUNE') == '1'
-  if tune:
-    agent_mod.Pipeline.WARM, agent_mod.Pipeline.TIMED = 1, 2
-  steps = 6 + (12 * 3 if tune else 0)
+  steps = 6 + (12 * agent_mod.Pipeline.TRIAL + 1 if tune else 0)
   for mode in (False, True):
     ag = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': mode}))
     assert ag.world == world and ag.rank == rank and ag.ops.name == 'hip'

@@ -100,7 +100,7 @@ def test_pipeline_bookkeeping_survives_a_failed_fetch(monkeypatch):
   p.pa1 = p.pa2 = p.pb = Plan()
   p.ev_in, p.ev_a, p.ev_b = Ev(), Ev(), [Ev(), Ev()]
   p.pub_a = p.pub_b = [None, None]
-  p.k, p.pending, p.handle, p.keys = 0, None, None, ('model_loss',)
+  p.k, p.pending, p.handle, p.keys, p.tuned = 0, None, None, ("model_loss",), True
   monkeypatch.setattr(A.torch.cuda, 'current_stream', lambda d=None: fake)
   p._publish = lambda pub, stream, clear=False: None
   bad = {1}

@@ -750,3 +750,42 @@ def test_non_finite_gradient_raises_and_skips_the_update(hip, pipeline):
     _, state, mets = ag.train(data, None if _ == 0 else state)
     assert helpers.metrics_finite(mets)
   ag.flush()
+
+
+def test_stream_pair_measurement_keeps_parameters_bit_identical(hip):
+  """The pipelined agent's stream-pair measurement (agent.Pipeline: 12 ordered pairs x TRIAL real
+  train steps inside the first pipelined calls, each pair with its own captured graphs): the steps
+  it runs are ordinary train steps - parameters, moments and metrics after it equal the
+  sequential schedule's, bit for bit - and the selected pair is cached for the process."""
+  import numpy as np
+  from daydreamer_amd import agent as agent_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=6, imag_horizon=3)
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  batches = [synthetic.make_batch(obs, act, 4, 6, seed=s, smooth_images=True) for s in range(3)]
+  n = 2 + 12 * agent_mod.Pipeline.TRIAL + 1 + 3
+  runs = {}
+  keep = dict(agent_mod.Pipeline.BEST)
+  try:
+    for mode in (False, True):
+      ag = agent_mod.Agent(obs, act, None, cfg.update({'hip.pipeline': mode}))
+      state = None
+      for i in range(n):
+        if mode and i == 2:
+          assert ag._pipe is not None
+          ag._pipe.k_tune, ag._pipe.periods, ag._pipe.ticks, ag._pipe.tuned = 0, {}, [], False   # (DD_PIPE_TUNE=0 in the tests)
+        _, state, m = ag.train(batches[i % 3], state)
+      last = ag.flush() or m
+      if mode:
+        pipe = ag._pipe
+        assert pipe.tuned and len(pipe.periods) == 12 and all(p > 0 for p in pipe.periods.values())
+        assert agent_mod.Pipeline.BEST[pipe.key] == pipe.pair == min(pipe.periods, key=pipe.periods.get)
+        assert list(pipe.plans) == [pipe.pair]            # the losing pairs' graphs are retired
+      runs[mode] = (ag.save(), dict(last))
+  finally:
+    agent_mod.Pipeline.BEST.clear()
+    agent_mod.Pipeline.BEST.update(keep)
+  (sa, ma), (sb, mb) = runs[False], runs[True]
+  for k in sa:
+    assert np.array_equal(np.asarray(sa[k]), np.asarray(sb[k]), equal_nan=True), k
+  for k in ma:
+    assert np.array_equal(ma[k], mb[k], equal_nan=True), k

@@ -27,7 +27,7 @@ for _ in range(2):
   _, state, _ = ag.train(data, state)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-state = ag.tune_pipeline(data, state)
+state = ag.tune_pipeline(data, state, force=True)
 ag.flush()
 torch.cuda.synchronize()
 print(f'tuning wall time {time.perf_counter() - t0:.2f} s')
