@@ -138,7 +138,7 @@ def pmc_live(argv_tail, timeout=170):
     cmd = [exe, '--pmc', counter, '--kernel-trace', '-d', out, '-o', 'b', '--output-format', 'csv', '--',
            sys.executable, os.path.abspath(__file__), '--child', '--steps', '2', '--warmup', '3',
            '--no-cpu-baseline', '--pmc', 'off'] + argv_tail
-    env = dict(os.environ, TMPDIR='/tmp', PYTHONPATH=ROOT)
+    env = dict(os.environ, TMPDIR='/tmp', PYTHONPATH=ROOT, DD_PIPE_TUNE='0')   # (the counters only need the kernels: skip the 48 stream-pair trial steps)
     try:
       subprocess.run(cmd, env=env, cwd='/tmp', timeout=timeout, check=True,
                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

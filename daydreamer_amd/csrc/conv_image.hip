@@ -342,7 +342,7 @@ template <int KS, int NT, typename TB>
 __global__ void __launch_bounds__(256, 2)
 k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, const float* __restrict__ bias,
                   float* __restrict__ small, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, int OPK,
-                  float in_scale, int tiles_j, int tiles_i, int n_tiles) {
+                  float in_scale, int tiles_j, int tiles_i, int n_tiles, int dbg) {
   constexpr int EPV = sizeof(TB) == 1 ? 16 : 4;        // elements per 16-byte vector
   constexpr int RMAX = 12, RSMAX = 264;                // staged rows (k + 6 <= 12), row stride (elements, wb*Cb + 8 <= 264): 19 KB
   __shared__ __attribute__((aligned(16))) unsigned short patch[3][RMAX * RSMAX];
@@ -376,7 +376,7 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int id = tid + 256 * v;
-      if (id < nvec) {
+      if (id < nvec && !((dbg & 8) && pre[v].x != 0x12345u)) {
         const int r = id / vec_per_row, c = (id - r * vec_per_row) * EPV;
         float f[EPV];
         if constexpr (sizeof(TB) == 1) {
@@ -423,6 +423,7 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r16 = lane & 15, q = lane >> 4;
+    if (!(dbg & 2))
 #pragma unroll
     for (int s_ = 0; s_ < KS; ++s_) {
       const int o = s_ * 4 + q;
@@ -459,7 +460,7 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
       }
     }
     // ---- epilogue: elements (rows (lane >> 4) * 4 + r = channels, column lane & 15 = output column) of tile (m, t)
-    if (i < hs) {
+    if (i < hs && !(dbg & 4)) {
       float* dst = small + ((img * hs + i) * (long)ws_) * Cs;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -503,12 +504,13 @@ int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const flo
   if (nt_ > (1 << 30)) return 1;
   const int n_tiles = (int)nt_;
   const int grid = n_tiles < 512 ? n_tiles : 512;
+  static const int dbg = getenv("DD_IMG_DBG") ? atoi(getenv("DD_IMG_DBG")) : 0;   // measurement aid: 2 no MFMAs, 4 no stores, 8 no staging
 #define LD(KS_)                                                                                        \
   if (KS == KS_) {                                                                                     \
     if (big_is_u8) k_conv_image_down<KS_, 4, unsigned char><<<grid, 256, 0, st>>>(                     \
-        (const unsigned char*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles); \
+        (const unsigned char*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles, dbg); \
     else k_conv_image_down<KS_, 4, float><<<grid, 256, 0, st>>>(                                       \
-        (const float*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles); \
+        (const float*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles, dbg); \
   }
   LD(2) LD(3) LD(5)
 #undef LD

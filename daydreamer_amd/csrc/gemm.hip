@@ -22,6 +22,9 @@ int g_gemm_mode = -1;
 int g_ws_select[3] = {-1, 1024, 1024};
 
 extern "C" int dd_gemm_set_ws(int on, int kmin, int kmin_tc) {
+#ifndef DD_BUILD_WS
+  DD_REQUIRE(!on, "dd_gemm_set_ws: the role-separated loop is not in this build (make WS=1)");
+#endif
   ws_selected(0, false);   // (environment defaults first)
   const int prev = g_ws_select[0];
   g_ws_select[0] = on ? 1 : 0;

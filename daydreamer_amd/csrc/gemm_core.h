@@ -1310,7 +1310,8 @@ k_mfma_gemm_ws(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 // The same record shows why: with ZERO operands the identical instruction stream runs 4096^3 in
 // 484 us instead of 717 (284 vs 191 TFLOP/s) - the loop is bound by the chip's power-limited
 // clock on real data (~1.55 vs ~2.3 GHz), not by its schedule, so a schedule that keeps the matrix
-// pipe busier is paid back in clock.  Kept as a selectable variant (dd_gemm_set_ws / DD_WS=1;
+// pipe busier is paid back in clock.  Kept as a selectable variant of an opt-in build (`make WS=1`
+// defines DD_BUILD_WS; the default library does not instantiate it) (dd_gemm_set_ws / DD_WS=1;
 // launches with >= DD_WS_KMIN contraction elements per split-K slab, DD_WS_KMIN_TC for the banded
 // transposed-convolution launches) and covered by the parity tests (bit-identical results).
 inline bool ws_selected(int kps, bool tile_ctx) {
@@ -1378,12 +1379,14 @@ void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps,
 #endif
     k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false, DD_A2_64><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   } else {
+#ifdef DD_BUILD_WS   // (`make WS=1`: the role-separated loop, measured equal in steady state - not in the default build)
     if constexpr (BM == 128 && BN == 128) {
       if (ws_selected(kps, has_tile_ctx<AL>::value)) {
         k_mfma_gemm_ws<AKC, BKC, AL, BL, EP><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tm);
         return;
       }
     }
+#endif
     k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 2, true><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   }
 }

@@ -3,8 +3,8 @@
 # kernel stats of the train loop (default schedule and pipeline), PMC HBM traffic, phase / scan /
 # imagination / call-site timings, the other BASELINE config shards.  Writes gpurun_out/<tag>_*;
 # copy what is to be judged into profiles/.
-#   gpurun --timeout 2400 -- 'bash tools/evidence.sh r04'
-tag=${1:-r04}
+#   gpurun --timeout 2400 -- 'bash tools/evidence.sh r05'
+tag=${1:-r05}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rA 2>&1 | tail -260 > gpurun_out/${tag}_pytest_gpu.log)
 (timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1)
@@ -17,10 +17,10 @@ cd /tmp && export TMPDIR=/tmp
 K=10; W=3
 for mode in 0 1; do
   rm -rf /tmp/prof$mode
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof$mode -o b -- python $GRAFT_REPO_ROOT/bench.py --child --steps $K --warmup $W --no-cpu-baseline --pmc off --pipeline $mode > /tmp/prof$mode.log 2>&1
+  DD_PIPE_TUNE=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof$mode -o b -- python $GRAFT_REPO_ROOT/bench.py --child --steps $K --warmup $W --no-cpu-baseline --pmc off --pipeline $mode > /tmp/prof$mode.log 2>&1
   DB=$(ls /tmp/prof$mode/*/*.db /tmp/prof$mode/*.db 2>/dev/null | head -1)
   # (the child run makes max(W, 3) + K train calls and nothing else)
-  python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $DB $((K + W)) > $GRAFT_REPO_ROOT/gpurun_out/${tag}_rocprof_kernel_stats_pipeline$mode.csv 2>> /tmp/prof$mode.log
+  python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $DB $((K + W)) $W > $GRAFT_REPO_ROOT/gpurun_out/${tag}_rocprof_kernel_stats_pipeline$mode.csv 2>> /tmp/prof$mode.log
 done
 cd $GRAFT_REPO_ROOT
 bash tools/pmc_bench.sh > gpurun_out/${tag}_pmc_hbm_traffic.txt 2>&1

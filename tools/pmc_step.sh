@@ -9,7 +9,7 @@
 # GRBM_GUI_ACTIVE / 8 XCDs is printed beside it - its window is wider than a short kernel).
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_step
-PYTHONPATH=$GRAFT_REPO_ROOT timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_step -o s --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --child --steps 3 --warmup 3 --no-cpu-baseline --pmc off > /tmp/pmc_step.log 2>&1
+DD_PIPE_TUNE=0 PYTHONPATH=$GRAFT_REPO_ROOT timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_step -o s --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --child --steps 3 --warmup 3 --no-cpu-baseline --pmc off > /tmp/pmc_step.log 2>&1
 python - <<'PY'
 import csv, glob, collections, re
 cc = glob.glob("/tmp/pmc_step/**/*counter_collection*.csv", recursive=True)
