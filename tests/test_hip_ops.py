@@ -580,7 +580,7 @@ def test_video_grid(hip, ref):
                    [z, img, out], [2])
         for g, c in res:
           close(g, c, rtol=1e-6, what=f'video_grid {order} truth={truth} channels {c0}:{c1}')
-        zz = z.numpy().astype(np.float64).reshape((B, T) if order == 'bt' else (T, B), hw, hw, ct)
+        zz = z.numpy().astype(np.float64).reshape(((B, T) if order == 'bt' else (T, B)) + (hw, hw, ct))
         ii = img.numpy().reshape(zz.shape)
         if order == 'tb':
           zz, ii = zz.transpose(1, 0, 2, 3, 4), ii.transpose(1, 0, 2, 3, 4)
