@@ -329,11 +329,11 @@ class Pipeline:
   HIP streams onto a few hardware queues in creation order, and the steady-state step time falls
   into three classes by the pair the phases (and their graphs' internal branches) land on -
   29.4 / 31.1 / 33.5 ms at configs[1] - and which pairs are in the fast class differs from
-  process to process (profiles/r05_pipe_pairs.txt).  So the pair is MEASURED, once per process
-  and device, inside the first pipelined train calls of the first pipelined agent: every ordered
+  process to process (profiles/r05_pipe_pairs.txt).  So the pair is MEASURED by every pipelined
+  learner inside its first pipelined train calls: every ordered
   pair of a pool of four streams runs TRIAL consecutive real train steps, the time between the
   behaviour-phase ends of its last steps (device events: steady state, both phases of consecutive
-  steps in flight) is its period, the fastest pair is kept for every later agent (BEST) and the
+  steps in flight) is its period, the fastest pair is kept and the
   other pairs' graphs are retired.  12 pairs x 4 steps; parameters stay bit-identical through the
   switches.  `hip.tune_pipeline: false` (or DD_PIPE_TUNE=0) skips it and runs DEFAULT_PAIR (or
   DD_PIPE_PAIR=a,b).  (Rounds 2-4 measured three-step trials from their first tick: the transient
@@ -342,7 +342,7 @@ class Pipeline:
 
   DEFAULT_PAIR = (1, 3)
   POOLS = {}  # device -> ([4 phase streams], read-out stream)
-  BEST = {}   # device -> pair measured in this process
+  BEST = {}   # device -> the pair the latest measurement of this process selected (a record)
   TRIAL = 4   # train steps per candidate pair: one after the switch, one more, two measured periods
 
   def __init__(self, learner, device, comm=None, tune=True):
@@ -360,15 +360,15 @@ class Pipeline:
     # one set of captured graphs per stream pair: a graph executable is only ever
     # launched on one stream (relaunching it on another one crashes the runtime)
     self.plans = {}
-    pair = Pipeline.BEST.get(key)
-    if pair is None:
-      env = os.environ.get('DD_PIPE_PAIR')
-      pair = tuple(int(x) for x in env.split(',')) if env else Pipeline.DEFAULT_PAIR
-      assert pair in self.cands, pair
+    env = os.environ.get('DD_PIPE_PAIR')
+    pair = tuple(int(x) for x in env.split(',')) if env else Pipeline.DEFAULT_PAIR
+    assert pair in self.cands, pair
     self.pair = None
     self._use_pair(*pair)
-    self.tuned = (key in Pipeline.BEST or not tune or os.environ.get('DD_PIPE_TUNE', '1') == '0'
-                  or 'DD_PIPE_PAIR' in os.environ)
+    # (every Pipeline measures for itself: the class a pair falls into also depends on how the
+    # runtime laid out THIS learner's graph executables - a second agent of one process ran
+    # 31.4 ms on the pair the first one had measured at 29.4, tools/interleaved_loop.py)
+    self.tuned = not tune or os.environ.get('DD_PIPE_TUNE', '1') == '0' or env is not None
     self.k_tune, self.ticks = 0, []
     self.ev_in = torch.cuda.Event()
     self.ev_a = torch.cuda.Event()
@@ -489,8 +489,8 @@ class Pipeline:
 
   def tune(self, run_step, force=False):
     """Finish the stream-pair measurement now instead of inside the next train calls: run_step()
-    must perform one train step (through step()).  No-op once a pair has been measured in this
-    process, unless `force` (measure again, e.g. after the process created other streams)."""
+    must perform one train step (through step()).  No-op once this pipeline has measured (or
+    with the measurement switched off), unless `force`."""
     if force:
       self.k_tune, self.periods, self.ticks, self.tuned = 0, {}, [], False
     while not self.tuned:
@@ -618,9 +618,8 @@ class Agent:
       # side context of the behaviour phase (heads of finished time chunks next to the
       # imagination rollout, learner.phase_imagine)
       hipc = self.cfg.get('hip', {})
-      piped = pipeline_mode(hipc.get('pipeline', 'auto'), self.world, bool(hipc.get('graph', True)))
       self.ops_b2 = (hipops.HipOps(self.device, ws_bytes=1024 << 20)
-                     if hipc.get('overlap_heads', True) and not piped else None)
+                     if hipc.get('overlap_heads', True) else None)
     else:
       self.ops = _ops
       self.ops2 = None
@@ -633,6 +632,17 @@ class Agent:
     self._noise_seed = int(hip.get('noise_seed', 0))
     # two-stream pipeline of consecutive steps (class Pipeline): 'auto' = on for world size 1
     self._pipeline = pipeline_mode(hip.get('pipeline', 'auto'), self.world, self._use_graph)
+    # `auto` also follows the caller's loop.  The pipeline only pays while train calls follow each
+    # other (the learner process of run/learning.py): policy / report / save between two train
+    # calls must drain it (they read weights the phase in flight writes), and a drained pipeline is
+    # the sequential step WITHOUT its in-step overlaps (~1 ms slower at configs[1]).  So after
+    # ADAPT train calls in a row that each followed such a call (run/train.py: act, then train) the
+    # sequential plan is replayed instead, and after ADAPT train calls in a row without one the
+    # pipeline again.  Both schedules produce the same parameters bit for bit, so switching is
+    # invisible apart from the metrics' type (host values / LazyMetrics).
+    self._adaptive = self._pipeline and str(hip.get('pipeline', 'auto')).strip().lower() == 'auto'
+    self._touched, self._streak_touched, self._streak_clean, self._prefer_seq = False, 0, 0, False
+    self._seq_plan = None
     # rank-sharded prefetch: every rank assembles and uploads only its own rows
     self._shard_dataset = bool(hip.get('shard_dataset', True))
     self.comm_b = self.comm_m = None
@@ -747,7 +757,7 @@ class Agent:
       if saved is not None:
         self.learner.import_state(saved)
       L = self.learner
-      self._plan, self._pipe, self._train_calls = None, None, 0
+      self._plan, self._pipe, self._seq_plan, self._train_calls = None, None, None, 0
     carry = isinstance(state, TrainState) and state.owner is L
     if self._pipe is not None and not carry:
       # reset_carry reads world-model weights and writes the carried state on this
@@ -756,19 +766,30 @@ class Agent:
     L.upload(self._shard(data))
     if not carry:
       L.reset_carry()
-    if self._pipeline and self._train_calls >= 1 and 'key' not in data:
+    if self._adaptive:
+      if self._touched:
+        self._streak_touched, self._streak_clean = self._streak_touched + 1, 0
+      else:
+        self._streak_touched, self._streak_clean = 0, self._streak_clean + 1
+      self._touched = False
+      if self._streak_touched >= self.ADAPT:
+        self._prefer_seq = True
+      elif self._streak_clean >= self.ADAPT:
+        self._prefer_seq = False
+    if self._pipeline and not self._prefer_seq and self._train_calls >= 1 and 'key' not in data:
       if self._pipe is None:
         self._pipe = Pipeline(L, self.device, self.comm_m,
                               tune=bool(self.cfg.get('hip', {}).get('tune_pipeline', True)))
         self._pipe.keys = tuple(self._last_metrics)   # (the first call of a learner is eager)
-        self._plan = self._pipe
+      self._plan = self._pipe
       metrics = self._last_metrics = self._pipe.step()   # this call's metrics, fetched lazily
       self._train_calls += 1
       return {}, TrainState(L), metrics
     self.flush()
     if self._use_graph and self._train_calls >= 1:
-      if self._plan is None or isinstance(self._plan, Pipeline):
-        self._plan = L.capture()
+      if self._seq_plan is None:
+        self._seq_plan = L.capture()
+      self._plan = self._seq_plan
       self._plan.replay()
     else:
       L.train_step_device(True)
@@ -787,6 +808,7 @@ class Agent:
     return outs, TrainState(L), metrics
 
   train_step = train  # BASELINE.json names the learner step `train_step`
+  ADAPT = 4           # consecutive train calls of one kind before `hip.pipeline: auto` switches schedule
 
   def tune_pipeline(self, data, state=None, force=False):
     """Optional: finish (force: repeat) the pipeline's stream-pair measurement now, with train
@@ -822,6 +844,7 @@ class Agent:
            for k, v in obs.items() if not k.startswith('log_')}
     n = len(obs['is_first'])
     self._ensure_params()
+    self._touched = True
     self.flush()  # (pipelined mode: the behaviour phase in flight still writes the actor)
     P = self._policies.get(n)
     if P is None:
@@ -870,6 +893,7 @@ class Agent:
     data = {k: (v if isinstance(v, torch.Tensor) else np.asarray(v))
             for k, v in data.items() if not k.startswith('log_')}
     B, T = data['is_first'].shape[:2]
+    self._touched = True
     self.flush()
     self._ensure_params()
     key = ('report', B, T)
@@ -953,6 +977,7 @@ class Agent:
 
   def save(self):
     self._ensure_params()
+    self._touched = True
     self.flush()
     L = self.learner
     out = {f'params/{k}': v for k, v in L.export_params().items()}

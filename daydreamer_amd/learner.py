@@ -148,6 +148,9 @@ class Learner:
     # ops_b2: the behaviour phase's own side context: the reward / cont / slow-critic heads of
     # finished time chunks run next to the rest of the (latency-bound) imagination rollout
     self.ops_b2 = ops_b2
+    # (off while the pipelined schedule's behaviour phase is captured: there the next step's
+    # world-model phase fills the chip next to the rollout, a third stream only competes)
+    self.overlap_b = True
     self.side_stream_b = (graphs.stream(self.device, 'side_b')
                           if ops_b2 is not None and self.device.type == 'cuda' else None)
     self.dtype = dtype  # float32 in the product; tests may use float64
@@ -1551,7 +1554,7 @@ class Learner:
       # (agent.py:391-396: then heads['critic_target'] aliases the online parameters)
       self.head_fwd('critic_target', self.acts_im['critic_target'], x, sel)
     side = self.side_stream_b   # (None on CPU: the chunks then run inline, same arithmetic)
-    if self.ops_b2 is None or not self._in_b:
+    if self.ops_b2 is None or not self._in_b or not self.overlap_b:
       self.imagine_rollout()
       heads(0, M)
     else:
@@ -1759,7 +1762,7 @@ class Learner:
       # the reverse scan as one persistent launch (dd_imagine_rollout_bwd) after the bulk heads
       heads_bwd(0, H + 1)
       self.imagine_reverse_fused()
-    elif self.ops_b2 is None or not self._in_b:
+    elif self.ops_b2 is None or not self._in_b or not self.overlap_b:
       heads_bwd(0, H + 1)
       for t in reversed(range(1, H + 1)):
         scan_step(t)
@@ -1913,11 +1916,15 @@ class Learner:
     optimizer + hand-over | behaviour phase) for the two-stream software pipeline of
     agent.Agent: step k's behaviour phase runs next to step k+1's world-model phase."""
     plans = []
-    for fn in (lambda: self.phase_a1(True), self.phase_wm_opt, self.phase_b):
-      plan = graphs.GraphPlan(self.device)
-      self.plan = plan
-      plan.capture(fn)
-      plans.append(plan)
+    keep, self.overlap_b = self.overlap_b, False
+    try:
+      for fn in (lambda: self.phase_a1(True), self.phase_wm_opt, self.phase_b):
+        plan = graphs.GraphPlan(self.device)
+        self.plan = plan
+        plan.capture(fn)
+        plans.append(plan)
+    finally:
+      self.overlap_b = keep
     return plans
 
   def metric_tensors(self):

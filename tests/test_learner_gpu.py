@@ -789,3 +789,45 @@ def test_stream_pair_measurement_keeps_parameters_bit_identical(hip):
     assert np.array_equal(np.asarray(sa[k]), np.asarray(sb[k]), equal_nan=True), k
   for k in ma:
     assert np.array_equal(ma[k], mb[k], equal_nan=True), k
+
+
+def test_auto_schedule_follows_the_callers_loop(hip):
+  """hip.pipeline: auto (the default).  Train calls in a row (the learner process of
+  run/learning.py) run the two-stream pipeline; once every train call follows a policy call
+  (run/train.py: act, then train - each policy call drains the pipeline, which then is the
+  sequential step without its in-step overlaps) the sequential plan is replayed instead, and
+  the pipeline again when the train calls come in a row again.  Parameters are those of the
+  sequential schedule throughout, bit for bit."""
+  import numpy as np
+  from daydreamer_amd import agent as agent_mod, synthetic
+  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=4, replay_chunk=6, imag_horizon=3)
+  obs, act = synthetic.make_spaces(64, 5, 3)
+  batches = [synthetic.make_batch(obs, act, 4, 6, seed=s, smooth_images=True) for s in range(3)]
+  o = {k: v[:, 0] for k, v in batches[0].items() if k not in ('action', 'reset')}
+  K = agent_mod.Agent.ADAPT
+  pattern = [False] * (K + 2) + [True] * (K + 3) + [False] * (K + 2)     # policy call before the train call?
+  runs = {}
+  for mode in ('auto', False):
+    ag = agent_mod.Agent(obs, act, None, cfg if mode == 'auto' else cfg.update({'hip.pipeline': False}))
+    state, pst, kinds = None, None, []
+    for i, act_first in enumerate(pattern):
+      if act_first:
+        _, pst = ag.policy(o, pst, 'train')
+      _, state, m = ag.train(batches[i % 3], state)
+      kinds.append(isinstance(m, agent_mod.LazyMetrics))
+    last = dict(ag.flush() or m)
+    if mode == 'auto':
+      a, b = K + 2, 2 * K + 5
+      assert kinds[0] is False and all(kinds[1:a])                 # eager first call, then pipelined
+      assert all(kinds[a:a + K - 1]) and not any(kinds[a + K - 1:b])   # K calls behind a policy call: sequential plan
+      assert ag._seq_plan is not None and ag._pipe is not None
+      assert not any(kinds[b:b + K - 1]) and all(kinds[b + K - 1:])    # K calls in a row again: pipelined
+      assert ag._plan is ag._pipe
+    else:
+      assert not any(kinds)
+    runs[mode] = (ag.save(), last)
+  (sa, ma), (sb, mb) = runs['auto'], runs[False]
+  for k in sa:
+    assert np.array_equal(np.asarray(sa[k]), np.asarray(sb[k]), equal_nan=True), k
+  for k in ma:
+    assert np.array_equal(ma[k], mb[k], equal_nan=True), k
