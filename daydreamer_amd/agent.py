@@ -674,6 +674,7 @@ class Agent:
     self._plan = None
     self._train_calls = 0
     self._policies = {}
+    self._policy_plans = {}   # (rows, sample, noise amount) -> captured Agent.policy launch sequence
     self._pending_load = None
 
   # ------------------------------------------------------------------ helpers
@@ -866,7 +867,25 @@ class Agent:
     if isinstance(state, PolicyState):
       b['action'].copy_(state.action_dev)
     noise = self.cfg['eval_noise'] if mode == 'eval' else self.cfg['expl_noise']
-    act = P.policy_device(sample=(mode != 'eval'), noise=float(noise))
+    # The device work of a policy call is one fixed launch sequence per (batch, sample / mode,
+    # noise amount): run eagerly once, then replayed from a HIP graph (~60 launches on a handful
+    # of rows are pure launch latency: 0.96 -> 0.4 ms per call at the reference's TEST_CONFIG).
+    sample = mode != 'eval'
+    entry = self._policy_plans.setdefault((n, sample, float(noise)), dict(calls=0, plan=None))
+    if entry['plan'] is not None:
+      entry['plan'].replay()
+      act = entry['act']
+    else:
+      act = entry['act'] = P.policy_device(sample=sample, noise=float(noise))
+      if self._use_graph and entry['calls'] >= 1:   # (second call: lazily created buffers exist)
+        plan = graphs.GraphPlan(self.device)
+        P.plan = plan
+        try:
+          plan.capture(lambda: P.policy_device(sample=sample, noise=float(noise)))
+        finally:
+          P.plan = graphs.EagerPlan()
+        entry['plan'] = plan
+      entry['calls'] += 1
     st = PolicyState(b['carry'].clone(), None)
     st.action_dev = act.clone()
     action = act.cpu().numpy().astype(np.float32).reshape((n,) + tuple(self.act_space.shape))
