@@ -29,7 +29,6 @@ bash tools/pmc_bench.sh > gpurun_out/${tag}_pmc_hbm_traffic.txt 2>&1
 (timeout 200 python tools/trace_shapes.py > gpurun_out/${tag}_contraction_call_sites.txt 2>&1)
 (timeout 200 python tools/imag_time.py > gpurun_out/${tag}_fused_imagination_times.txt 2>&1)
 (timeout 200 python tools/ln_bench.py > gpurun_out/${tag}_ln_bandwidth.txt 2>&1)
-(timeout 300 python tools/ws_steady.py 120 > gpurun_out/${tag}_ws_steady.txt 2>&1)
 (timeout 200 python bench.py --cnn resnet --steps 4 --warmup 2 --no-cpu-baseline --pmc off > gpurun_out/${tag}_bench_resnet.json 2>/dev/null)
 (timeout 120 python tools/graph_stress.py --iters 45 > gpurun_out/${tag}_graph_stress.log 2>&1)
 (timeout 300 python tools/dp_preflight.py --gpus 1 2>&1 | grep -a preflight > gpurun_out/${tag}_dp_preflight_1rank_rccl.log)
