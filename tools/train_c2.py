@@ -10,7 +10,7 @@ cfg = config_mod.Config(cfgs['defaults']).update(cfgs['a1_vision'])
 obs, act = synthetic.make_spaces(64, 16, 16)
 ag = agent_mod.Agent(obs, act, None, cfg)
 batches = [synthetic.make_batch(obs, act, 50, 50, seed=s, smooth_images=True, terminals=0.01) for s in range(8)]
-state = ag.tune_pipeline(batches[0])  # one-time stream-pair selection (38 untimed train steps)
+state = ag.tune_pipeline(batches[0])  # finish the stream-pair trial steps (real train steps, untimed)
 torch.cuda.synchronize()
 t0 = time.time()
 for i in range(steps):
