@@ -409,7 +409,7 @@ class Pipeline:
     not looked at them yet.  The caller's current stream holds the uploaded inputs."""
     cur = torch.cuda.current_stream(self.device)
     if not self.tuned:
-      self._tune_step()   # (first pipelined agent of the process: this step's stream pair)
+      self._tune_step()   # (the stream pair of this step, while the pairs are being measured)
     s1, s2 = self.s1, self.s2
     par = self.k & 1
     s1.wait_stream(cur)                    # inputs / carry reset issued by the caller
@@ -493,7 +493,13 @@ class Pipeline:
     with the measurement switched off), unless `force`."""
     if force:
       self.k_tune, self.periods, self.ticks, self.tuned = 0, {}, [], False
+    budget = 2 * (len(self.cands) * self.TRIAL + 1) + 8
     while not self.tuned:
+      # (run_step() that does not come through step() - a minibatch with replay keys, which takes
+      # the sequential path - would never finish the measurement)
+      budget -= 1
+      if budget < 0:
+        raise RuntimeError('Pipeline.tune: run_step() does not perform pipelined train steps')
       run_step()
 
   def _read(self, par):
@@ -816,8 +822,9 @@ class Agent:
     steps on `data` (12 pairs x 4 steps; see Pipeline), instead of inside the next train calls.
     Returns the recurrent state to continue from.  No-op with the sequential schedule."""
     box = [state]
-    if not self._pipeline:
+    if not self._pipeline or 'key' in data:
       return state
+    self._prefer_seq, self._streak_touched, self._touched = False, 0, False
     for _ in range(2 if self._pipe is None else 0):   # eager step + pipeline creation
       _, box[0], _ = self.train(data, box[0])
     if self._pipe is not None:
