@@ -75,6 +75,7 @@ _SIGS = {
     'dd_onehot_policy_grad': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p],
     'dd_philox': [c_p, c_l, c_l, c_i, c_l, c_l, c_ull, c_p, c_u, c_i, c_p],
     'dd_counter_add': [c_p, c_ull, c_p],
+    'dd_reduce_stats_multi': [c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'dd_reduce_stats': [c_p, c_l, c_l, c_p, c_p, c_p],
     'dd_autoadapt_update': [c_p, c_p, c_i, c_d, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_p],
     'dd_normalize_update': [c_p, c_p, c_d, c_p, c_d, c_d, c_i, c_i, c_p, c_p],
@@ -108,7 +109,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
-ABI_VERSION = 7   # include/daydreamer_hip.h DD_ABI_VERSION
+ABI_VERSION = 8   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -726,6 +727,19 @@ class HipOps:
     self._check(self.lib.dd_reduce_stats(
         p, x.shape[0], stride, sums.data_ptr(), maxs.data_ptr(), self.stream),
         'dd_reduce_stats')
+
+  def reduce_stats_multi(self, items):
+    """reduce_stats of several (x, sums, maxs) triples in launches of up to 16 vectors."""
+    for i0 in range(0, len(items), 16):
+      part = items[i0:i0 + 16]
+      k = len(part)
+      vec = [_vec(x) for x, _, _ in part]
+      xs = (ctypes.c_void_p * k)(*[v[0] for v in vec])
+      ns = (ctypes.c_long * k)(*[x.shape[0] for x, _, _ in part])
+      st = (ctypes.c_long * k)(*[v[1] for v in vec])
+      sm = (ctypes.c_void_p * k)(*[s_.data_ptr() for _, s_, _ in part])
+      mx = (ctypes.c_void_p * k)(*[m.data_ptr() for _, _, m in part])
+      self._check(self.lib.dd_reduce_stats_multi(k, xs, ns, st, sm, mx, self.stream), 'dd_reduce_stats_multi')
 
   def autoadapt_update(self, scale, sums, count, target, thres, vel, lo, hi,
                        inverse, impl='mult'):

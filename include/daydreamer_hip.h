@@ -31,8 +31,8 @@ extern "C" {
  * 6: dd_adam_step gained `float warmup` in front of `stream`; the `sync2` buffer of
  * dd_observe_scan_fwd / _bwd grew from 2 to 1088 words (the launches clear 512 row-block counters
  * at word 576: a caller with the old 2-word buffer gets an out-of-bounds device write).
- * 7 (round 5): dd_video_grid added. */
-#define DD_ABI_VERSION 7
+ * 7 (round 5): dd_video_grid added.  8: dd_reduce_stats_multi added. */
+#define DD_ABI_VERSION 8
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -357,6 +357,10 @@ int dd_philox(float* out, long outer, long inner, int cols, long inner_global,
 int dd_counter_add(unsigned long long* counter, unsigned long long v, void* stream);
 /* sums = {sum, sum sq, sum abs} (fp64), maxs = {max, max(-x), max|x|}. */
 int dd_reduce_stats(const float* x, long n, long stride, double* sums, float* maxs, void* stream);
+/* dd_reduce_stats of `count` <= 16 vectors in one launch (HOST arrays of device pointers / sizes;
+ * the same sums / maxs per vector, bit for bit).  (ABI 8.) */
+int dd_reduce_stats_multi(int count, const float* const* x, const long* n, const long* stride,
+                          double* const* sums, float* const* maxs, void* stream);
 int dd_autoadapt_update(float* scale, const double* sums, int n, double count,
                         float target, float thres, float vel, float lo, float hi,
                         int inverse, int impl, void* stream);

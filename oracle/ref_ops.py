@@ -605,6 +605,10 @@ class RefOps:
     maxs[1] = (-x).max()
     maxs[2] = x.abs().max()
 
+  def reduce_stats_multi(self, items):
+    for x, sums, maxs in items:
+      self.reduce_stats(x, sums, maxs)
+
   def autoadapt_update(self, scale, sums, count, target, thres, vel, lo, hi,
                        inverse, impl='mult'):
     n = scale.numel()

@@ -563,6 +563,23 @@ def test_gemm_deferred_on_a_ragged_contraction_axis(hip, M, N, K):
     close(sb, sa.cpu(), rtol=1e-5, what=f'deferred LayerNorm statistics beta{beta}')
 
 
+def test_reduce_stats_multi_equals_single_launches(hip):
+  """dd_reduce_stats_multi: the step's metric statistics as one launch - the same sums and
+  extrema as dd_reduce_stats per vector, bit for bit (same block shape, same summation order),
+  strided views and more than 16 vectors included."""
+  xs = [rnd(n, seed=i, scale=1.0 + i).cuda() for i, n in enumerate([2500, 40000, 37500, 1, 7, 2500, 1024] + [300] * 12)]
+  xs[5] = rnd(2500, 3, seed=50).cuda()[:, 1]          # a column view (stride 3)
+  one = [(torch.zeros(3, dtype=torch.float64, device='cuda'), torch.zeros(3, device='cuda')) for _ in xs]
+  many = [(torch.zeros(3, dtype=torch.float64, device='cuda'), torch.zeros(3, device='cuda')) for _ in xs]
+  for x, (s_, m) in zip(xs, one):
+    hip.reduce_stats(x, s_, m)
+  hip.reduce_stats_multi([(x, s_, m) for x, (s_, m) in zip(xs, many)])
+  torch.cuda.synchronize()
+  for i, ((s1, m1), (s2, m2)) in enumerate(zip(one, many)):
+    assert torch.equal(s1, s2) and torch.equal(m1, m2), i
+  assert abs(float(one[1][0][0]) - float(xs[1].double().sum())) < 1e-6 * 40000
+
+
 def test_video_grid(hip, ref):
   """dd_video_grid vs its restatement and vs the host form Agent.report used before (numpy,
   float64: agent.py:266-282 / tfutils.video_grid tfutils.py:390-392): batch-major and time-major
