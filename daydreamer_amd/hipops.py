@@ -99,6 +99,7 @@ _SIGS = {
     'dd_imag_wprep_t': [c_p, c_l, c_i, c_i, c_p, c_p],
     'dd_imagine_rollout_bwd': [c_i] * 7 + [c_f] + [ctypes.POINTER(c_p), c_i, c_p],
     'dd_imagine_rollout_fwd': [c_i] * 10 + [c_f] * 3 + [ctypes.POINTER(c_p), c_i, c_p],
+    'dd_imagine_rollout_oh_fwd': [c_i] * 11 + [c_f] * 2 + [ctypes.POINTER(c_p), c_i, c_p],
     'dd_stream_create': [ctypes.POINTER(c_p)],
     'dd_stream_destroy': [c_p],
     'dd_graph_capture_begin': [c_p],
@@ -109,7 +110,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
-ABI_VERSION = 8   # include/daydreamer_hip.h DD_ABI_VERSION
+ABI_VERSION = 9   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -533,6 +534,25 @@ class HipOps:
     self._check(self._traced(f'imagine N{N} H{H} B{nbytes}', flops, lambda: self.lib.dd_imagine_rollout_fwd(
         N, H, t0, t1, D, U, G, C, A, actor_units, unimix, lo, hi, arr, n, self.stream)),
         'dd_imagine_rollout_fwd')
+
+  def imagine_rollout_oh_fwd(self, N, H, D, U, G, C, A, actor_units, row_width, unimix, actor_unimix,
+                             tensors, t0=0, t1=None):
+    """tensors: the 64 device tensors of dd_imagine_rollout_oh_fwd, in header order."""
+    t1 = H + 1 if t1 is None else t1
+    n = len(tensors)
+    assert n == 64
+    for t in tensors:
+      assert t.is_contiguous() or t.dim() == 2
+    arr = (c_p * n)(*[t.data_ptr() for t in tensors])
+    S, F, AU = G * C, D + G * C, actor_units
+    actor = F * AU + 3 * AU * AU + AU * A
+    img = (S + A) * U + (D + U) * 3 * D + U * D + 2 * U * U + U * S
+    na, ni = t1 - t0, min(t1, H) - t0    # policy evaluations, img_steps of this launch
+    flops = 2.0 * N * (na * actor + ni * img)
+    nbytes = 4 * (actor + img) + 4 * N * (na * (F + A + 8 * AU + 2 * A) + ni * (2 * U + 3 * D + 6 * U + S))
+    self._check(self._traced(f'imagine N{N} H{H} B{nbytes}', flops, lambda: self.lib.dd_imagine_rollout_oh_fwd(
+        N, H, t0, t1, D, U, G, C, A, actor_units, row_width, unimix, actor_unimix, arr, n, self.stream)),
+        'dd_imagine_rollout_oh_fwd')
 
   # ---- categorical latent -----------------------------------------------------
 

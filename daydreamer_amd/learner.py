@@ -460,10 +460,12 @@ class Learner:
     # kernels index rows by F + A themselves, so shapes they cover keep the exact width.
     ca = self.cfg['actor']
     self.fused_imag = (bool(self.cfg.get('hip', {}).get('fused_imag', True)) and
-                       self.dtype == torch.float32 and hasattr(self.ops, 'imagine_rollout_fwd') and H >= 1 and
+                       self.dtype == torch.float32 and H >= 1 and
+                       hasattr(self.ops, 'imagine_rollout_oh_fwd' if self.discrete else 'imagine_rollout_fwd') and
                        self.ops.imagine_rollout_supported(D, U, G, self.C, A, ca['units'], ca['layers'],
                                                           self.n_prior, self.discrete))
-    self.TW = F + A if self.fused_imag else (F + A + 3) // 4 * 4
+    # (the one-hot kernel takes the row width as an argument and keeps the padded rows)
+    self.TW = F + A if (self.fused_imag and not self.discrete) else (F + A + 3) // 4 * 4
     W = self.TW
     b['traj'] = z(H + 1, N, W)     # [deter | stoch | action | zero padding]
     b['dtraj'] = z(H + 1, N, W)
@@ -491,23 +493,28 @@ class Learner:
       pl['actor0'] = (layers[0].W[:D], i16(D, ca['units']), 0)
       for i in range(1, ca['layers']):
         pl[f'actor{i}'] = (layers[i].W, i16(ca['units'], ca['units']), 0)
-      head = i16(ca['units'], 2 * A)
-      pl['head_m'] = (outs[0].W, head, 0)
-      pl['head_s'] = (outs[1].W, head, A)
+      if self.discrete:
+        pl['head'] = (outs[0].W, i16(ca['units'], A), 0)
+      else:
+        head = i16(ca['units'], 2 * A)
+        pl['head_m'] = (outs[0].W, head, 0)
+        pl['head_s'] = (outs[1].W, head, A)
       pl['gru'] = (self.P['gru'].W, i16(D + U, 3 * D), 0)
       for i in range(self.n_prior):
         pl[f'img_out{i}'] = (self.P[f'img_out_{i}'].W, i16(D if i == 0 else U, U), 0)
       pl['stats'] = (self.P['img_stats'].W, i16(U, S), 0)
       # transposed caches of the reverse pass (dd_imag_wprep_t: W [n, K] -> operand [K, n])
+      # (one-hot actions: actor_grad reinforce has no reverse pass through the rollout)
       self.fused_imag_bwd = (bool(self.cfg.get('hip', {}).get('fused_imag_bwd', True)) and
-                             hasattr(self.ops, 'imagine_rollout_bwd'))
+                             hasattr(self.ops, 'imagine_rollout_bwd') and not self.discrete)
       plt = self.imag_planes_t = {}
-      plt['stats'] = (self.P['img_stats'].W, i16(S, U))            # [U, S] -> K = S, n = U
-      for i in range(self.n_prior):
-        Wl = self.P[f'img_out_{i}'].W
-        plt[f'img_out{i}'] = (Wl, i16(Wl.shape[1], Wl.shape[0]))
-      plt['gru'] = (self.P['gru'].W, i16(3 * D, D + U))             # [D+U, 3D] -> K = 3D, n = D+U
-      plt['img_in'] = (self.P['img_in'].W, i16(U, S + A))           # [S+A, U] -> K = U, n = S+A
+      if self.fused_imag_bwd:
+        plt['stats'] = (self.P['img_stats'].W, i16(S, U))            # [U, S] -> K = S, n = U
+        for i in range(self.n_prior):
+          Wl = self.P[f'img_out_{i}'].W
+          plt[f'img_out{i}'] = (Wl, i16(Wl.shape[1], Wl.shape[0]))
+        plt['gru'] = (self.P['gru'].W, i16(3 * D, D + U))             # [D+U, 3D] -> K = 3D, n = D+U
+        plt['img_in'] = (self.P['img_in'].W, i16(U, S + A))           # [S+A, U] -> K = U, n = S+A
     for k in ('value', 'cont', 'weight', 'value2', 'ent_row'):
       b['i_' + k] = z(M)
     for k in ('reward', 'ret', 'ret2', 'diff', 'crit_loss', 'critic', 'actor_loss',
@@ -1516,6 +1523,8 @@ class Learner:
     pl = self.imag_planes
     layers, outs = self.heads['actor']
     acts, oacts = self.acts_im['actor']
+    if self.discrete:
+      return self._imagine_rollout_fused_onehot(t0, t1)
     t = [b['traj'], b['u_img'], b['eps']]
     for i in range(ca['layers']):
       t += [pl[f'actor{i}'][1], layers[i].gamma, layers[i].beta, acts[i].z, acts[i].stats, acts[i].out]
@@ -1531,6 +1540,27 @@ class Learner:
       t.append(self.imag_stamps)
     ops.imagine_rollout_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'],
                             self.unimix, ca['minstd'], ca['maxstd'], t, t0, t1)
+
+  def _imagine_rollout_fused_onehot(self, t0=0, t1=None):
+    """dd_imagine_rollout_oh_fwd (csrc/imag_oh.hip): the one-hot / REINFORCE rollout at deter =
+    units = 512 as one persistent launch, forward only."""
+    ops, b, cfg, P = self.ops, self.b, self.cfg, self.P
+    ca, pl = cfg['actor'], self.imag_planes
+    layers, outs = self.heads['actor']
+    acts, oacts = self.acts_im['actor']
+    t = [b['traj'], b['u_img'], b['u_act']]
+    for i in range(ca['layers']):
+      t += [pl[f'actor{i}'][1], layers[i].gamma, layers[i].beta, acts[i].z, acts[i].stats, acts[i].out]
+    t += [layers[0].W, pl['head'][1], outs[0].bias, oacts[0].z, b['alogit']]
+    ai = self.ai_img_in
+    t += [P['img_in'].W, P['img_in'].gamma, P['img_in'].beta, ai.z, ai.stats, ai.out]
+    t += [pl['gru'][1], P['gru_h'].gamma, P['gru_h'].beta, b['iz3'], b['igstats']]
+    for i in range(self.n_prior):
+      L, a = P[f'img_out_{i}'], self.ai_img_out[i]
+      t += [pl[f'img_out{i}'][1], L.gamma, L.beta, a.z, a.stats, a.out]
+    t += [pl['stats'][1], P['img_stats'].bias, self.ai_img_stats.z]
+    ops.imagine_rollout_oh_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'], self.TW,
+                               self.unimix, float(ca['unimix']), t, t0, t1)
 
   def imagine_reverse_fused(self):
     """Steps t = H .. 1 of the reverse imagination scan (stats / img_out / GRU / img_in backward)

@@ -31,8 +31,9 @@ extern "C" {
  * 6: dd_adam_step gained `float warmup` in front of `stream`; the `sync2` buffer of
  * dd_observe_scan_fwd / _bwd grew from 2 to 1088 words (the launches clear 512 row-block counters
  * at word 576: a caller with the old 2-word buffer gets an out-of-bounds device write).
- * 7 (round 5): dd_video_grid added.  8: dd_reduce_stats_multi added. */
-#define DD_ABI_VERSION 8
+ * 7 (round 5): dd_video_grid added.  8: dd_reduce_stats_multi added.
+ * 9: dd_imagine_rollout_oh_fwd added; dd_imagine_rollout_supported answers discrete = 1 shapes. */
+#define DD_ABI_VERSION 9
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -449,6 +450,17 @@ int dd_imagine_rollout_supported(int D, int U, int G, int C, int A, int actor_un
 int dd_imagine_rollout_fwd(int N, int H, int t0, int t1, int D, int U, int G, int C, int A,
                            int actor_units, float unimix, float lo, float hi,
                            const void* const* ptrs, int n_ptrs, void* stream);
+/* The same for ONE-HOT action spaces (actor_grad 'reinforce', agent.py:357-358: no gradient through
+ * the dynamics, so forward only) at deter = units = 512 (xarm / ur5 blocks, configs.yaml:245-295):
+ * policy head = Linear(A) + unimix softmax + inverse-CDF draw (the class dd_stats_sample_fwd draws
+ * from u_act, bit for bit); writes the actor's activations, its raw logits, normalised
+ * log-probabilities, the one-hot actions and states of traj[t0 + 1 .. t1 - 1] (rows of `row_width`
+ * floats, a multiple of four >= deter + stoch + A), and the img_step buffers the launch sequence
+ * writes.  `ptrs`: HOST array of 64 device pointers, order at the definition (csrc/imag_oh.hip).
+ * Shapes: dd_imagine_rollout_supported(..., discrete = 1).  (ABI 9.) */
+int dd_imagine_rollout_oh_fwd(int N, int H, int t0, int t1, int D, int U, int G, int C, int A,
+                              int actor_units, int row_width, float unimix, float actor_unimix,
+                              const void* const* ptrs, int n_ptrs, void* stream);
 
 /* ---- launch runtime: process-owned streams and HIP-graph segments ------------------------
  * Role of the reference's concrete-function cache (tfagent.py:56-70, tf.function :60-64): the

@@ -65,8 +65,10 @@ def test_fused_imagination_shape_queries():
   q = lib.dd_imagine_rollout_supported
   assert q(256, 256, 32, 32, 16, 512, 4, 3, 0) == 1      # configs[1]
   assert q(256, 256, 32, 32, 6, 512, 4, 3, 0) == 1       # configs[0]
-  assert q(256, 256, 32, 32, 16, 512, 4, 3, 1) == 0      # one-hot actions: REINFORCE path
-  assert q(512, 512, 32, 32, 6, 512, 4, 3, 1) == 0       # xarm / ur5
+  assert q(256, 256, 32, 32, 16, 512, 4, 3, 1) == 0      # one-hot actions at 256: launch sequence
+  assert q(512, 512, 32, 32, 6, 512, 4, 3, 1) == 1       # xarm / ur5: forward-only one-hot rollout (imag_oh.hip)
+  assert q(512, 512, 32, 32, 6, 512, 4, 3, 0) == 0       # continuous actions at 512: launch sequence
+  assert q(512, 512, 32, 32, 9, 512, 4, 3, 1) == 0       # (the serial action draw covers <= 8 classes)
   assert q(4096, 256, 64, 64, 16, 512, 4, 3, 0) == 0     # a1_scaled
   assert q(256, 256, 32, 32, 16, 512, 2, 3, 0) == 0      # debug block: 2 actor layers
   assert q(256, 256, 32, 32, 16, 256, 4, 3, 0) == 0

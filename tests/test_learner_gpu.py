@@ -297,6 +297,71 @@ def test_fused_imagination_rollout_equals_launch_sequence(hip):
     torch.cuda.empty_cache()
 
 
+def test_fused_onehot_rollout_equals_launch_sequence(hip):
+  """csrc/imag_oh.hip: the one-hot / REINFORCE rollout at deter = units = 512 (xarm / ur5 blocks) as
+  ONE persistent launch, forward only, against the per-layer launch sequence inside a whole train
+  step on the same minibatch and weights: at the xarm shard's row count (25 x 50), on a ragged row
+  count and with the 4-class instantiation.  Rows whose latent AND action draws all agree must
+  agree in every buffer the actor's backward pass and the heads read; the losses and the actor /
+  critic gradient norms of the step agree to the tolerance of the oracle parity tests."""
+  for (B, T, H, adim) in ((25, 50, 15, 6), (7, 5, 4, 6), (3, 4, 3, 4)):
+    plain, sp, shapes, params, data = helpers.make_named_problem('xarm', B, T, horizon=H)
+    if adim != 6:   # the 4-class instantiation: same networks, another action space
+      from daydreamer_amd import spec as spec_mod, synthetic
+      obs, act = synthetic.config_spaces('xarm')
+      act['action'] = synthetic.Space(np.float32, (adim,), 0, 1)
+      act['action'].discrete = True
+      sp = spec_mod.build_spec(plain, shapes, adim, True)
+      params = spec_mod.init_params(sp, 0)
+      data = synthetic.make_batch(obs, act, B, T, seed=2, terminals=0.01, smooth_images=True)
+      idx = np.random.RandomState(3).randint(0, adim, (B, T))
+      data['action'] = np.eye(adim, dtype=np.float32)[idx]
+    Ls, mets = [], []
+    for fused in (True, False):
+      plain2 = dict(plain, hip=dict(plain.get('hip', {}), fused_imag=fused))
+      sp2 = type(sp)(**{**sp.__dict__, 'cfg': plain2})
+      L = learner_mod.Learner(sp2, hip, 'cuda:0', B, T, params=params, noise_seed=7)
+      assert L.discrete and L.fused_imag == fused and not L.fused_imag_bwd
+      L.upload(data)
+      L.train_step_device(use_carry=False)
+      torch.cuda.synchronize()
+      mets.append(L.read_metrics())
+      Ls.append(L)
+    A, Bq = Ls
+    N, G, C, D, F, Ad = A.N, A.G, A.C, A.D, A.F, A.A
+    assert A.TW == Bq.TW == (F + Ad + 3) // 4 * 4
+    ta, tb = A.b['traj'], Bq.b['traj']
+    sa, sb = ta[:, :, D:F].reshape(H + 1, N, G, C), tb[:, :, D:F].reshape(H + 1, N, G, C)
+    aa, ab = ta[:, :, F:F + Ad], tb[:, :, F:F + Ad]
+    assert torch.equal(sa.sum(-1), torch.ones_like(sa.sum(-1))) and torch.equal(aa.sum(-1), torch.ones_like(aa.sum(-1)))
+    assert float(ta[:, :, F + Ad:].abs().max()) == 0.0 if A.TW > F + Ad else True      # the padding stays zero
+    same = ((sa.argmax(-1) == sb.argmax(-1)).all(-1) & (aa.argmax(-1) == ab.argmax(-1))).all(0)
+    flipped = int((~same).sum())
+    print(f'fused one-hot rollout B{B} T{T} H{H} A{adim}: {flipped} of {N} rows contain a flipped draw')
+    assert flipped <= max(1, N // 40)
+    def cmp(x, y, what, rows_per_t, tol=5e-5):
+      x = x.reshape(rows_per_t, N, -1)[:, same].double()
+      y = y.reshape(rows_per_t, N, -1)[:, same].double()
+      err = float((x - y).abs().max() / (y.abs().max() + 1e-30))
+      assert err < tol, (what, err)
+    cmp(ta, tb, 'traj', H + 1)
+    la, lb = A.acts_im['actor'], Bq.acts_im['actor']
+    for i in range(len(la[0])):
+      cmp(la[0][i].z, lb[0][i].z, f'actor{i}.z', H + 1)
+      cmp(la[0][i].stats, lb[0][i].stats, f'actor{i}.stats', H + 1)
+      cmp(la[0][i].out, lb[0][i].out, f'actor{i}.out', H + 1)
+    cmp(la[1][0].z, lb[1][0].z, 'actor logits', H + 1)
+    cmp(A.b['alogit'], Bq.b['alogit'], 'actor log-probabilities', H + 1)
+    cmp(A.b['iz3'], Bq.b['iz3'], 'z3', H)
+    cmp(A.ai_img_stats.z, Bq.ai_img_stats.z, 'img_stats', H)
+    if flipped == 0:
+      for k in ('model_loss', 'extr_critic_loss', 'actor_loss', 'actor_grad_norm', 'extr_critic_grad_norm', 'actent_mean'):
+        a_, b_ = float(mets[0][k]), float(mets[1][k])
+        assert abs(a_ - b_) <= 1e-3 * max(abs(b_), 1e-2), (k, a_, b_)
+    del Ls, A, Bq
+    torch.cuda.empty_cache()
+
+
 def test_fused_imagination_reverse_equals_launch_sequence(hip):
   """csrc/imag.hip k_imagine_reverse: the data gradient of the imagined rollout (steps H .. 1 of
   draw / img_stats / img_out / GRU / img_in backward) as ONE persistent launch against the
