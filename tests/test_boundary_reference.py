@@ -51,3 +51,37 @@ def test_reference_run_loop_drives_agent(tmp_path):
   assert a.keys() == b.keys()
   for k in a:
     assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+def test_lazy_metrics_through_the_reference_logger():
+  """What the pipelined agent's train() returns (a LazyMetrics of LazyScalars) through the
+  reference's own consumers: run/train.py:77-85 collects the values per call and takes
+  np.nanmean at the log interval, embodied.Logger.add does np.array(value) and accepts ranks
+  0 / 2 / 3 / 4 (core/logger.py:25-33), the JSON-lines output formats floats."""
+  import collections
+  sys.modules.setdefault('gym', types.ModuleType('gym'))
+  sys.path.insert(0, str(REF))
+  import embodied
+  from daydreamer_amd.agent import LazyMetrics
+  fetched = []
+  def lazy(i):
+    vals = {'model_loss': np.float32(10.0 - i), 'actor_loss': np.float32(float('nan') if i == 1 else i)}
+    return LazyMetrics(tuple(vals), lambda: (fetched.append(i), vals)[1])
+  step = embodied.Counter()
+  seen = []
+  logger = embodied.Logger(step, [seen.extend])
+  metrics = collections.defaultdict(list)
+  for i in range(3):                                   # run/train.py:77-78
+    mets = lazy(i)
+    [metrics[key].append(value) for key, value in mets.items()]
+    step.increment()
+  assert not fetched                                   # collecting never waited for the device
+  for name, values in metrics.items():                 # run/train.py:83-85
+    logger.scalar('train/' + name, np.nanmean(values, dtype=np.float64))
+  logger.add(lazy(7), prefix='last')                   # a LazyMetrics handed to the logger as it is
+  logger.write()
+  got = {name: float(value) for _, name, value in seen}
+  assert got['train/model_loss'] == pytest.approx(9.0) and got['train/actor_loss'] == pytest.approx(1.0)
+  assert got['last/model_loss'] == pytest.approx(3.0) and got['last/actor_loss'] == pytest.approx(7.0)
+  assert sorted(fetched) == [0, 1, 2, 7]
+  assert all(np.asarray(value).shape == () for _, _, value in seen)
