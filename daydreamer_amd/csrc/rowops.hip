@@ -171,7 +171,9 @@ template <int LPR, int V>
 __global__ void __launch_bounds__(256)
 k_ln_act_fwd_v(float* __restrict__ z, long ldz, const float* __restrict__ gamma,
                const float* __restrict__ beta, float* __restrict__ out, long ldo,
-               float* __restrict__ stats, long lds, int rows, int C, int act, PreSum ps) {
+               float* __restrict__ stats, long lds, int rows, int C, int act, PreSum ps,
+               const float* __restrict__ head_w = nullptr, const float* __restrict__ head_b = nullptr,
+               float* __restrict__ head_out = nullptr) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -181,6 +183,7 @@ k_ln_act_fwd_v(float* __restrict__ z, long ldz, const float* __restrict__ gamma,
     const bool live = row < rows;
     float4 x[V];
     float s = 0.f;
+    float hd = 0.f;   // head_w: the one-unit output layer behind this layer, out . w (+ b), folded in
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       int c = (l + LPR * i) * 4;
@@ -221,9 +224,17 @@ k_ln_act_fwd_v(float* __restrict__ z, long ldz, const float* __restrict__ gamma,
           y.w = (x[i].w - mean) * rstd * g.w + bb.w;
           if (act) { y.x = elu_(y.x); y.y = elu_(y.y); y.z = elu_(y.z); y.w = elu_(y.w); }
           *reinterpret_cast<float4*>(out + row * ldo + c) = y;
+          if (head_w) {
+            const float4 hw = *reinterpret_cast<const float4*>(head_w + c);
+            hd += (y.x * hw.x + y.y * hw.y) + (y.z * hw.z + y.w * hw.w);
+          }
         }
       }
       if (l == 0) { stats[row * lds] = mean; stats[row * lds + 1] = rstd; }
+    }
+    if (head_w) {   // (all lanes of the row group take part in the shuffles)
+      hd = grp_sum<LPR>(hd);
+      if (live && l == 0) head_out[row] = hd + (head_b ? head_b[0] : 0.f);
     }
   }
 }
@@ -235,7 +246,8 @@ k_ln_act_bwd_v(float* __restrict__ dout, long ldd, const float* __restrict__ z, 
                const float* __restrict__ out, long ldo, const float* __restrict__ stats, long lds,
                const float* __restrict__ gamma, const float* __restrict__ beta,
                float* __restrict__ dz, long lddz,
-               float* __restrict__ partials, int rows, int C, int act, PreSum ps) {
+               float* __restrict__ partials, int rows, int C, int act, PreSum ps,
+               const float* __restrict__ head_dy = nullptr, const float* __restrict__ head_w = nullptr) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -258,7 +270,11 @@ k_ln_act_bwd_v(float* __restrict__ dout, long ldd, const float* __restrict__ z, 
       if (live && c < C) {
         float4* dyp = reinterpret_cast<float4*>(dout + row * ldd + c);
         float4 dy;
-        if (ps.S) {
+        if (head_dy) {   // the gradient of a one-unit output layer: dy[row] * w, never stored
+          const float hg = head_dy[row];
+          const float4 hw = *reinterpret_cast<const float4*>(head_w + c);
+          dy = make_float4(hg * hw.x, hg * hw.y, hg * hw.z, hg * hw.w);
+        } else if (ps.S) {
           dy = presum4(ps, row, c, ps.beta != 0.f ? *dyp : make_float4(0.f, 0.f, 0.f, 0.f));
           *dyp = dy;  // the bulk parameter-gradient pass reads it later
         } else {
@@ -710,14 +726,40 @@ inline int row_blocks(long rows, int cap) {
 
 }  // namespace
 
+namespace {
+int ln_act_fwd_impl(float* z, long ldz, const float* gamma, const float* beta,
+                    float* out, long ldo, float* stats, long lds, int rows, int C, int act,
+                    const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
+                    const float* head_w, const float* head_b, float* head_out, void* stream);
+}
+
 extern "C" int dd_ln_act_fwd(float* z, long ldz, const float* gamma, const float* beta,
                              float* out, long ldo, float* stats, long lds, int rows, int C, int act,
                              const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
                              void* stream) {
+  return ln_act_fwd_impl(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act, slabs, n_slabs, beta_pre,
+                         bias_pre, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int dd_ln_act_fwd_head(float* z, long ldz, const float* gamma, const float* beta,
+                                  float* out, long ldo, float* stats, long lds, int rows, int C, int act,
+                                  const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
+                                  const float* head_w, const float* head_b, float* head_out, void* stream) {
+  DD_REQUIRE(head_w != nullptr && head_out != nullptr, "dd_ln_act_fwd_head: head kernel and output required");
+  return ln_act_fwd_impl(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act, slabs, n_slabs, beta_pre,
+                         bias_pre, head_w, head_b, head_out, stream);
+}
+
+namespace {
+int ln_act_fwd_impl(float* z, long ldz, const float* gamma, const float* beta,
+                    float* out, long ldo, float* stats, long lds, int rows, int C, int act,
+                    const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
+                    const float* head_w, const float* head_b, float* head_out, void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = C % 4 == 0 && C <= 1024 && ldz % 4 == 0 && ldo % 4 == 0 && al16(z) && al16(out) &&
-                   al16(gamma) && al16(beta) && al16(slabs) && al16(bias_pre);
+                   al16(gamma) && al16(beta) && al16(slabs) && al16(bias_pre) && al16(head_w);
+  DD_REQUIRE(vec || head_w == nullptr, "dd_ln_act_fwd_head: needs the vector path (C % 4 == 0, C <= 1024, 16-byte aligned rows)");
   if (n_slabs > 0 && !vec) {  // the scalar kernels take plain input: finish the sum first
     int rc = dd_splitk_finish(slabs, n_slabs, z, ldz, rows, C, beta_pre, bias_pre, stream);
     if (rc) return rc;
@@ -729,7 +771,8 @@ extern "C" int dd_ln_act_fwd(float* z, long ldz, const float* gamma, const float
       constexpr int LPR = decltype(lpr)::value, V = decltype(v)::value;
       long groups = (rows + (64 / LPR) - 1) / (64 / LPR);
       int blocks = row_blocks(groups, 1 << 20);
-      k_ln_act_fwd_v<LPR, V><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act, ps);
+      k_ln_act_fwd_v<LPR, V><<<blocks, 256, 0, st>>>(z, ldz, gamma, beta, out, ldo, stats, lds, rows, C, act, ps,
+                                                     head_w, head_b, head_out);
       DD_CHECK_LAUNCH("dd_ln_act_fwd");
       return 0;
     });
@@ -741,6 +784,7 @@ extern "C" int dd_ln_act_fwd(float* z, long ldz, const float* gamma, const float
     return 0;
   });
 }
+}  // namespace
 
 extern "C" int dd_ln_bwd_parts(int rows, int C) {
   // Number of partial rows dd_ln_act_bwd's fused parameter-gradient pass uses.
@@ -751,12 +795,47 @@ extern "C" int dd_ln_bwd_parts(int rows, int C) {
   return row_blocks(rows, 256);
 }
 
+namespace {
+int ln_act_bwd_impl(float* dout, long ldd, const float* z, long ldz,
+                    const float* out, long ldo, const float* stats, long lds, const float* gamma,
+                    const float* beta_ln,
+                    float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
+                    int accumulate, int rows, int C, int act, float* ws, size_t ws_bytes,
+                    const float* slabs, int n_slabs, float beta_pre,
+                    const float* head_dy, const float* head_w, void* stream);
+}
+
 extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
                              const float* out, long ldo, const float* stats, long lds, const float* gamma,
                              const float* beta_ln,
                              float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
                              int accumulate, int rows, int C, int act, float* ws, size_t ws_bytes,
                              const float* slabs, int n_slabs, float beta_pre, void* stream) {
+  return ln_act_bwd_impl(dout, ldd, z, ldz, out, ldo, stats, lds, gamma, beta_ln, dz, lddz, dgamma, dbeta,
+                         dbias_pre, accumulate, rows, C, act, ws, ws_bytes, slabs, n_slabs, beta_pre,
+                         nullptr, nullptr, stream);
+}
+
+extern "C" int dd_ln_act_bwd_head(const float* head_dy, const float* head_w, const float* z, long ldz,
+                                  const float* out, long ldo, const float* stats, long lds, const float* gamma,
+                                  const float* beta_ln,
+                                  float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
+                                  int accumulate, int rows, int C, int act, float* ws, size_t ws_bytes,
+                                  void* stream) {
+  DD_REQUIRE(head_dy != nullptr && head_w != nullptr, "dd_ln_act_bwd_head: head gradient and kernel required");
+  // (`dout` is never touched: any 16-byte aligned address with a valid leading dimension will do)
+  return ln_act_bwd_impl(dz, lddz, z, ldz, out, ldo, stats, lds, gamma, beta_ln, dz, lddz, dgamma, dbeta,
+                         dbias_pre, accumulate, rows, C, act, ws, ws_bytes, nullptr, 0, 0.f, head_dy, head_w, stream);
+}
+
+namespace {
+int ln_act_bwd_impl(float* dout, long ldd, const float* z, long ldz,
+                    const float* out, long ldo, const float* stats, long lds, const float* gamma,
+                    const float* beta_ln,
+                    float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
+                    int accumulate, int rows, int C, int act, float* ws, size_t ws_bytes,
+                    const float* slabs, int n_slabs, float beta_pre,
+                    const float* head_dy, const float* head_w, void* stream) {
   if (rows <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool want = dgamma != nullptr;
@@ -766,7 +845,8 @@ extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
   if (!out) ldo = 4;
   const bool vec = C % 4 == 0 && C <= 1024 && ldd % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 &&
                    lddz % 4 == 0 && al16(dout) && al16(z) && al16(out) && al16(dz) && al16(gamma) &&
-                   al16(beta_ln) && al16(slabs);
+                   al16(beta_ln) && al16(slabs) && al16(head_w);
+  DD_REQUIRE(vec || head_dy == nullptr, "dd_ln_act_bwd_head: needs the vector path (C % 4 == 0, C <= 1024, 16-byte aligned rows)");
   // the deferred sum shares the workspace with the parameter-gradient partials: only
   // the parameter-free vector path consumes it in place
   if (n_slabs > 0 && (!vec || want)) {
@@ -789,7 +869,8 @@ extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
       size_t shmem = want ? (size_t)WPB * RPW * 3 * C * sizeof(float) : 0;
       if (want) DD_REQUIRE(ws && (size_t)blocks * 3 * C * sizeof(float) <= ws_bytes, "dd_ln_act_bwd: workspace too small");
       k_ln_act_bwd_v<LPR, V><<<blocks, 256, shmem, st>>>(
-          dout, ldd, z, ldz, out, ldo, stats, lds, gamma, beta_ln, dz, lddz, want ? ws : nullptr, rows, C, act, ps);
+          dout, ldd, z, ldz, out, ldo, stats, lds, gamma, beta_ln, dz, lddz, want ? ws : nullptr, rows, C, act, ps,
+          head_dy, head_w);
       DD_CHECK_LAUNCH("dd_ln_act_bwd");
       if (want) {
         const int nout = dbias_pre ? 3 : 2;
@@ -834,6 +915,7 @@ extern "C" int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
   if (dbias_pre) return dd_col_sum(dz, lddz, dbias_pre, b, rows, C, ws, ws_bytes, stream);
   return 0;
 }
+}  // namespace
 
 // Parameter gradients only (bulk pass after a scan): dgamma/dbeta from stored
 // dout / out / z / stats of all steps.

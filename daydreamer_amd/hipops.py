@@ -41,6 +41,8 @@ _SIGS = {
     'dd_repeat2': [c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
     'dd_ln_act_fwd': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_i, c_f, c_p, c_p],
     'dd_ln_act_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p, c_i, c_f, c_p],
+    'dd_ln_act_fwd_head': [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p],
+    'dd_ln_act_bwd_head': [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_ln_bwd_parts': [c_i, c_i],
     'dd_ln_param_grad': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_col_sum': [c_p, c_l, c_p, c_f, c_l, c_i, c_p, c_z, c_p],
@@ -110,7 +112,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
-ABI_VERSION = 9   # include/daydreamer_hip.h DD_ABI_VERSION
+ABI_VERSION = 10   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -362,13 +364,37 @@ class HipOps:
 
   # ---- LayerNorm / GRU -------------------------------------------------------
 
-  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True, pre=None):
+  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True, pre=None, head=None):
+    """head = (w [C, 1], b [1], y [rows, 1]): the one-unit output layer behind this layer, folded in
+    (dd_ln_act_fwd_head: y = out @ w + b)."""
     rows, C = z.shape
     zp, ldz = _mat(z)
     op, ldo = _mat(out)
+    if head is not None:
+      w, b, y = head
+      assert w.is_contiguous() and w.numel() == C and y.is_contiguous() and y.numel() == rows
+      self._check(self.lib.dd_ln_act_fwd_head(
+          zp, ldz, gamma.data_ptr(), beta.data_ptr(), op, ldo, *_mat(stats),
+          rows, C, int(act), *self._pre(pre, rows, C), w.data_ptr(), _ptr(b), y.data_ptr(), self.stream),
+          'dd_ln_act_fwd_head')
+      return
     self._check(self.lib.dd_ln_act_fwd(
         zp, ldz, gamma.data_ptr(), beta.data_ptr(), op, ldo, *_mat(stats),
         rows, C, int(act), *self._pre(pre, rows, C), self.stream), 'dd_ln_act_fwd')
+
+  def ln_act_bwd_head(self, head_dy, head_w, z, out, stats, gamma, dz, dgamma=None, dbeta=None,
+                      accumulate=False, act=True, dbias_pre=None, beta=None):
+    """ln_act_bwd of a layer whose output gradient is head_dy [rows, 1] x head_w [C, 1] (the
+    one-unit output layer behind it): formed in registers, no `dout` tensor."""
+    rows, C = z.shape
+    assert head_dy.is_contiguous() and head_dy.numel() == rows and head_w.is_contiguous() and head_w.numel() == C
+    zp, ldz = _mat(z)
+    op, ldo = _mat(out) if (beta is None or not act) else (0, 0)
+    dzp, lddz = _mat(dz)
+    self._check(self.lib.dd_ln_act_bwd_head(
+        head_dy.data_ptr(), head_w.data_ptr(), zp, ldz, op, ldo, *_mat(stats), gamma.data_ptr(), _ptr(beta),
+        dzp, lddz, _ptr(dgamma), _ptr(dbeta), _ptr(dbias_pre), int(accumulate), rows, C, int(act),
+        self.ws.data_ptr(), self.ws_bytes, self.stream), 'dd_ln_act_bwd_head')
 
   def ln_act_bwd(self, dout, z, out, stats, gamma, dz, dgamma=None,
                  dbeta=None, accumulate=False, act=True, dbias_pre=None, pre=None, beta=None):

@@ -151,6 +151,9 @@ class Learner:
     # (off while the pipelined schedule's behaviour phase is captured: there the next step's
     # world-model phase fills the chip next to the rollout, a third stream only competes)
     self.overlap_b = True
+    # one-unit output layers folded into the LayerNorm kernels (fold_head; hip.fold_heads)
+    self._fold_heads = (bool(spec.cfg.get('hip', {}).get('fold_heads', True)) and
+                        hasattr(ops, 'ln_act_bwd_head'))
     self.side_stream_b = (graphs.stream(self.device, 'side_b')
                           if ops_b2 is not None and self.device.type == 'cuda' else None)
     self.dtype = dtype  # float32 in the product; tests may use float64
@@ -648,18 +651,32 @@ class Learner:
       else:
         self.plan.cut(lambda: comm.allreduce_sum(t))
 
-  def lin_fwd(self, P, A, x, sel=None, defer=False):
+  def lin_fwd(self, P, A, x, sel=None, defer=False, head=None):
     """Linear (+ LayerNorm + ELU).  The GEMM of a normed layer leaves a split-K sum to
     the LayerNorm kernel (one launch less); for a plain layer `defer=True` returns
-    (z, pending sum) for a consumer that takes `pre=`."""
+    (z, pending sum) for a consumer that takes `pre=`.  head = (P_out, A_out): the one-unit
+    output layer behind this layer is evaluated inside the LayerNorm kernel (fold_head)."""
     sel = sel or (lambda t: t)
     zv = sel(A.z)
     if not P.norm:
       pre = self.ops.gemm(x, P.W, zv, bias=P.bias, defer=defer)
       return (zv, pre) if defer else zv
     pre = self.ops.gemm(x, P.W, zv, defer=True)
-    self.ops.ln_act_fwd(zv, P.gamma, P.beta, sel(A.out), sel(A.stats), True, pre=pre)
+    if head is not None:
+      Po, Ao = head
+      self.ops.ln_act_fwd(zv, P.gamma, P.beta, sel(A.out), sel(A.stats), True, pre=pre,
+                          head=(Po.W, Po.bias, sel(Ao.z)))
+    else:
+      self.ops.ln_act_fwd(zv, P.gamma, P.beta, sel(A.out), sel(A.stats), True, pre=pre)
     return sel(A.out)
+
+  def fold_head(self, layers, outs):
+    """The scalar heads (reward / cont / critic: MLP -> one-unit output layer, nets.py:428-492):
+    the output layer as a 1-column contraction is a GEMV at ~1 TFLOP/s and its data gradient an
+    outer product through HBM; both are folded into the last hidden layer's LayerNorm kernels
+    (dd_ln_act_fwd_head / dd_ln_act_bwd_head)."""
+    return (self._fold_heads and len(outs) == 1 and outs[0].units == 1 and len(layers) >= 1 and
+            layers[-1].norm and layers[-1].units % 4 == 0 and layers[-1].units <= 1024)
 
   def lin_bwd(self, P, A, x, sel=None, dx=None, dx_beta=0.0, params=True,
               defer=None):
@@ -709,6 +726,11 @@ class Learner:
   def head_fwd(self, name, acts, x, sel=None):
     layers, outs = self.heads[name]
     la, oa = acts
+    if self.fold_head(layers, outs):
+      s_ = sel or (lambda t: t)
+      h = self.mlp_fwd(layers[:-1], la[:-1], x, sel)
+      self.lin_fwd(layers[-1], la[-1], h, sel, head=(outs[0], oa[0]))
+      return [s_(oa[0].z)]
     h = self.mlp_fwd(layers, la, x, sel)
     return [self.lin_fwd(P, A, h, sel) for P, A in zip(outs, oa)]
 
@@ -719,6 +741,36 @@ class Learner:
     layers, outs = self.heads[name]
     la, oa = acts
     top = sel(la[-1].out)
+    if self.fold_head(layers, outs):
+      # output layer: its parameter gradients as before (bias: column sum, kernel: top^T dz); its
+      # data gradient dz x W^T is never formed - the last hidden layer's LayerNorm backward takes
+      # dz and W and builds it in registers
+      Po, Ao, Pl, Al = outs[0], oa[0], layers[-1], la[-1]
+      dzo = sel(Ao.dout)
+      if params:
+        if defer is not None:
+          defer.append(lambda o, dzo=dzo, Po=Po: o.col_sum(dzo, Po.dbias))
+          defer.append(lambda o, top=top, dzo=dzo, Po=Po: o.gemm(top, dzo, Po.dW, ta=True))
+        else:
+          self.ops.col_sum(dzo, Po.dbias)
+          self.ops.gemm(top, dzo, Po.dW, ta=True)
+      dzl = sel(Al.dz)
+      self.ops.ln_act_bwd_head(dzo, Po.W, sel(Al.z), sel(Al.out), sel(Al.stats), Pl.gamma, dzl,
+                               Pl.dgamma if params else None, Pl.dbeta if params else None,
+                               False, True, beta=Pl.beta)
+      n = len(layers)
+      xin = x if n == 1 else sel(la[n - 2].out)
+      tgt = dx if n == 1 else sel(la[n - 2].dout)
+      if params:
+        if defer is not None:
+          defer.append(lambda o, xin=xin, dzl=dzl, Pl=Pl: o.gemm(xin, dzl, Pl.dW, ta=True))
+        else:
+          self.ops.gemm(xin, dzl, Pl.dW, ta=True)
+      if tgt is not None:
+        self.ops.gemm(dzl, Pl.W, tgt, tb=True, beta=dx_beta if n == 1 else 0.0)
+      if n > 1:
+        self.mlp_bwd(layers[:-1], la[:-1], x, sel, dx, dx_beta, params, defer)
+      return
     for j, (P, A) in enumerate(zip(outs, oa)):
       self.lin_bwd(P, A, top, sel, sel(la[-1].dout), 0.0 if j == 0 else 1.0,
                    params, defer)

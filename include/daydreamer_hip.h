@@ -32,8 +32,9 @@ extern "C" {
  * dd_observe_scan_fwd / _bwd grew from 2 to 1088 words (the launches clear 512 row-block counters
  * at word 576: a caller with the old 2-word buffer gets an out-of-bounds device write).
  * 7 (round 5): dd_video_grid added.  8: dd_reduce_stats_multi added.
- * 9: dd_imagine_rollout_oh_fwd added; dd_imagine_rollout_supported answers discrete = 1 shapes. */
-#define DD_ABI_VERSION 9
+ * 9: dd_imagine_rollout_oh_fwd added; dd_imagine_rollout_supported answers discrete = 1 shapes.
+ * 10: dd_ln_act_fwd_head / dd_ln_act_bwd_head added. */
+#define DD_ABI_VERSION 10
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -150,6 +151,23 @@ int dd_ln_act_bwd(float* dout, long ldd, const float* z, long ldz,
                   int accumulate,
                   int rows, int C, int act, float* ws, size_t ws_bytes,
                   const float* slabs, int n_slabs, float beta_pre, void* stream);
+/* A Linear + LayerNorm + ELU layer that feeds a ONE-UNIT output layer (the reward / cont / critic
+ * heads: MLP -> DistLayer with shape (), nets.py:428-492): the output layer is folded into the
+ * LayerNorm kernels instead of running as a 1-column contraction.  Forward: head_out[row] =
+ * out[row, :] . head_w + head_b[0] next to everything dd_ln_act_fwd writes.  Backward: the layer's
+ * output gradient is head_dy[row] * head_w[:] (formed in registers, never stored: no `dout`
+ * tensor), everything else as dd_ln_act_bwd without a deferred sum.  Vector path only
+ * (C % 4 == 0, C <= 1024, 16-byte aligned rows).  (ABI 10.) */
+int dd_ln_act_fwd_head(float* z, long ldz, const float* gamma, const float* beta,
+                       float* out, long ldo, float* stats, long lds, int rows, int C, int act,
+                       const float* slabs, int n_slabs, float beta_pre, const float* bias_pre,
+                       const float* head_w, const float* head_b, float* head_out, void* stream);
+int dd_ln_act_bwd_head(const float* head_dy, const float* head_w, const float* z, long ldz,
+                       const float* out, long ldo, const float* stats, long lds, const float* gamma,
+                       const float* beta_ln,
+                       float* dz, long lddz, float* dgamma, float* dbeta, float* dbias_pre,
+                       int accumulate, int rows, int C, int act, float* ws, size_t ws_bytes,
+                       void* stream);
 int dd_ln_bwd_parts(int rows, int C);
 /* dgamma/dbeta only, from stored activations of all scan steps. */
 int dd_ln_param_grad(const float* dout, long ldd, const float* z, long ldz,

@@ -230,7 +230,7 @@ class RefOps:
 
   # ---- LayerNorm / GRU ----------------------------------------------------------
 
-  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True, pre=None):
+  def ln_act_fwd(self, z, gamma, beta, out, stats, act=True, pre=None, head=None):
     assert pre is None
     mean = z.mean(-1, keepdim=True)
     var = ((z - mean) ** 2).mean(-1, keepdim=True)
@@ -239,6 +239,15 @@ class RefOps:
     out.copy_(F.elu(y) if act else y)
     stats[:, 0] = mean[:, 0]
     stats[:, 1] = rstd[:, 0]
+    if head is not None:   # dd_ln_act_fwd_head: the one-unit output layer behind this layer
+      w, b, yh = head
+      yh.copy_(out @ w.reshape(-1, 1) + (b if b is not None else 0.0))
+
+  def ln_act_bwd_head(self, head_dy, head_w, z, out, stats, gamma, dz, dgamma=None, dbeta=None,
+                      accumulate=False, act=True, dbias_pre=None, beta=None):
+    """dd_ln_act_bwd_head: the layer's output gradient is head_dy x head_w."""
+    dout = head_dy.reshape(-1, 1) * head_w.reshape(1, -1)
+    self.ln_act_bwd(dout, z, out, stats, gamma, dz, dgamma, dbeta, accumulate, act, dbias_pre, beta=beta)
 
   def _ln_dy(self, dout, out, act):
     if act:

@@ -563,6 +563,38 @@ def test_gemm_deferred_on_a_ragged_contraction_axis(hip, M, N, K):
     close(sb, sa.cpu(), rtol=1e-5, what=f'deferred LayerNorm statistics beta{beta}')
 
 
+@pytest.mark.parametrize('rows,C', [(2500, 512), (40000, 512), (37, 128), (1000, 1024)])
+def test_ln_act_with_a_folded_one_unit_head(hip, ref, rows, C):
+  """dd_ln_act_fwd_head / dd_ln_act_bwd_head: a LayerNorm + ELU layer with the one-unit output layer
+  behind it folded in (scalar heads).  Forward: the layer's own outputs are bit-identical to
+  dd_ln_act_fwd and head_out = out @ w + b; backward: equal to dd_ln_act_bwd on the explicit
+  outer product dy x w, parameter-gradient partials included."""
+  z = rnd(rows, C, seed=1, scale=2.0)
+  gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+  w, b, dy = rnd(C, 1, seed=4, scale=0.1), rnd(1, seed=5), rnd(rows, 1, seed=6)
+  def fwd(ops, z, gamma, beta, out, st, w, b, y, out2, st2):
+    ops.ln_act_fwd(z.clone(), gamma, beta, out, st, True, head=(w, b, y))
+    ops.ln_act_fwd(z.clone(), gamma, beta, out2, st2, True)
+  out, st, y, out2, st2 = (torch.zeros(rows, C), torch.zeros(rows, 2), torch.zeros(rows, 1), torch.zeros(rows, C),
+                           torch.zeros(rows, 2))
+  res = both(hip, ref, fwd, [z, gamma, beta, out, st, w, b, y, out2, st2], [3, 4, 7, 8, 9])
+  (og, oc), (sg, sc), (yg, yc), (o2g, _), (s2g, _) = res
+  assert torch.equal(og, o2g) and torch.equal(sg, s2g)            # the layer itself: untouched by the fold
+  close(og, oc, rtol=1e-5, what='out'); close(yg, yc, rtol=1e-5, what='head output')
+  want = (og.double() @ w.double().cuda() + b.double().cuda())
+  close(yg, want.cpu(), rtol=2e-6, what='head output vs fp64 of the device layer output')
+  def bwd(ops, z, out, st, gamma, beta, w, dy, dz, dg, db, dz2, dg2, db2):
+    ops.ln_act_bwd_head(dy, w, z, out, st, gamma, dz, dg, db, False, True, beta=beta)
+    dout = dy.reshape(-1, 1) * w.reshape(1, -1)
+    ops.ln_act_bwd(dout.contiguous(), z, out, st, gamma, dz2, dg2, db2, False, True, beta=beta)
+  zs = [torch.zeros(rows, C), torch.zeros(C), torch.zeros(C), torch.zeros(rows, C), torch.zeros(C), torch.zeros(C)]
+  res = both(hip, ref, bwd, [z, oc, sc, gamma, beta, w, dy] + zs, [7, 8, 9, 10, 11, 12])
+  (dzg, dzc), (dgg, dgc), (dbg, dbc), (dz2g, _), (dg2g, _), (db2g, _) = res
+  close(dzg, dz2g.cpu(), rtol=1e-6, what='dz vs explicit outer product (device)')
+  close(dgg, dg2g.cpu(), rtol=1e-5, what='dgamma vs explicit'); close(dbg, db2g.cpu(), rtol=1e-5, what='dbeta vs explicit')
+  close(dzg, dzc, rtol=1e-5, what='dz'); close(dgg, dgc, rtol=2e-4, what='dgamma'); close(dbg, dbc, rtol=2e-4, what='dbeta')
+
+
 def test_reduce_stats_multi_equals_single_launches(hip):
   """dd_reduce_stats_multi: the step's metric statistics as one launch - the same sums and
   extrema as dd_reduce_stats per vector, bit for bit (same block shape, same summation order),
