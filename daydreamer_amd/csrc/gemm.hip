@@ -81,3 +81,47 @@ extern "C" int dd_gemm_f32(const float* A, const float* B, float* C, int M, int 
 #undef DD_RUN
 }
 
+
+// dd_gemm_f32 with a hint: columns [xa0, xa1) of the stored A matrix (resp. [xb0, xb1) of the
+// stored B matrix) hold values that are exact in bf16 - the one-hot `stoch` columns of the
+// feature matrix (nets.py:88-97).  The six-product loop then leaves out the three products
+// with that operand's (all-zero) middle / low planes: bit-identical results, half the matrix
+// instructions on that range (gemm_core.h ExactA / ExactB).  The hint is only ever dropped,
+// never trusted beyond what it says: shapes / modes the variant does not cover take
+// dd_gemm_f32's path.  One operand at a time (A wins).
+extern "C" int dd_gemm_f32_x(const float* A, const float* B, float* C, int M, int N, int K,
+                             long lda, long ldb, long ldc, int transA, int transB,
+                             float alpha, float beta, const float* bias,
+                             float* ws, size_t ws_bytes, int* deferred,
+                             int xa0, int xa1, int xb0, int xb1, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int va = aligned16(A) && (lda % 4 == 0);
+  const int vb = aligned16(B) && (ldb % 4 == 0);
+  const bool fa = va && (transA ? (M % 4 == 0 && M >= 4) : (K % 4 == 0 && K >= 4));
+  const bool fb = vb && (transB ? (K % 4 == 0 && K >= 4) : (N % 4 == 0 && N >= 4));
+  static const int off = getenv("DD_EXACT_OFF") ? atoi(getenv("DD_EXACT_OFF")) : 0;
+  const bool xa = xa1 - xa0 >= 64, xb = !xa && xb1 - xb0 >= 64 && !transB;
+  if (off || gemm_mode() != 6 || !fa || !fb || !(xa || xb) || (transB && transA))
+    return dd_gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, transA, transB, alpha, beta, bias, ws,
+                       ws_bytes, deferred, stream);
+  if (deferred) {
+    *deferred = 0;
+    if (alpha != 1.f) deferred = nullptr;
+  }
+  const char* nm = "dd_gemm_f32_x";
+  if (xa) {
+    if (!transA && !transB)
+      return run_mat<true, false>(ExactA<MatKC<true>>{{A, lda, M, va}, xa0, xa1}, MatRC<true>{B, ldb, N, vb},
+                                  M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm, deferred);
+    if (!transA && transB)
+      return run_mat<true, true>(ExactA<MatKC<true>>{{A, lda, M, va}, xa0, xa1}, MatKC<true>{B, ldb, N, vb},
+                                 M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm, deferred);
+    return run_mat<false, false>(ExactA<MatRC<true>>{{A, lda, M, va}, xa0, xa1}, MatRC<true>{B, ldb, N, vb},
+                                 M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm, deferred);
+  }
+  if (!transA)
+    return run_mat<true, false>(MatKC<true>{A, lda, M, va}, ExactB<MatRC<true>>{{B, ldb, N, vb}, xb0, xb1},
+                                M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm, deferred);
+  return run_mat<false, false>(MatRC<true>{A, lda, M, va}, ExactB<MatRC<true>>{{B, ldb, N, vb}, xb0, xb1},
+                               M, N, K, C, ldc, bias, alpha, beta, ws, ws_bytes, st, nm, deferred);
+}

@@ -567,6 +567,30 @@ template <class EP, class = void> struct epi_reads_c : std::false_type {};
 template <class EP> struct epi_reads_c<EP, std::enable_if_t<EP::READS_C>> : std::true_type {};
 
 // ---------------------------------------------------------------------------
+// Operands with a range that is exact in ONE bf16 plane (one-hot latents: the `stoch` columns of
+// the feature matrix, nets.py:88-97 / tfutils.py:368-382 - every element 0 or 1).  Their middle
+// and low planes are all zero, so of the six plane products only the three with the high plane of
+// that operand can be non-zero: the loop issues those three in the same order and leaves out
+// three exact `+ 0` updates of the accumulator - the result is bit-identical to the six-product
+// loop at half the matrix instructions.  [x0, x1) = the exact columns of the STORED matrix:
+// a k range when the operand is k-contiguous (not transposed), a row range of the tile otherwise.
+// ---------------------------------------------------------------------------
+template <class L>
+struct ExactA : L {   // A operand
+  int x0, x1;
+  static constexpr bool EXACT_A = true;
+};
+template <class L>
+struct ExactB : L {   // B operand (row range only: stored [K, N], columns = output columns)
+  int x0, x1;
+  static constexpr bool EXACT_B = true;
+};
+template <class AL, class = void> struct has_exact_a : std::false_type {};
+template <class AL> struct has_exact_a<AL, std::enable_if_t<AL::EXACT_A>> : std::true_type {};
+template <class BL, class = void> struct has_exact_b : std::false_type {};
+template <class BL> struct has_exact_b<BL, std::enable_if_t<BL::EXACT_B>> : std::true_type {};
+
+// ---------------------------------------------------------------------------
 // Tile <-> workgroup mapping.
 // ---------------------------------------------------------------------------
 
@@ -1018,7 +1042,10 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       }
     }
   };
-  auto compute = [&](int buf) {
+  // xs = 0: all products; 1 / 2: A / B is exact in its high plane for this k-tile (ExactA /
+  // ExactB), only the products with that plane are issued
+  auto compute = [&](int buf, auto xs_tag) {
+    constexpr int XS = decltype(xs_tag)::value;
     if constexpr (DD_PRIO_ON(AKC, BKC)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -1026,11 +1053,11 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, ks, lane);
+        for (int p = 0; p < (XS == 1 ? 1 : NPL); ++p) af[a][p] = LA::frag(As[buf] + p * LA::BYTES, wm0 + a * 32, ks, lane);
 #pragma unroll
       for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, ks, lane);
+        for (int p = 0; p < (XS == 2 ? 1 : NPL); ++p) bf[b][p] = LB::frag(Bs[buf] + p * LB::BYTES, wn0 + b * 32, ks, lane);
       // product (pa, pb) of the bit-planes, smallest terms first; consecutive MFMAs go
       // to different accumulators
       constexpr int PA_[6] = {NPL - 1, 0, 1, 1, 0, 0}, PB_[6] = {0, NPL - 1, 1, 0, 1, 0};
@@ -1044,6 +1071,8 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 #pragma unroll
           for (int b = 0; b < TN; ++b) {
             const int q = (A2 && NP == 6) ? ORD_[qi] : qi;
+            if constexpr (XS == 1) { if (PA_[q] != 0) continue; }
+            if constexpr (XS == 2) { if (PB_[q] != 0) continue; }
 #ifdef DD_ABL_NOMFMA    // ablation: fragment reads kept alive, no matrix instruction
             acc[a][b][q] += (float)af[a][PA_[q]][0] + (float)bf[b][PB_[q]][0];
 #elif defined(DD_ABL_ONEMFMA)  // ablation: one product instead of six (dependent-chain length)
@@ -1068,13 +1097,32 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
   // between the variants and the hardware then waits for the prefetch before the MFMAs
   // instead of after them.
   const int nfull = (ke - kb) / BK, nk = (ke - kb + BK - 1) / BK;
+  // k-tiles [tx0, tx1) of this workgroup lie inside the exact range of an ExactA / ExactB
+  // operand (both multiples of ST; empty without such an operand)
+  constexpr int XSEL = (NP == 6 && has_exact_a<AL>::value) ? 1 : ((NP == 6 && has_exact_b<BL>::value) ? 2 : 0);
+  int tx0 = 0, tx1 = 0;
+  if constexpr (XSEL == 1) {
+    if constexpr (AKC) {   // k range
+      tx0 = max(0, (al.x0 - kb + BK - 1) / BK);
+      tx0 = (tx0 + ST - 1) / ST * ST;
+      tx1 = al.x1 > kb ? (min(al.x1, ke) - kb) / BK / ST * ST : 0;
+    } else if (m0 >= al.x0 && m0 + BM <= al.x1) {
+      tx1 = nk + ST;
+    }
+  }
+  if constexpr (XSEL == 2) {
+    static_assert(XSEL != 2 || !BKC, "ExactB: row-contiguous B only");
+    if (n0 >= bl.x0 && n0 + BN <= bl.x1) tx1 = nk + ST;
+  }
+  if (tx1 < tx0) tx1 = tx0;
 #pragma unroll
   for (int s_ = 0; s_ < ST; ++s_)
     if (s_ < nk) gload_rt(kb + s_ * BK, ra_[s_], rb_[s_]);
   if (nk > 0) sstore(0, ra_[0], rb_[0]);
   __syncthreads();
-  int t0 = 0;
-  for (; t0 + 2 * ST <= nfull; t0 += ST) {
+  // one steady-state iteration group (ST k-tiles) with the product set XS
+  auto steady = [&](int t0, auto xs_tag) {
+    constexpr int XS = decltype(xs_tag)::value;
 #pragma unroll
     for (int s_ = 0; s_ < ST; ++s_) {
       const int t = t0 + s_;
@@ -1082,29 +1130,42 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       // keep the prefetch issued ahead of the MFMA block (the scheduler otherwise sinks
       // the loads next to their first use, behind the MFMAs, and exposes their latency)
       __builtin_amdgcn_sched_barrier(0);
-      compute(t & 1);
+      compute(t & 1, xs_tag);
       if (!IL) __builtin_amdgcn_sched_barrier(0);
       sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
       if (IL) {  // tile t+1 arrived an iteration ago: split + stage it under the MFMAs
-        constexpr int NMF = TM * TN * NP * (BK / 16);
+        constexpr int NMF = TM * TN * (XS ? 3 : NP) * (BK / 16);
 #pragma unroll
         for (int i = 0; i < NMF; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-          if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, XS ? 8 : 4, 0);
+          if (XS || (i & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
     }
+  };
+  int t0 = 0;
+  if constexpr (XSEL != 0) {
+    // (three loops, each with one code path: see the note above about variants inside the loop)
+    const int lim = nfull - 2 * ST + 1;      // t0 < lim  <=>  t0 + 2 ST <= nfull
+    for (; t0 < min(tx0, lim); t0 += ST) steady(t0, std::integral_constant<int, 0>());
+    for (; t0 < min(tx1, lim); t0 += ST) steady(t0, std::integral_constant<int, XSEL>());
   }
+  for (; t0 + 2 * ST <= nfull; t0 += ST) steady(t0, std::integral_constant<int, 0>());
   for (; t0 < nk; t0 += ST) {
 #pragma unroll
     for (int s_ = 0; s_ < ST; ++s_) {
       const int t = t0 + s_;
       if (t < nk) {
         if (t + ST < nk) gload_rt(kb + (t + ST) * BK, ra_[s_], rb_[s_]);
-        compute(t & 1);
+        if constexpr (XSEL != 0) {
+          if (t >= tx0 && t < tx1 && t < nfull) compute(t & 1, std::integral_constant<int, XSEL>());
+          else compute(t & 1, std::integral_constant<int, 0>());
+        } else {
+          compute(t & 1, std::integral_constant<int, 0>());
+        }
         if (t + 1 < nk) sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
         __syncthreads();
       }
@@ -1351,18 +1412,22 @@ void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps,
     grid.x = (unsigned)(((tm + 7) & ~7) * tiles_n);
     tm |= TILES_STRIDED;
   }
-  if constexpr (!has_tile_ctx<AL>::value && BM <= 128) {   // (tile-context loaders: split loop only, the caller checks the mode)
+  // (exact-range operands: six-product mode only, the caller checks the mode)
+  constexpr bool XE = has_exact_a<AL>::value || has_exact_b<BL>::value;
+  if constexpr (!has_tile_ctx<AL>::value && BM <= 128 && !XE) {   // (tile-context loaders: split loop only, the caller checks the mode)
     if (gemm_mode() == 0) {
       k_mfma_gemm<BM, BN, AKC, BKC, AL, BL, EP><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
       return;
     }
   }
-  if (gemm_mode() == 1) {
-    if constexpr (BM == 64 && BN == 64)
-      k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 1, 16, 4, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-    else
-      k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 1, 16, 2, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
-    return;
+  if constexpr (!XE) {
+    if (gemm_mode() == 1) {
+      if constexpr (BM == 64 && BN == 64)
+        k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 1, 16, 4, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+      else
+        k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 1, 16, 2, false><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
+      return;
+    }
   }
   // (64x64 tiles, about one workgroup per CU: prefetch distance 8 measured equal to 4 on every
   // 2500-row and 50-row shape of the step - round 2, profiles/r02_gemm_prefetch_distance.txt -
@@ -1380,7 +1445,7 @@ void launch_tile(dim3 grid, hipStream_t st, AL al, BL bl, EP ep, int K, int kps,
     k_mfma_gemm_s3<BM, BN, AKC, BKC, AL, BL, EP, 6, 16, 4, false, DD_A2_64><<<grid, 256, 0, st>>>(al, bl, ep, K, kps, tm);
   } else {
 #ifdef DD_BUILD_WS   // (`make WS=1`: the role-separated loop, measured equal in steady state - not in the default build)
-    if constexpr (BM == 128 && BN == 128) {
+    if constexpr (BM == 128 && BN == 128 && !XE) {
       if (ws_selected(kps, has_tile_ctx<AL>::value)) {
         k_mfma_gemm_ws<AKC, BKC, AL, BL, EP><<<grid, 512, 0, st>>>(al, bl, ep, K, kps, tm);
         return;

@@ -30,6 +30,7 @@ _SIGS = {
     'dd_gemm_set_mode': [c_i],
     'dd_gemm_set_ws': [c_i, c_i, c_i],
     'dd_gemm_f32': [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p, c_p, c_z, c_p, c_p],
+    'dd_gemm_f32_x': [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p, c_p, c_z, c_p, c_i, c_i, c_i, c_i, c_p],
     'dd_splitk_finish': [c_p, c_i, c_p, c_l, c_i, c_i, c_f, c_p, c_p],
     'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
     'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
@@ -112,7 +113,7 @@ _SIGS = {
 }
 
 EXPORTS = sorted(list(_SIGS) + ['dd_version', 'dd_last_error'])
-ABI_VERSION = 10   # include/daydreamer_hip.h DD_ABI_VERSION
+ABI_VERSION = 11   # include/daydreamer_hip.h DD_ABI_VERSION
 
 
 def load_library():
@@ -182,6 +183,45 @@ def onehot_sample_host(x, u, G, C, unimix, mode=0):
 SCAN_SYNC_WORDS = 576 + 512
 
 
+# Buffers with columns that hold values exact in ONE bfloat16 plane (the one-hot `stoch` columns of
+# the feature matrices): (weakref to the owning tensor, row length in floats, lo, hi).  A
+# contraction whose operand is a view into such a buffer with the buffer's row length as its
+# leading dimension goes through dd_gemm_f32_x, which leaves out the plane products that are
+# exactly zero (bit-identical result).  The owner being alive guarantees that the address range is
+# still that buffer; dead entries are dropped on lookup.
+_EXACT = []
+
+
+def mark_exact(t, lo, hi):
+  """Declare that columns [lo, hi) of the last axis of the contiguous tensor `t` only ever hold
+  values exact in bfloat16 (one-hot classes) whenever a contraction reads it."""
+  import weakref
+  assert t.is_contiguous() and 0 <= lo < hi <= t.shape[-1]
+  _EXACT.append((weakref.ref(t), t.shape[-1], lo, hi))
+
+
+def _exact_cols(ptr, ld, ncols):
+  """Exact column range of the 2-D view (ptr, leading dimension ld, ncols columns), or (0, 0)."""
+  dead = False
+  out = (0, 0)
+  for ref, row, lo, hi in _EXACT:
+    t = ref()
+    if t is None:
+      dead = True
+      continue
+    base = t.data_ptr()
+    if ld == row and base <= ptr < base + 4 * t.numel():
+      col0 = ((ptr - base) // 4) % row
+      if col0 + ncols <= row:
+        a, b = max(lo - col0, 0), min(hi - col0, ncols)
+        if b > a:
+          out = (a, b)
+      break
+  if dead:
+    _EXACT[:] = [e for e in _EXACT if e[0]() is not None]
+  return out
+
+
 class Slabs:
   """Deferred split-K partial sums sitting in a HipOps workspace (dd_gemm_f32 `deferred`).
   `beta` / `bias` are what the CONSUMER must apply to C together with the sum.  They are the
@@ -206,6 +246,11 @@ class HipOps:
     self.ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=self.device)
     self.ws_bytes = ws_bytes
     self.trace = None  # list of (label, flops, start_event, end_event) when profiling
+
+  def mark_exact(self, t, lo, hi):
+    """Columns [lo, hi) of `t`'s rows hold one-hot classes whenever a contraction reads them
+    (module-level registry: every launch context of the process sees it)."""
+    mark_exact(t, lo, hi)
 
   def set_gemm_mode(self, mode):
     """Arithmetic of all contractions of the process (dd_gemm_set_mode): 6 exact-split fp32
@@ -268,10 +313,19 @@ class HipOps:
                          alpha, 1.0, bias, defer)
     # in deferred mode bias / beta are applied by the consumer together with the sum
     flag = ctypes.c_int(0) if (defer and alpha == 1.0) else None
-    self._check(self._traced(f'gemm {M}x{N}x{K} ta{int(ta)} tb{int(tb)} B{4 * (M * K + K * N + M * N)}', 2.0 * M * N * K, lambda: self.lib.dd_gemm_f32(
-        a, b, c, M, N, K, lda, ldb, ldc, int(ta), int(tb), alpha, beta,
-        _ptr(bias), self.ws.data_ptr(), self.ws_bytes,
-        ctypes.byref(flag) if flag is not None else None, self.stream)), 'dd_gemm_f32')
+    xa = _exact_cols(a, lda, A.shape[1]) if _EXACT else (0, 0)
+    xb = _exact_cols(b, ldb, B.shape[1]) if _EXACT and not tb else (0, 0)
+    if xa[1] or xb[1]:
+      self._check(self._traced(f'gemm {M}x{N}x{K} ta{int(ta)} tb{int(tb)} B{4 * (M * K + K * N + M * N)}', 2.0 * M * N * K, lambda: self.lib.dd_gemm_f32_x(
+          a, b, c, M, N, K, lda, ldb, ldc, int(ta), int(tb), alpha, beta,
+          _ptr(bias), self.ws.data_ptr(), self.ws_bytes,
+          ctypes.byref(flag) if flag is not None else None, xa[0], xa[1], xb[0], xb[1],
+          self.stream)), 'dd_gemm_f32_x')
+    else:
+      self._check(self._traced(f'gemm {M}x{N}x{K} ta{int(ta)} tb{int(tb)} B{4 * (M * K + K * N + M * N)}', 2.0 * M * N * K, lambda: self.lib.dd_gemm_f32(
+          a, b, c, M, N, K, lda, ldb, ldc, int(ta), int(tb), alpha, beta,
+          _ptr(bias), self.ws.data_ptr(), self.ws_bytes,
+          ctypes.byref(flag) if flag is not None else None, self.stream)), 'dd_gemm_f32')
     if flag is not None and flag.value > 0:
       return Slabs(flag.value, M, N, beta, bias)
     return None

@@ -471,6 +471,11 @@ class Learner:
     self.TW = F + A if (self.fused_imag and not self.discrete) else (F + A + 3) // 4 * 4
     W = self.TW
     b['traj'] = z(H + 1, N, W)     # [deter | stoch | action | zero padding]
+    # the stoch columns of both feature matrices are one-hot classes (nets.py:88-97): exact in one
+    # bfloat16 plane, so contractions over them need three plane products, not six (dd_gemm_f32_x)
+    if hasattr(self.ops, 'mark_exact') and bool(self.cfg.get('hip', {}).get('exact_planes', True)):
+      self.ops.mark_exact(b['post'], D, F)
+      self.ops.mark_exact(b['traj'], D, F)
     b['dtraj'] = z(H + 1, N, W)
     self.ai_img_in = Act(self, H * N, U, True)
     b['iz3'] = z(H * N, 3 * D)

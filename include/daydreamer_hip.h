@@ -33,8 +33,9 @@ extern "C" {
  * at word 576: a caller with the old 2-word buffer gets an out-of-bounds device write).
  * 7 (round 5): dd_video_grid added.  8: dd_reduce_stats_multi added.
  * 9: dd_imagine_rollout_oh_fwd added; dd_imagine_rollout_supported answers discrete = 1 shapes.
- * 10: dd_ln_act_fwd_head / dd_ln_act_bwd_head added. */
-#define DD_ABI_VERSION 10
+ * 10: dd_ln_act_fwd_head / dd_ln_act_bwd_head added.
+ * 11 (round 6): dd_gemm_f32_x added. */
+#define DD_ABI_VERSION 11
 int dd_version(void);
 const char* dd_last_error(void);
 
@@ -48,6 +49,18 @@ int dd_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
                 long lda, long ldb, long ldc, int transA, int transB,
                 float alpha, float beta, const float* bias,
                 float* ws, size_t ws_bytes, int* deferred, void* stream);
+/* dd_gemm_f32 with a hint about one operand: columns [xa0, xa1) of the STORED A matrix (or
+ * [xb0, xb1) of the stored B matrix; pass an empty range for the other) hold values that are
+ * exact in bfloat16 - the one-hot `stoch` columns of the feature matrix, nets.py:88-97,
+ * tfutils.py:368-382.  Those elements have all-zero middle / low planes in the three-way
+ * split, so the three plane products that involve them are left out: the result is
+ * bit-identical to dd_gemm_f32 at half the matrix instructions over that range.  A hint the
+ * variant does not cover (shape, alignment, arithmetic mode) is ignored. */
+int dd_gemm_f32_x(const float* A, const float* B, float* C, int M, int N, int K,
+                  long lda, long ldb, long ldc, int transA, int transB,
+                  float alpha, float beta, const float* bias,
+                  float* ws, size_t ws_bytes, int* deferred,
+                  int xa0, int xa1, int xb0, int xb1, void* stream);
 /* Deferred split-K sum.  With `deferred` != NULL (host pointer) and alpha == 1, a GEMM that
  * splits K leaves its n = *deferred partial results [n][M][N] at the start of ws instead of
  * running the reduce pass, and does not touch C; *deferred = 0 means C is complete.  The

@@ -118,6 +118,58 @@ def test_role_separated_loop_is_bit_identical(hip):
     assert torch.isfinite(a).all() and torch.equal(a, b), i
 
 
+@pytest.mark.parametrize('M,N,K,ta,tb,which', [
+    (2500, 512, 1280, 0, 0, 'a'), (4000, 512, 1280, 0, 0, 'a'), (50, 512, 1280, 0, 0, 'a'),
+    (300, 6400, 1280, 0, 0, 'a'), (700, 512, 1280, 0, 1, 'a'), (2500, 512, 1296, 0, 0, 'a'),
+    (1280, 512, 2500, 1, 0, 'a'), (1280, 512, 20000, 1, 0, 'a'), (1040, 256, 2500, 1, 0, 'a'),
+    (640, 1280, 2500, 1, 0, 'b'), (300, 1280, 512, 0, 0, 'b')])
+def test_gemm_exact_planes_is_bit_identical(hip, M, N, K, ta, tb, which):
+  """dd_gemm_f32_x: an operand whose feature columns [256, 1280) are one-hot classes (the `stoch`
+  part of [deter | stoch], nets.py:88-97) - the three plane products with its zero middle / low
+  planes are left out.  Equality with dd_gemm_f32, not a tolerance: k-range form (A not
+  transposed; 128x128, 128x64 and 64x64 tiles, K tail, beta / bias), row-tile form (weight
+  gradient A^T dY incl. split-K), and the B-side form (decoder filter gradient dY^T feat)."""
+  from daydreamer_amd import hipops
+  import numpy as np
+  D = 256
+  # the stored matrix whose columns are features [deter | stoch | (action)]
+  shape = ((K, M) if ta else (M, K)) if which == 'a' else (K, N)
+  feat = rnd(*shape, seed=1)
+  rows = shape[0]
+  ncol = feat.shape[1]
+  hi = min(1280, D + (ncol - D) // 32 * 32)
+  g = np.random.default_rng(5)
+  oh = torch.zeros(rows, (hi - D) // 32, 32)
+  idx = torch.from_numpy(g.integers(0, 32, size=(rows, (hi - D) // 32)))
+  oh.scatter_(2, idx[..., None], 1.0)
+  feat[:, D:hi] = oh.view(rows, -1)
+  feat = feat.cuda()
+  if which == 'a':
+    A, B = feat, rnd(*((N, K) if tb else (K, N)), seed=2).cuda()
+  else:
+    A, B = rnd(*((K, M) if ta else (M, K)), seed=2).cuda(), feat
+  bias = rnd(N, seed=4).cuda()
+  outs = []
+  for marked in (False, True):
+    hipops._EXACT[:] = []
+    if marked:
+      hipops.mark_exact(feat, D, hi)
+    res = []
+    for beta, bs in ((0.0, None), (1.0, bias)):
+      C = rnd(M, N, seed=3).cuda()
+      hip.trace = []
+      hip.gemm(A, B, C, bool(ta), bool(tb), 1.0, beta, bs)
+      hip.trace = None
+      res.append(C)
+    outs.append(res)
+  hipops._EXACT[:] = []
+  opA, opB = (A.T if ta else A), (B.T if tb else B)
+  want = opA.double() @ opB.double()
+  close(outs[1][0], want.cpu(), what='exact-plane gemm vs float64')
+  for a, b in zip(*outs):
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_gemm_bf16_input_mode(hip, ref):
   """dd_gemm_set_mode(1): the opt-in reduced-precision arithmetic (operands rounded to bf16,
   one product, fp32 accumulation).  Its error is that of bf16 inputs - relative 2^-9 per
