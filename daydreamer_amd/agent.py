@@ -269,17 +269,23 @@ class LazyMetrics(collections.abc.Mapping):
 
   def __init__(self, keys, fetch):
     self._keys, self._fetch, self._vals, self._error = tuple(keys), fetch, None, None
+    # a logger thread may look at the values while the training thread's next call resolves the
+    # same step (Pipeline.step): one of them fetches, the other waits and gets the same outcome
+    self._lock = threading.Lock()
 
   def resolve(self):
     if self._vals is None:
-      if self._error is not None:
-        raise self._error
-      fetch, self._fetch = self._fetch, None
-      try:
-        self._vals = fetch()
-      except Exception as e:   # (e.g. read_metrics: a loss is not finite) - every later look raises it again
-        self._error = e
-        raise
+      with self._lock:
+        if self._vals is not None:
+          return self._vals
+        if self._error is not None:
+          raise self._error
+        fetch, self._fetch = self._fetch, None
+        try:
+          self._vals = fetch()
+        except Exception as e:   # (e.g. read_metrics: a loss is not finite) - every later look raises it again
+          self._error = e
+          raise
     return self._vals
 
   @property

@@ -18,6 +18,15 @@
 #include <stdlib.h>
 #include "../../include/daydreamer_hip.h"
 
+// Measurement hooks of tools/conv_image_probe.py / conv_down_probe.py (2 no MFMAs, 4 no stores, 8 no
+// staging - wrong results by design): only in a `make IMGDBG=1` build, where the DD_IMG_DBG
+// environment variable selects them; the default library compiles the branches away.
+#ifdef DD_BUILD_IMGDBG
+#define IMG_DBG(bit) ((dbg & (bit)) != 0)
+#else
+#define IMG_DBG(bit) false
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -150,7 +159,7 @@ k_convT_image(const float* __restrict__ small, const char* __restrict__ planes,
     if (unit >= n_units) return;
 #pragma unroll
     for (int u = 0; u < NPI; ++u) {
-      if (ipi[u] >= 0 && !((dbg & 8) && pre[slot][u][0].x != 12345.f)) {
+      if (ipi[u] >= 0 && !(IMG_DBG(8) && pre[slot][u][0].x != 12345.f)) {
         const float v[8] = {pre[slot][u][0].x, pre[slot][u][0].y, pre[slot][u][0].z, pre[slot][u][0].w,
                             pre[slot][u][1].x, pre[slot][u][1].y, pre[slot][u][1].z, pre[slot][u][1].w};
         uint4 pl[3];
@@ -164,7 +173,7 @@ k_convT_image(const float* __restrict__ small, const char* __restrict__ planes,
   auto multiply = [&](int unit) {            // the group's patch x the chunk's tap weights (+ the tile's epilogue)
     if (unit < 0 || unit >= n_units) return;
     const int c = unit % NCH;
-    if (!(dbg & 2)) {
+    if (!IMG_DBG(2)) {
       const int r16 = lane & 15, kq = lane >> 4;
       const char* blc = bl + (long)c * (TT * NT * 3 * 1024);
 #pragma unroll
@@ -219,7 +228,7 @@ k_convT_image(const float* __restrict__ small, const char* __restrict__ planes,
             const int n = t * 16 + (lane >> 4) * 4 + r;            // even; n + 1 is in the same parity row (2 * Cb even)
             const int py = n / (2 * Cb), w2 = n - py * 2 * Cb;      // w2 = px * Cb + cb, even
             const int y = 2 * i + py;
-            const bool ok = n < 4 * Cb && y < hb && !(dbg & 4);
+            const bool ok = n < 4 * Cb && y < hb && !IMG_DBG(4);
             const int x0 = 2 * j;                                    // the block's first output column
             if (ok && x0 * Cb + w2 + 1 < wb * Cb) {
               const float b0 = bias ? bias[w2 % Cb] : 0.f, b1 = bias ? bias[(w2 + 1) % Cb] : 0.f;
@@ -271,7 +280,11 @@ int dd_convT_image_fwd(const float* small, const float* w, const float* bias, fl
   const long total = (long)NT * T * T * NCH * 64;
   k_convT_image_wprep<<<(int)((total + 255) / 256), 256, 0, st>>>(w, k, Cb, Cs, NT, planes);
   DD_CHECK_LAUNCH("dd_conv2d_s2_up(image wprep)");
+#ifdef DD_BUILD_IMGDBG
   const int dbg = getenv("DD_IMG_DBG") ? atoi(getenv("DD_IMG_DBG")) : 0;   // measurement aid: 2 no MFMAs, 4 no stores
+#else
+  const int dbg = 0;
+#endif
   const int nbi = (hb + 1) / 2, nbj = (wb + 1) / 2;
   const int tj = (nbj + BJ - 1) / BJ, ti = (nbi + BI - 1) / BI;
   const long nt_ = (long)tj * ti * n_img;
@@ -376,7 +389,7 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int id = tid + 256 * v;
-      if (id < nvec && !((dbg & 8) && pre[v].x != 0x12345u)) {
+      if (id < nvec && !(IMG_DBG(8) && pre[v].x != 0x12345u)) {
         const int r = id / vec_per_row, c = (id - r * vec_per_row) * EPV;
         float f[EPV];
         if constexpr (sizeof(TB) == 1) {
@@ -423,7 +436,7 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r16 = lane & 15, q = lane >> 4;
-    if (!(dbg & 2))
+    if (!IMG_DBG(2))
 #pragma unroll
     for (int s_ = 0; s_ < KS; ++s_) {
       const int o = s_ * 4 + q;
@@ -460,7 +473,7 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
       }
     }
     // ---- epilogue: elements (rows (lane >> 4) * 4 + r = channels, column lane & 15 = output column) of tile (m, t)
-    if (i < hs && !(dbg & 4)) {
+    if (i < hs && !IMG_DBG(4)) {
       float* dst = small + ((img * hs + i) * (long)ws_) * Cs;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -504,7 +517,11 @@ int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const flo
   if (nt_ > (1 << 30)) return 1;
   const int n_tiles = (int)nt_;
   const int grid = n_tiles < 512 ? n_tiles : 512;
+#ifdef DD_BUILD_IMGDBG
   static const int dbg = getenv("DD_IMG_DBG") ? atoi(getenv("DD_IMG_DBG")) : 0;   // measurement aid: 2 no MFMAs, 4 no stores, 8 no staging
+#else
+  const int dbg = 0;
+#endif
 #define LD(KS_)                                                                                        \
   if (KS == KS_) {                                                                                     \
     if (big_is_u8) k_conv_image_down<KS_, 4, unsigned char><<<grid, 256, 0, st>>>(                     \

@@ -16,6 +16,7 @@
 // Global->register->LDS double buffering, one barrier per k-tile.
 // Split-K (deterministic: slabs in a caller workspace + a reduce pass) gives
 // small-M / huge-K problems enough workgroups to cover 256 CUs.
+#include <stdio.h>
 #include "gemm_core.h"
 
 int g_gemm_mode = -1;
@@ -54,6 +55,16 @@ extern "C" int dd_gemm_f32(const float* A, const float* B, float* C, int M, int 
                            float alpha, float beta, const float* bias,
                            float* ws, size_t ws_bytes, int* deferred, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+#ifndef DD_BUILD_WS
+  // (the environment selector of the role-separated loop must not be silently ignored)
+  static const bool ws_warned = [] {
+    const char* e = getenv("DD_WS");
+    if (e && atoi(e))
+      fprintf(stderr, "daydreamer_hip: DD_WS=%s ignored - the role-separated loop is not in this build (make WS=1)\n", e);
+    return true;
+  }();
+  (void)ws_warned;
+#endif
   if (deferred) {
     *deferred = 0;
     if (alpha != 1.f) deferred = nullptr;  // slabs are raw accumulators

@@ -136,3 +136,40 @@ def test_pipeline_bookkeeping_survives_a_failed_fetch(monkeypatch):
   with pytest.raises(FloatingPointError):
     p.flush()
   assert p.pending is None and p.handle is None and p.flush() is None
+
+
+def test_two_threads_resolving_one_step_fetch_once():
+  """A logger thread looks at a call's metrics while the training thread's next call resolves the
+  same step (Pipeline.step -> prev.resolve()): exactly one of them runs the fetch, the other waits
+  and gets the same values - or the same stored error, never a TypeError from a fetch that the
+  first thread has already taken."""
+  import threading, time
+  for fail in (False, True):
+    log, started = [], threading.Event()
+    def fetch():
+      log.append(1)
+      started.set()
+      time.sleep(0.05)       # (the device wait of the real fetch)
+      if fail:
+        raise FloatingPointError('model_loss is not finite')
+      return {'a': np.float32(2.0)}
+    m = LazyMetrics(('a',), fetch)
+    got = []
+    def look():
+      try:
+        got.append(float(m['a']))
+      except Exception as e:
+        got.append(e)
+    th = threading.Thread(target=look)
+    th.start()
+    started.wait(2.0)
+    try:
+      got.append(dict(m.resolve())['a'])
+    except Exception as e:
+      got.append(e)
+    th.join(2.0)
+    assert log == [1] and len(got) == 2
+    if fail:
+      assert all(isinstance(g, FloatingPointError) for g in got) and m.failed
+    else:
+      assert got == [2.0, 2.0] and m.resolved

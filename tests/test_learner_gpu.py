@@ -231,6 +231,19 @@ def test_fused_observe_scan_equals_launch_sequence(hip):
     torch.cuda.empty_cache()
 
 
+def _record_flips(what, B, T, H, adim, flipped, N):
+  """Rows whose discrete draws differ between the fused kernel and the launch sequence, kept next
+  to the test log (gpurun_out/ travels back from the GPU box; copied into profiles/)."""
+  import os, pathlib
+  out = pathlib.Path(os.environ.get('GRAFT_REPO_ROOT', pathlib.Path(__file__).resolve().parents[1])) / 'gpurun_out'
+  try:
+    out.mkdir(exist_ok=True)
+    with open(out / 'fused_rollout_flipped_rows.txt', 'a') as f:
+      f.write(f'{what} B{B} T{T} H{H} A{adim}: {flipped} of {N} rows contain a flipped draw\n')
+  except OSError:
+    pass
+
+
 def test_fused_imagination_rollout_equals_launch_sequence(hip):
   """csrc/imag.hip: WorldModel.imagine (H img_steps + H + 1 policy evaluations) as ONE persistent
   launch against the per-layer launch sequence, inside a whole train step on the same minibatch
@@ -264,7 +277,8 @@ def test_fused_imagination_rollout_equals_launch_sequence(hip):
     same = (sa.argmax(-1) == sb.argmax(-1)).all(-1).all(0)                # rows with identical draws throughout
     flipped = int((~same).sum())
     print(f'fused imagination {name} B{B} T{T} H{H} A{adim}: {flipped} of {N} rows contain a flipped draw')
-    assert flipped <= max(1, N // 40)
+    _record_flips('fused imagination (continuous)', B, T, H, adim, flipped, N)
+    assert flipped <= max(1, N // 500)
     def cmp(x, y, what, rows_per_t, tol=5e-5):
       x = x.reshape(rows_per_t, N, -1)[:, same].double()
       y = y.reshape(rows_per_t, N, -1)[:, same].double()
@@ -289,10 +303,12 @@ def test_fused_imagination_rollout_equals_launch_sequence(hip):
       cmp(A.ai_img_out[i].stats, Bq.ai_img_out[i].stats, f'img_out{i}.stats', H)
       cmp(A.ai_img_out[i].out, Bq.ai_img_out[i].out, f'img_out{i}.out', H)
     cmp(A.ai_img_stats.z, Bq.ai_img_stats.z, 'img_stats', H)
-    if flipped == 0:
-      for k in ('model_loss', 'extr_critic_loss', 'actor_loss', 'actor_grad_norm', 'extr_critic_grad_norm'):
-        a_, b_ = float(mets[0][k]), float(mets[1][k])
-        assert abs(a_ - b_) <= 1e-3 * max(abs(b_), 1e-2), (k, a_, b_)
+    # (a flipped row's trajectory differs from its flipped draw on: the batch means move by at most
+    # that row's share - the tolerance grows by 4 x the flipped share, 1e-3 with no flip)
+    mtol = 1e-3 + 4.0 * flipped / N
+    for k in ('model_loss', 'extr_critic_loss', 'actor_loss', 'actor_grad_norm', 'extr_critic_grad_norm'):
+      a_, b_ = float(mets[0][k]), float(mets[1][k])
+      assert abs(a_ - b_) <= mtol * max(abs(b_), 1e-2), (k, a_, b_, flipped)
     del Ls, A, Bq
     torch.cuda.empty_cache()
 
@@ -338,7 +354,8 @@ def test_fused_onehot_rollout_equals_launch_sequence(hip):
     same = ((sa.argmax(-1) == sb.argmax(-1)).all(-1) & (aa.argmax(-1) == ab.argmax(-1))).all(0)
     flipped = int((~same).sum())
     print(f'fused one-hot rollout B{B} T{T} H{H} A{adim}: {flipped} of {N} rows contain a flipped draw')
-    assert flipped <= max(1, N // 40)
+    _record_flips('fused one-hot rollout', B, T, H, adim, flipped, N)
+    assert flipped <= max(1, N // 500)
     def cmp(x, y, what, rows_per_t, tol=5e-5):
       x = x.reshape(rows_per_t, N, -1)[:, same].double()
       y = y.reshape(rows_per_t, N, -1)[:, same].double()
@@ -354,10 +371,10 @@ def test_fused_onehot_rollout_equals_launch_sequence(hip):
     cmp(A.b['alogit'], Bq.b['alogit'], 'actor log-probabilities', H + 1)
     cmp(A.b['iz3'], Bq.b['iz3'], 'z3', H)
     cmp(A.ai_img_stats.z, Bq.ai_img_stats.z, 'img_stats', H)
-    if flipped == 0:
-      for k in ('model_loss', 'extr_critic_loss', 'actor_loss', 'actor_grad_norm', 'extr_critic_grad_norm', 'actent_mean'):
-        a_, b_ = float(mets[0][k]), float(mets[1][k])
-        assert abs(a_ - b_) <= 1e-3 * max(abs(b_), 1e-2), (k, a_, b_)
+    mtol = 1e-3 + 4.0 * flipped / N
+    for k in ('model_loss', 'extr_critic_loss', 'actor_loss', 'actor_grad_norm', 'extr_critic_grad_norm', 'actent_mean'):
+      a_, b_ = float(mets[0][k]), float(mets[1][k])
+      assert abs(a_ - b_) <= mtol * max(abs(b_), 1e-2), (k, a_, b_, flipped)
     del Ls, A, Bq
     torch.cuda.empty_cache()
 
