@@ -27,43 +27,14 @@
 // L2 / Infinity Cache as pre-split planes in fragment order (dd_imag_wprep: every (tile, k-step,
 // plane) is one contiguous 1 KB block = one 16-byte load per lane), two k-steps in flight, the
 // first two k-steps of the NEXT layer requested before the current layer's epilogue.
+#include <stdlib.h>
 #include "imag_core.h"
 #include "../../include/daydreamer_hip.h"
 
 namespace {
 
-struct LayerP {            // a Linear + LayerNorm + ELU layer in one row space
-  const char* planes;      // fragment-major bf16 planes [N/16][K/32][3][64][8]
-  const float* gamma;
-  const float* beta;
-  float* z;                // [rows, N] pre-norm
-  float* st;               // [rows, 2] mean, rstd
-  float* out;              // [rows, N] post-activation
-};
-
-struct ImagArgs {
-  int N, H;
-  int t0, t1;              // this launch runs the policy of steps t0 .. t1 - 1 and the img_steps of those < H
-  float unimix, lo, hi;
-  float* traj;             // [H+1, N, F + A]
-  const float* u_img;      // [H, N, G]
-  const float* eps;        // [H+1, N, A]
-  LayerP actor[4];
-  const float* w_actor0;   // actor dense0 kernel [F, AU] fp32 (stoch rows are gathered)
-  const char* head_planes; // [2A -> padded][AU]
-  const float* head_bias_m;
-  const float* head_bias_s;
-  float* z_om;             // [M, A]
-  float* z_os;             // [M, A]
-  LayerP img_in;           // planes unused
-  const float* w_in;       // img_in kernel [S + A, U] fp32
-  LayerP gru;              // gamma / beta over 3D; z = iz3 [H*N, 3D], st = igstats; out unused
-  LayerP img_out[3];
-  const char* stats_planes;
-  const float* stats_bias;
-  float* xs;               // [H*N, S] raw statistics
-  unsigned long long* dbg; // optional: time stamps of step 1 on block 0 (100 MHz wall clock)
-};
+using LayerP = DDImagLayerP;     // (imag_core.h: shared with the 32-row form, imag32.hip)
+using ImagArgs = DDImagArgs;
 
 // LDS row strides (floats): stride % 16 == 4 keeps the 16-row accesses of both thread mappings
 // (a finished tile's elements, a row's 8-float chunks) off each other's banks
@@ -961,7 +932,8 @@ bool imag_device_ok() {
     (void)hipGetLastError();
     return true;
   }
-  return lds >= (IMAG_LDS > IMAG_BWD_LDS ? IMAG_LDS : IMAG_BWD_LDS);
+  const int need16 = IMAG_LDS > IMAG_BWD_LDS ? IMAG_LDS : IMAG_BWD_LDS;
+  return lds >= need16 && lds >= dd_imag32_lds_bytes();
 }
 }
 
@@ -1020,6 +992,22 @@ extern "C" int dd_imag_wprep(const float* W, long ld, int K, int n, int col0, vo
   return 0;
 }
 
+// rows per workgroup of the forward rollout: 16 (k_imagine_rollout) or 32 (k_imagine_rollout32)
+static int g_imag_rows = -1;
+static int imag_rows() {
+  if (g_imag_rows < 0) {
+    const char* e = getenv("DD_IMAG_ROWS");
+    g_imag_rows = (e && atoi(e) == 16) ? 16 : 32;
+  }
+  return g_imag_rows;
+}
+extern "C" int dd_imag_set_rows(int rows) {
+  const int prev = imag_rows();
+  DD_REQUIRE(rows == 16 || rows == 32, "dd_imag_set_rows: 16 or 32");
+  g_imag_rows = rows;
+  return prev;
+}
+
 // compiled shapes (deter, units, groups, classes, action dims, actor units); actor layers = 4,
 // prior layers = 3, continuous actions
 #define DD_IMAG_SHAPES(X) X(256, 256, 32, 32, 16, 512) X(256, 256, 32, 32, 6, 512)
@@ -1073,8 +1061,13 @@ extern "C" int dd_imagine_rollout_fwd(int N, int H, int t0, int t1, int D, int U
   for (int l = 0; l < 3; ++l) a.img_out[l] = layer(44 + 6 * l);
   a.stats_planes = (const char*)p[62]; a.stats_bias = (const float*)p[63]; a.xs = (float*)p[64];
   a.dbg = n_ptrs == 66 ? (unsigned long long*)p[65] : nullptr;
-  const int blocks = (N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
+  if (imag_rows() == 32) {      // 32 rows per workgroup (imag32.hip): half the CUs for the same weight stream
+    const int rc = dd_imag32_launch(a, D, U, G, C, A, actor_units, st);
+    if (rc == 0) { DD_CHECK_LAUNCH("dd_imagine_rollout_fwd(32 rows)"); return 0; }
+    if (rc != 1) return rc;
+  }
+  const int blocks = (N + 15) / 16;
   bool launched = false;
 #define X(d, u, g, c, a_, au)                                                                    \
   if (!launched && D == d && U == u && G == g && C == c && A == a_ && actor_units == au) {       \

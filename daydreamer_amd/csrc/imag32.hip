@@ -1,0 +1,608 @@
+// Fused imagination rollout, 32 rows per workgroup (round 6).  Same algorithm, same outputs and the
+// same arithmetic per row as k_imagine_rollout (imag.hip; reference agent.py:234-254,
+// nets.py:119-138, 394-468) - what changes is how many rows share one pass over the weights.
+//
+// Why: the 16-row kernel is bound by the path from L2 / Infinity Cache into ONE CU (115-140 GB/s,
+// profiles/r05_stream_probe_per_cu.txt): a row block's step has to pull every weight plane
+// (10.5 MB) through it, however many rows it feeds.  Here a workgroup owns 32 rows: the launch
+// holds half the CUs for about the same time (79 instead of 157 at configs[1]), which the
+// pipelined schedule hands to the other phase's contractions.
+//
+// Layout: 8 waves.  A wave's column tiles are multiplied against BOTH 16-row operand tiles from
+// the same weight fragments (two MFMA groups per streamed fragment), so the weight stream per
+// workgroup and step is unchanged while the rows double.  LDS (160 KB per CU) cannot hold two
+// copies of the 16-row kernel's buffers:
+//   * the operand planes [16 k-steps][3][2 row tiles][1 KB] take 96 KB;
+//   * the z buffer (32 rows x up to 768 columns, 97 KB) aliases the operand buffer's upper half
+//     (k-steps 8..15) and the 50 KB behind it.  Layers with K = 512 therefore separate "everybody
+//     has finished reading the operand" from "tiles are written to z" by a barrier, and a
+//     LayerNorm phase that writes k-steps >= 8 reads its z rows into registers, waits, then writes;
+//   * deter_t is not kept in LDS: it is re-read from traj[t] (this workgroup's own rows, written
+//     one step earlier); LayerNorm scale / offset and the action rows of W_in come from L2.
+#include <stdlib.h>
+#include "imag_core.h"
+#include "../../include/daydreamer_hip.h"
+
+namespace {
+
+using LayerP = DDImagLayerP;
+using ImagArgs = DDImagArgs;
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int R32 = 32;          // rows per workgroup
+constexpr int ZS2 = 516;         // z buffer row stride (floats): stride % 16 == 4 (see imag.hip ZS)
+constexpr int ABUF_BYTES = 16 * 3 * 2 * 1024;          // operand planes
+constexpr int ZB_OFF = 8 * 3 * 2 * 1024;               // z buffer starts behind k-steps 0..7
+constexpr int ZS3 = 772;         // ... of the GRU's 768-wide rows
+constexpr int ZB_BYTES = R32 * ZS3 * 4;
+constexpr int MISC_OFF = (ZB_OFF + ZB_BYTES > ABUF_BYTES ? ZB_OFF + ZB_BYTES : ABUF_BYTES);
+constexpr int IMAG32_LDS = MISC_OFF + R32 * 32 * 4 /*cls*/ + R32 * 16 * 4 * 2 /*actb, ebuf*/ + R32 * 32 * 4 /*ubuf*/;
+
+// ---- weight stream against two 16-row operand tiles --------------------------------------------
+template <int NT, int KS, bool DD_I32_PRE, int TKS = KS>
+struct Stream2 {
+  static constexpr int TILE_BYTES = TKS * 3 * 1024;
+  uint4 bq[2][NT][3];
+  // Buffer loads: the wave-uniform part of a fragment's address (tile, plane, k-step) is the scalar
+  // offset of the instruction, the lane part ONE 32-bit register shared by every load.  (With flat
+  // pointers the compiler forms a 64-bit per-lane address per (tile, plane), hoists the ~100 of
+  // them out of the time loop and spills them: at two waves per SIMD a wave has 256 registers.)
+  __device__ __forceinline__ void load(int buf, const char* wp, int ks) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane_off = (threadIdx.x & 63u) * 16u;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, ks * 3072 + (j * TILE_BYTES + p * 1024), 0);
+        bq[buf][j][p] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+  }
+  __device__ __forceinline__ void prefetch(const char* wp) { if (DD_I32_PRE) { load(0, wp, 0); load(1, wp, 1); } }
+  __device__ __forceinline__ void step(int buf, const char* abuf, int ks, f32x4 (&acc)[2][NT]) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[m][p] = *reinterpret_cast<const bf16x8*>(abuf + (((ks * 3 + p) * 2 + m) * 64 + lane) * 16);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bq[buf][j][p]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        // six cross products, smallest terms first (the order of imag_core.h Stream / k_mfma_gemm_s3)
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][2], b[0], acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[2], acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], b[1], acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], b[0], acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[1], acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[0], acc[m][j], 0, 0, 0);
+      }
+    }
+  }
+  // (k-steps 0 and 1 already requested by prefetch(wp))
+  __device__ __forceinline__ void run(const char* wp, const char* abuf, f32x4 (&acc)[2][NT]) {
+    static_assert(KS % 2 == 0, "k-steps in pairs");
+    if (!DD_I32_PRE) { load(0, wp, 0); load(1, wp, 1); }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += 2) {
+      step(0, abuf, ks, acc);
+      if (ks + 2 < KS) load(0, wp, ks + 2);
+      step(1, abuf, ks + 1, acc);
+      if (ks + 3 < KS) load(1, wp, ks + 3);
+    }
+  }
+};
+
+// chunk (row, 8 columns from k = (q + 16 i) * 8) -> operand planes: k-step k / 32, row tile row >> 4,
+// fragment lane ((k % 32) / 8) * 16 + (row & 15)
+__device__ __forceinline__ void put_operand2(char* abuf, int ks0, int row, int q, int i, const float (&o)[8]) {
+  uint4 pl[3];
+  split8(o, pl);
+  const int ks = ks0 + (q >> 2) + 4 * i, fl = (q & 3) * 16 + (row & 15), m = row >> 4;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    *reinterpret_cast<uint4*>(abuf + (((ks * 3 + p) * 2 + m) * 64 + fl) * 16) = pl[p];
+}
+
+// finished tiles -> z buffer: element (row m * 16 + (lane >> 4) * 4 + r, column lane & 15) of tile (m, j)
+template <int NT, bool ADD, int ZST = ZS2>
+__device__ __forceinline__ void tiles_to_z2(const f32x4 (&acc)[2][NT], float* zb, int col0, const float* bias) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = col0 + j * 16 + (lane & 15);
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* q = zb + (m * 16 + (lane >> 4) * 4 + r) * ZST + col;
+        *q = ADD ? (*q + acc[m][j][r]) : (acc[m][j][r] + bv);
+      }
+  }
+}
+
+// finished tiles -> rows of a global [rows, ld] matrix (64-byte segments per row; rows past N skipped)
+template <int NT>
+__device__ __forceinline__ void tiles_to_global2(const f32x4 (&acc)[2][NT], float* zrows, long ld, int col0,
+                                                 long row0, int N) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = col0 + j * 16 + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = m * 16 + (lane >> 4) * 4 + r;
+        if (row0 + rr < N) zrows[(long)rr * ld + col] = acc[m][j][r];
+      }
+  }
+}
+
+template <int NC>
+struct Affine2 {
+  float gm[NC][8], bt[NC][8];
+  __device__ __forceinline__ void load(const float* gamma, const float* beta, int q) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      ld8(gamma + (q + 16 * i) * 8, gm[i]);
+      ld8(beta + (q + 16 * i) * 8, bt[i]);
+    }
+  }
+};
+
+// LayerNorm + ELU of the rows in the z buffer -> z / statistics / output to global and the next
+// contraction's operand planes (k-steps ks0 ..).  WAIT: the operand range written overlaps the z
+// buffer - every thread has its z values in registers before anybody writes.
+template <int NC, bool WAIT>
+__device__ __forceinline__ void norm_layer2(const float* zb, const LayerP& L, const Affine2<NC>& af, long grow,
+                                            bool live, char* abuf, int ks0, int row, int q) {
+  constexpr int NCOL = NC * 128;
+  float v[NC][8];
+  float ps = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    ld8(zb + row * ZS2 + (q + 16 * i) * 8, v[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ps += v[i][j];
+  }
+  const float mean = row16_sum(ps) / (float)NCOL;
+  float pv = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pv += (v[i][j] - mean) * (v[i][j] - mean);
+  const float rstd = rsqrtf(row16_sum(pv) / (float)NCOL + LN_EPS);
+  if (WAIT) __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int k = (q + 16 * i) * 8;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = felu_((v[i][j] - mean) * rstd * af.gm[i][j] + af.bt[i][j]);
+    if (live) {
+      st8(L.z + grow * NCOL + k, v[i]);
+      st8(L.out + grow * NCOL + k, o);
+    }
+    put_operand2(abuf, ks0, row, q, i, o);
+  }
+  if (live && q == 0) *reinterpret_cast<float2*>(L.st + grow * 2) = make_float2(mean, rstd);
+}
+
+// z[r][col] = sum over groups of W[(g * C + cls[r][g]) * ldw + col] (the one-hot stoch times W,
+// exactly; see imag.hip gather_rows - the same batches, the same order of additions per row)
+template <int NCOL, int G, int C, class Extra>
+__device__ __forceinline__ void gather_rows2(const float* W, long ldw, const int (*cls)[G], float* zb, int r, int q,
+                                             Extra extra) {
+  constexpr int NJ = NCOL / 64, GB = 16 / NJ, NB = G / GB;
+  const int c4 = q * 4;
+  float4 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 w[2][GB][NJ];
+  float m[2][GB];
+  auto load = [&](int buf, int g0) {
+#pragma unroll
+    for (int gb = 0; gb < GB; ++gb) {
+      const int c = cls[r][g0 + gb];
+      m[buf][gb] = c >= 0 ? 1.f : 0.f;
+      const float* wr = W + (long)((g0 + gb) * C + max(c, 0)) * ldw + c4;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) w[buf][gb][j] = *reinterpret_cast<const float4*>(wr + 64 * j);
+    }
+  };
+  auto add = [&](int buf) {
+#pragma unroll
+    for (int gb = 0; gb < GB; ++gb)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[j].x += m[buf][gb] * w[buf][gb][j].x; acc[j].y += m[buf][gb] * w[buf][gb][j].y;
+        acc[j].z += m[buf][gb] * w[buf][gb][j].z; acc[j].w += m[buf][gb] * w[buf][gb][j].w;
+      }
+  };
+  load(0, 0);
+#pragma unroll 1
+  for (int bb = 0; bb < NB; bb += 2) {
+    load(1, (bb + 1) * GB);
+    add(0);
+    if (bb + 2 < NB) load(0, (bb + 2) * GB);
+    add(1);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    extra(r, c4 + 64 * j, acc[j]);
+    *reinterpret_cast<float4*>(zb + r * ZS2 + c4 + 64 * j) = acc[j];
+  }
+}
+
+#define TS(i) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && t == a.t0 + 1) a.dbg[i] = wall_clock64()
+
+template <int D, int U, int G, int C, int A, int AU, bool PRE>
+__global__ void __launch_bounds__(512, 1)
+k_imagine_rollout32(ImagArgs a) {
+  constexpr int S = G * C, F = D + S, W = F + A;
+  constexpr int HT = (2 * A + 15) / 16;            // head column tiles
+  static_assert(D == 256 && U == 256 && AU == 512 && C == 32 && G == 32 && A <= 16, "compiled shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* abuf = smem;                                               // [16 k-steps][3][2][1 KB]
+  float* zb = reinterpret_cast<float*>(smem + ZB_OFF);             // [32][ZS2], over k-steps 8..15 and beyond
+  int (*cls)[G] = reinterpret_cast<int (*)[G]>(smem + MISC_OFF);   // [32][G]
+  float* actb = reinterpret_cast<float*>(cls + R32);               // [32][16] action of the step
+  float* ebuf = actb + R32 * 16;                                   // [32][16] action noise of the step
+  float* ubuf = ebuf + R32 * 16;                                   // [32][G] uniforms of the step's draws
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7
+  const int N = a.N, H = a.H;
+  const long row0 = (long)blockIdx.x * R32;
+  const bool glive = row0 + (tid >> 4) < N;                        // row-wise mapping: 32 rows x 16 threads
+
+  // ---- prologue: classes of the one-hot stoch of step t0
+  {
+    const float* ts = a.traj + ((long)a.t0 * N) * W;
+    const int c = lane & 31, sub = wave * 2 + (lane >> 5);
+    for (int it = sub; it < R32 * G; it += 16) {
+      const int r = it & 31, g = it >> 5;
+      const long rr = min(row0 + r, (long)N - 1);
+      const float x = ts[rr * W + D + g * C + c];
+      unsigned long long b = __ballot(x == 1.f);
+      b = (b >> ((lane >> 5) * 32)) & 0xFFFFFFFFull;
+      if (c == 0) cls[r][g] = b ? __ffsll((long long)b) - 1 : -1;
+    }
+  }
+  __syncthreads();
+
+  Stream2<4, 8, PRE> sA0;     // actor layer 0, deter part: K = D, 4 of the 32 column tiles per wave
+  Stream2<4, 16, PRE> sA;     // actor layers 1..3: K = AU
+  Stream2<6, 16, PRE> sG;     // GRU: K = D + U, 6 of the 48 column tiles per wave
+  Stream2<2, 8, PRE> sO;      // img_out: K = D or U, 2 of the 16 column tiles per wave
+  Stream2<4, 8, PRE> sS;      // img_stats: K = U, 512 columns per pass
+
+  const int gr0 = tid >> 4, gq0 = tid & 15;
+  const long gg0 = min(row0 + gr0, (long)N - 1);
+  for (int t = a.t0; t < a.t1; ++t) {
+    // Opaque per-step copies of the thread's row / chunk indices: every per-lane address below is
+    // recomputed from them inside the step (a few VALU instructions) instead of being hoisted out
+    // of the time loop as ~170 loop-invariant 64-bit addresses that spill to scratch.
+    int gr = gr0, gq = gq0;
+    long gg = gg0;
+    asm volatile("" : "+v"(gr), "+v"(gq), "+v"(gg));
+    const long mrow = (long)t * N + gg;         // this thread's row in the [M, ..] / [H*N, ..] buffers
+    float* trow = a.traj + ((long)t * N) * W;
+    const float* hrow = trow + gg * W;          // deter_t of this thread's row
+
+    TS(0);
+    {
+      const float e = gq < A ? a.eps[mrow * A + gq] : 0.f;
+      float2 u2 = make_float2(0.f, 0.f);
+      if (t < H) u2 = *reinterpret_cast<const float2*>(a.u_img + mrow * G + gq * 2);
+      ebuf[gr * 16 + gq] = e;
+      *reinterpret_cast<float2*>(ubuf + gr * G + gq * 2) = u2;
+    }
+    // ================= actor on [deter_t | stoch_t]
+    // (the weight prefetch is issued AFTER the gather: its 96 registers next to the gather's two
+    // batches of rows in flight do not fit the 256 registers of a wave at two waves per SIMD)
+    const char* wp0 = a.actor[0].planes + (long)(wave * 4) * Stream2<4, 8, PRE>::TILE_BYTES;
+    gather_rows2<AU, G, C>(a.w_actor0 + (long)D * AU, AU, cls, zb, gr, gq, [](int, int, float4&) {});
+    sA0.prefetch(wp0);
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) {
+      float v[8];
+      ld8(hrow + (gq + 16 * i) * 8, v);
+      put_operand2(abuf, 0, gr, gq, i, v);
+    }
+    __syncthreads();
+    TS(1);
+    {
+      f32x4 acc[2][4];
+      sA0.run(wp0, abuf, acc);
+      const char* wp1 = a.actor[1].planes + (long)(wave * 4) * Stream2<4, 16, PRE>::TILE_BYTES;
+      sA.prefetch(wp1);
+      tiles_to_z2<4, true>(acc, zb, wave * 64, nullptr);     // (k-steps 0..7 only: the z buffer is not being read)
+    }
+    __syncthreads();
+    TS(2);
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+      {
+        Affine2<AU / 128> afA;
+        afA.load(a.actor[l].gamma, a.actor[l].beta, gq);
+        norm_layer2<AU / 128, true>(zb, a.actor[l], afA, mrow, glive, abuf, 0, gr, gq);
+      }
+      __syncthreads();
+      TS(3 + 2 * l);
+      if (l < 3) {
+        const char* wp = a.actor[l + 1].planes + (long)(wave * 4) * Stream2<4, 16, PRE>::TILE_BYTES;
+        f32x4 acc[2][4];
+        sA.run(wp, abuf, acc);
+        if (l < 2) {
+          const char* wn = a.actor[l + 2].planes + (long)(wave * 4) * Stream2<4, 16, PRE>::TILE_BYTES;
+          sA.prefetch(wn);
+        }
+        __syncthreads();          // every wave has read k-steps 8..15: the z buffer may be written
+        tiles_to_z2<4, false>(acc, zb, wave * 64, nullptr);
+        __syncthreads();
+        TS(4 + 2 * l);
+      }
+    }
+    // head [mean | std]: waves 0-3 row tile 0, waves 4-7 row tile 1, four k-steps each (the
+    // partial sums and their order are those of the 16-row kernel)
+    {
+      const int hm = wave >> 2, hw = wave & 3;
+      const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.head_planes), 0, 0x7fffffff, 0x00020000);
+      uint4 bq[HT][4][3];
+#pragma unroll
+      for (int j = 0; j < HT; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+          {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(hrs, (unsigned)lane * 16u,
+                                                                    j * (16 * 3072) + (hw * 4 + ks) * 3072 + p * 1024, 0);
+            bq[j][ks][p] = make_uint4(v.x, v.y, v.z, v.w);
+          }
+      f32x4 acc[HT];
+#pragma unroll
+      for (int j = 0; j < HT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 av[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          av[p] = *reinterpret_cast<const bf16x8*>(abuf + ((((hw * 4 + ks) * 3 + p) * 2 + hm) * 64 + lane) * 16);
+#pragma unroll
+        for (int j = 0; j < HT; ++j) {
+          bf16x8 b[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bq[j][ks][p]);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], b[0], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[2], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[1], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[0], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[1], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[0], acc[j], 0, 0, 0);
+        }
+      }
+      __syncthreads();            // the operand's upper half is read: the z buffer may be written
+      // partial of k-quarter hw, head column c -> zb[row][hw * 32 + c]
+#pragma unroll
+      for (int j = 0; j < HT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          zb[(hm * 16 + (lane >> 4) * 4 + r) * ZS2 + hw * 32 + j * 16 + (lane & 15)] = acc[j][r];
+    }
+    __syncthreads();
+    TS(10);
+    // action of step t
+    if (gq < A) {
+      const float* zr = zb + gr * ZS2;
+      const float om = ((zr[gq] + zr[32 + gq]) + zr[64 + gq]) + zr[96 + gq] + a.head_bias_m[gq];
+      const float os = ((zr[A + gq] + zr[32 + A + gq]) + zr[64 + A + gq]) + zr[96 + A + gq] + a.head_bias_s[gq];
+      const float sd = (a.hi - a.lo) * sigmoidf_(os) + a.lo;
+      const float act = tanhf(om) + sd * ebuf[gr * 16 + gq];
+      actb[gr * 16 + gq] = act;
+      if (glive) {
+        a.z_om[mrow * A + gq] = om;
+        a.z_os[mrow * A + gq] = os;
+        trow[gg * W + F + gq] = act;
+      }
+    }
+    if (t == H) break;
+    __syncthreads();
+    TS(11);
+
+    // ================= img_step: img_in (gather + action columns), LayerNorm, ELU
+    float* tnext = a.traj + ((long)(t + 1) * N) * W;
+    const char* wpg = a.gru.planes + (long)(wave * 6) * Stream2<6, 16, PRE>::TILE_BYTES;
+    Affine2<U / 128> afU;
+    {
+      const float* wact = a.w_in + (long)S * U;               // the action rows of W_in (L2)
+      gather_rows2<U, G, C>(a.w_in, U, cls, zb, gr, gq, [&](int r, int col, float4& acc) {
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          const float av = actb[r * 16 + j];
+          const float4 w = *reinterpret_cast<const float4*>(wact + j * U + col);
+          acc.x += av * w.x; acc.y += av * w.y; acc.z += av * w.z; acc.w += av * w.w;
+        }
+      });
+    }
+    sG.prefetch(wpg);
+    afU.load(a.img_in.gamma, a.img_in.beta, gq);
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) {                       // [deter_t | x1]: k-steps 0..7 = deter
+      float v[8];
+      ld8(hrow + (gq + 16 * i) * 8, v);
+      put_operand2(abuf, 0, gr, gq, i, v);
+    }
+    __syncthreads();
+    TS(12);
+    norm_layer2<U / 128, true>(zb, a.img_in, afU, mrow, glive, abuf, D / 32, gr, gq);
+    __syncthreads();
+    TS(13);
+    // ================= GRU contraction, LayerNorm over 3D, gates
+    {
+      f32x4 acc[2][6];
+      sG.run(wpg, abuf, acc);
+      sO.prefetch(a.img_out[0].planes + (long)(wave * 2) * Stream2<2, 8, PRE>::TILE_BYTES);
+      __syncthreads();            // every wave has read k-steps 8..15: the z buffer may be written
+      tiles_to_z2<6, false, ZS3>(acc, zb, wave * 96, nullptr);
+    }
+    __syncthreads();
+    TS(14);
+    {
+      constexpr int NC = 3 * D / 128, ND = D / 128;   // chunks per thread: [reset | cand | update] x ND
+      float v[NC][8];
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        ld8(zb + gr * ZS3 + (gq + 16 * i) * 8, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ps += v[i][j];
+      }
+      const float mean = row16_sum(ps) / (float)(3 * D);
+      float pv = 0.f;
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv += (v[i][j] - mean) * (v[i][j] - mean);
+      const float rstd = rsqrtf(row16_sum(pv) / (float)(3 * D) + LN_EPS);
+      if (glive) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) st8(a.gru.z + mrow * (3 * D) + (gq + 16 * i) * 8, v[i]);
+        if (gq == 0) *reinterpret_cast<float2*>(a.gru.st + mrow * 2) = make_float2(mean, rstd);
+      }
+      // (the new deter's operand planes are k-steps 0..7, below the z buffer: no wait)
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int d = (gq + 16 * i) * 8;
+        float hp[8], hn[8], g0[8], g1[8], g2[8], b0[8], b1[8], b2[8];
+        ld8(hrow + d, hp);
+        ld8(a.gru.gamma + d, g0); ld8(a.gru.gamma + D + d, g1); ld8(a.gru.gamma + 2 * D + d, g2);
+        ld8(a.gru.beta + d, b0); ld8(a.gru.beta + D + d, b1); ld8(a.gru.beta + 2 * D + d, b2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float yr = (v[i][j] - mean) * rstd * g0[j] + b0[j];
+          const float yc = (v[i + ND][j] - mean) * rstd * g1[j] + b1[j];
+          const float yu = (v[i + 2 * ND][j] - mean) * rstd * g2[j] + b2[j];
+          const float r = sigmoidf_(yr);
+          const float cand = tanhf(r * yc);
+          const float u = sigmoidf_(yu - 1.f);
+          hn[j] = u * cand + (1.f - u) * hp[j];
+        }
+        if (glive) st8(tnext + gg * W + d, hn);
+        put_operand2(abuf, 0, gr, gq, i, hn);
+      }
+    }
+    __syncthreads();
+    TS(15);
+    // ================= img_out 0..2 (K = 256: operand k-steps 0..7, the z buffer is free beside them)
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+      const char* wp = a.img_out[l].planes + (long)(wave * 2) * Stream2<2, 8, PRE>::TILE_BYTES;
+      afU.load(a.img_out[l].gamma, a.img_out[l].beta, gq);
+      f32x4 acc[2][2];
+      sO.run(wp, abuf, acc);
+      if (l < 2) {
+        const char* wn = a.img_out[l + 1].planes + (long)(wave * 2) * Stream2<2, 8, PRE>::TILE_BYTES;
+        sO.prefetch(wn);
+      } else {
+        sS.prefetch(a.stats_planes + (long)(wave * 4) * Stream2<4, 8, PRE>::TILE_BYTES);
+      }
+      tiles_to_z2<2, false>(acc, zb, wave * 32, nullptr);
+      __syncthreads();
+      TS(16 + 2 * l);
+      norm_layer2<U / 128, false>(zb, a.img_out[l], afU, mrow, glive, abuf, 0, gr, gq);
+      __syncthreads();
+      TS(17 + 2 * l);
+    }
+    // ================= img_stats + draw: S columns in passes of 512 (16 groups)
+    constexpr int NPASS = S / 512;
+#pragma unroll 1
+    for (int ps_ = 0; ps_ < NPASS; ++ps_) {
+      const char* wp = a.stats_planes + (long)(ps_ * 32 + wave * 4) * Stream2<4, 8, PRE>::TILE_BYTES;
+      f32x4 acc[2][4];
+      sS.run(wp, abuf, acc);
+      if (ps_ + 1 < NPASS)
+        sS.prefetch(a.stats_planes + (long)((ps_ + 1) * 32 + wave * 4) * Stream2<4, 8, PRE>::TILE_BYTES);
+      tiles_to_z2<4, false>(acc, zb, wave * 64, a.stats_bias + ps_ * 512);
+      __syncthreads();
+      TS(22 + 2 * ps_);
+      // 32 rows x 16 groups = 512 items, one per thread: row = tid & 31, group = tid >> 5
+      {
+        const int r = tid & 31, gl = tid >> 5, g = ps_ * 16 + gl;
+        float x[32];
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(zb + r * ZS2 + gl * C + c);
+          x[c] = q.x; x[c + 1] = q.y; x[c + 2] = q.z; x[c + 3] = q.w;
+        }
+        const int idx = draw_item32(x, ubuf[r * G + g], a.unimix);
+        cls[r][g] = idx;
+        if (row0 + r < N) {
+          const long gw = row0 + r;
+          float* xo = a.xs + ((long)t * N + gw) * S + g * C;
+          float* so = tnext + gw * W + D + g * C;
+#pragma unroll
+          for (int c = 0; c < 32; c += 4) {
+            *reinterpret_cast<float4*>(xo + c) = make_float4(x[c], x[c + 1], x[c + 2], x[c + 3]);
+            *reinterpret_cast<float4*>(so + c) = make_float4(idx == c ? 1.f : 0.f, idx == c + 1 ? 1.f : 0.f,
+                                                             idx == c + 2 ? 1.f : 0.f, idx == c + 3 ? 1.f : 0.f);
+          }
+        }
+      }
+      __syncthreads();
+      TS(23 + 2 * ps_);
+    }
+  }
+}
+
+int imag32_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return dev;
+}
+
+}  // namespace
+
+int dd_imag32_lds_bytes() { return IMAG32_LDS; }
+
+template <bool PRE_>
+static int imag32_launch_t(const DDImagArgs& a, int D, int U, int G, int C, int A, int AU, hipStream_t st) {
+  const int blocks = (a.N + R32 - 1) / R32;
+  bool launched = false;
+#define X(d, u, g, c, a_, au)                                                                    \
+  if (!launched && D == d && U == u && G == g && C == c && A == a_ && AU == au) {                \
+    static unsigned long long attr = 0;   /* one bit per device: the attribute is per device */  \
+    const unsigned long long bit = 1ull << (imag32_device() & 63);                               \
+    if (!(attr & bit)) {                                                                         \
+      hipError_t e = hipFuncSetAttribute((const void*)k_imagine_rollout32<d, u, g, c, a_, au, PRE_>,   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, IMAG32_LDS); \
+      if (e != hipSuccess) { dd_set_error("dd_imagine_rollout_fwd(attr, 32 rows)", e); return (int)e; } \
+      attr |= bit;                                                                               \
+    }                                                                                            \
+    k_imagine_rollout32<d, u, g, c, a_, au, PRE_><<<blocks, 512, IMAG32_LDS, st>>>(a);                 \
+    launched = true;                                                                             \
+  }
+  X(256, 256, 32, 32, 16, 512) X(256, 256, 32, 32, 6, 512)
+#undef X
+  return launched ? 0 : 1;
+}
+
+int dd_imag32_launch(const DDImagArgs& a, int D, int U, int G, int C, int A, int AU, hipStream_t st) {
+  // (PRE = true, the next layer's first two k-steps requested before the current layer's row-wise
+  // phase as in the 16-row kernel, needs 96-144 more live registers than a wave has at two waves
+  // per SIMD: 370 spilled registers, 4.98 instead of 3.34 ms at configs[1] - not instantiated)
+  return imag32_launch_t<false>(a, D, U, G, C, A, AU, st);
+}

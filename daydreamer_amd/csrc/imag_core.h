@@ -6,6 +6,44 @@
 #include "latent_core.h"
 #include <math.h>
 
+// ---- arguments of the fused forward rollout (imag.hip: 16 rows per workgroup; imag32.hip: 32) ----
+struct DDImagLayerP {            // a Linear + LayerNorm + ELU layer in one row space
+  const char* planes;      // fragment-major bf16 planes [N/16][K/32][3][64][8]
+  const float* gamma;
+  const float* beta;
+  float* z;                // [rows, N] pre-norm
+  float* st;               // [rows, 2] mean, rstd
+  float* out;              // [rows, N] post-activation
+};
+
+struct DDImagArgs {
+  int N, H;
+  int t0, t1;              // this launch runs the policy of steps t0 .. t1 - 1 and the img_steps of those < H
+  float unimix, lo, hi;
+  float* traj;             // [H+1, N, F + A]
+  const float* u_img;      // [H, N, G]
+  const float* eps;        // [H+1, N, A]
+  DDImagLayerP actor[4];
+  const float* w_actor0;   // actor dense0 kernel [F, AU] fp32 (stoch rows are gathered)
+  const char* head_planes; // [2A -> padded][AU]
+  const float* head_bias_m;
+  const float* head_bias_s;
+  float* z_om;             // [M, A]
+  float* z_os;             // [M, A]
+  DDImagLayerP img_in;           // planes unused
+  const float* w_in;       // img_in kernel [S + A, U] fp32
+  DDImagLayerP gru;              // gamma / beta over 3D; z = iz3 [H*N, 3D], st = igstats; out unused
+  DDImagLayerP img_out[3];
+  const char* stats_planes;
+  const float* stats_bias;
+  float* xs;               // [H*N, S] raw statistics
+  unsigned long long* dbg; // optional: time stamps of step 1 on block 0 (100 MHz wall clock)
+};
+
+// the 32-row form (imag32.hip); returns 0 when it launched the shape, 1 when it does not cover it
+int dd_imag32_launch(const DDImagArgs& a, int D, int U, int G, int C, int A, int AU, hipStream_t st);
+int dd_imag32_lds_bytes();
+
 namespace {
 
 constexpr float LN_EPS = 1e-3f;

@@ -99,6 +99,7 @@ _SIGS = {
     'dd_tanh_bwd': [c_p, c_p, c_p, c_i, c_f, c_p],
     'dd_imag_wprep': [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     'dd_imagine_rollout_supported': [c_i] * 9,
+    'dd_imag_set_rows': [c_i],
     'dd_imag_wprep_t': [c_p, c_l, c_i, c_i, c_p, c_p],
     'dd_imagine_rollout_bwd': [c_i] * 7 + [c_f] + [ctypes.POINTER(c_p), c_i, c_p],
     'dd_imagine_rollout_fwd': [c_i] * 10 + [c_f] * 3 + [ctypes.POINTER(c_p), c_i, c_p],
@@ -566,6 +567,14 @@ class HipOps:
   def imagine_rollout_supported(self, D, U, G, C, A, actor_units, actor_layers, prior_layers, discrete):
     return bool(self.lib.dd_imagine_rollout_supported(D, U, G, C, A, actor_units, actor_layers,
                                                       prior_layers, int(bool(discrete))))
+
+  def imag_set_rows(self, rows):
+    """Rows of the imagination batch per workgroup of the fused forward rollout (process-wide):
+    32 (default) or 16.  Returns the previous value."""
+    prev = self.lib.dd_imag_set_rows(int(rows))
+    if prev < 0:
+      raise RuntimeError(f'dd_imag_set_rows({rows}): {self.lib.dd_last_error().decode()}')
+    return prev
 
   def imag_wprep(self, W, planes, col0=0):
     """Weight cache of the fused rollout: W [K, n] fp32 -> columns col0.. of fragment-major bf16

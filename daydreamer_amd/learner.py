@@ -467,6 +467,7 @@ class Learner:
                        hasattr(self.ops, 'imagine_rollout_oh_fwd' if self.discrete else 'imagine_rollout_fwd') and
                        self.ops.imagine_rollout_supported(D, U, G, self.C, A, ca['units'], ca['layers'],
                                                           self.n_prior, self.discrete))
+    self._pipelined_capture = False   # set while capture_pipeline records the phase plans
     # (the one-hot kernel takes the row width as an argument and keeps the padded rows)
     self.TW = F + A if (self.fused_imag and not self.discrete) else (F + A + 3) // 4 * 4
     W = self.TW
@@ -1595,6 +1596,13 @@ class Learner:
     t += [pl['stats'][1], P['img_stats'].bias, self.ai_img_stats.z]
     if getattr(self, 'imag_stamps', None) is not None:   # measurement aid (tools/imag_time.py)
       t.append(self.imag_stamps)
+    if hasattr(ops, 'imag_set_rows'):
+      # rows per workgroup: 32 holds half the CUs for 1.23 x the time - it pays where another
+      # stream has work for the freed CUs (the pipelined schedule: -0.4 ms per step at configs[1])
+      # and costs 0.7 ms where the step waits for the rollout (sequential plan, eager steps)
+      rows = self.cfg.get('hip', {}).get('imag_rows', 'auto')
+      rows = (32 if self._pipelined_capture else 16) if str(rows) == 'auto' else int(rows)
+      ops.imag_set_rows(rows)
     ops.imagine_rollout_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'],
                             self.unimix, ca['minstd'], ca['maxstd'], t, t0, t1)
 
@@ -2024,6 +2032,7 @@ class Learner:
     agent.Agent: step k's behaviour phase runs next to step k+1's world-model phase."""
     plans = []
     keep, self.overlap_b = self.overlap_b, False
+    self._pipelined_capture = True
     try:
       for fn in (lambda: self.phase_a1(True), self.phase_wm_opt, self.phase_b):
         plan = graphs.GraphPlan(self.device)
@@ -2032,6 +2041,7 @@ class Learner:
         plans.append(plan)
     finally:
       self.overlap_b = keep
+      self._pipelined_capture = False
     return plans
 
   def metric_tensors(self):

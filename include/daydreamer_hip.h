@@ -34,7 +34,7 @@ extern "C" {
  * 7 (round 5): dd_video_grid added.  8: dd_reduce_stats_multi added.
  * 9: dd_imagine_rollout_oh_fwd added; dd_imagine_rollout_supported answers discrete = 1 shapes.
  * 10: dd_ln_act_fwd_head / dd_ln_act_bwd_head added.
- * 11 (round 6): dd_gemm_f32_x added. */
+ * 11 (round 6): dd_gemm_f32_x, dd_imag_set_rows added. */
 #define DD_ABI_VERSION 11
 int dd_version(void);
 const char* dd_last_error(void);
@@ -481,6 +481,11 @@ int dd_imagine_rollout_supported(int D, int U, int G, int C, int A, int actor_un
 int dd_imagine_rollout_fwd(int N, int H, int t0, int t1, int D, int U, int G, int C, int A,
                            int actor_units, float unimix, float lo, float hi,
                            const void* const* ptrs, int n_ptrs, void* stream);
+/* Rows of the imagination batch per workgroup of dd_imagine_rollout_fwd: 32 (default: a workgroup
+ * multiplies two 16-row operand tiles against every streamed weight fragment, the launch holds
+ * half the CUs) or 16 (the round 3-5 kernel; also DD_IMAG_ROWS=16).  Same outputs, same arithmetic
+ * per row.  Returns the previous value. */
+int dd_imag_set_rows(int rows);
 /* The same for ONE-HOT action spaces (actor_grad 'reinforce', agent.py:357-358: no gradient through
  * the dynamics, so forward only) at deter = units = 512 (xarm / ur5 blocks, configs.yaml:245-295):
  * policy head = Linear(A) + unimix softmax + inverse-CDF draw (the class dd_stats_sample_fwd draws

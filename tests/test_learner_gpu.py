@@ -244,8 +244,10 @@ def _record_flips(what, B, T, H, adim, flipped, N):
     pass
 
 
-def test_fused_imagination_rollout_equals_launch_sequence(hip):
-  """csrc/imag.hip: WorldModel.imagine (H img_steps + H + 1 policy evaluations) as ONE persistent
+@pytest.mark.parametrize('rows', [16, 32])
+def test_fused_imagination_rollout_equals_launch_sequence(hip, rows):
+  """(rows: of the imagination batch per workgroup - csrc/imag.hip 16, csrc/imag32.hip 32.)
+  csrc/imag.hip: WorldModel.imagine (H img_steps + H + 1 policy evaluations) as ONE persistent
   launch against the per-layer launch sequence, inside a whole train step on the same minibatch
   and weights, at the full configs[1] size, on a ragged row count (N = 21 * 7 = 147: a partly
   filled 16-row block) and for the 6-dim action space.  Rows whose latent draws all agree must
@@ -260,7 +262,7 @@ def test_fused_imagination_rollout_equals_launch_sequence(hip):
         cfg, image=64, vector=16, action=adim, terminals=0.02, smooth=True)
     Ls, mets = [], []
     for fused in (True, False):
-      plain2 = dict(plain, hip=dict(plain.get('hip', {}), fused_imag=fused))
+      plain2 = dict(plain, hip=dict(plain.get('hip', {}), fused_imag=fused, imag_rows=rows))
       sp2 = type(sp)(**{**sp.__dict__, 'cfg': plain2})
       L = learner_mod.Learner(sp2, hip, 'cuda:0', B, T, params=params, noise_seed=7)
       assert L.fused_imag == fused
@@ -277,7 +279,7 @@ def test_fused_imagination_rollout_equals_launch_sequence(hip):
     same = (sa.argmax(-1) == sb.argmax(-1)).all(-1).all(0)                # rows with identical draws throughout
     flipped = int((~same).sum())
     print(f'fused imagination {name} B{B} T{T} H{H} A{adim}: {flipped} of {N} rows contain a flipped draw')
-    _record_flips('fused imagination (continuous)', B, T, H, adim, flipped, N)
+    _record_flips(f'fused imagination (continuous, {rows} rows per workgroup)', B, T, H, adim, flipped, N)
     assert flipped <= max(1, N // 500)
     def cmp(x, y, what, rows_per_t, tol=5e-5):
       x = x.reshape(rows_per_t, N, -1)[:, same].double()

@@ -1,11 +1,16 @@
 """A/B of one `hip.<knob>` on the same box, alternating runs: step time of configs[1] under the
 sequential and the shipped default schedule with the knob on / off.
-  python tools/ab_knob.py fold_heads [config]"""
+  python tools/ab_knob.py fold_heads [config]
+  python tools/ab_knob.py imag_rows=32,16 [config]      (two values instead of on / off)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 from daydreamer_amd import agent as agent_mod, config as config_mod, synthetic
 knob = sys.argv[1]
+vals = (True, False)
+if '=' in knob:
+  knob, vs = knob.split('=')
+  vals = tuple(int(v) if v.lstrip('-').isdigit() else v for v in vs.split(','))
 name = sys.argv[2] if len(sys.argv) > 2 else 'a1_vision'
 cfgs = config_mod.load_configs()
 base = config_mod.Config(cfgs['defaults']).update(cfgs[name])
@@ -29,9 +34,9 @@ def run(cfg, n=30):
 for rep in range(3):
   for pipe in (False, 'auto'):
     res = []
-    for on in (True, False):
+    for on in vals:
       cfg = base.update({f'hip.{knob}': on})
       if pipe is False:
         cfg = cfg.update({'hip.pipeline': False})
       res.append(run(cfg))
-    print(f'rep {rep} schedule {"sequential" if pipe is False else "default"}: {knob} on {res[0]:.2f} ms  off {res[1]:.2f} ms', flush=True)
+    print(f'rep {rep} schedule {"sequential" if pipe is False else "default"}: {knob} {vals[0]} {res[0]:.2f} ms  {vals[1]} {res[1]:.2f} ms', flush=True)
