@@ -16,6 +16,7 @@
 // from a pre-split fragment-major plane cache.  v_mfma_f32_16x16x32_bf16, six products.
 #include "dd_common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/daydreamer_hip.h"
 
 // Measurement hooks of tools/conv_image_probe.py / conv_down_probe.py (2 no MFMAs, 4 no stores, 8 no
@@ -532,5 +533,257 @@ int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const flo
   LD(2) LD(3) LD(5)
 #undef LD
   DD_CHECK_LAUNCH("dd_conv2d_s2_down(image)");
+  return 0;
+}
+
+namespace {
+// ============================================================================================
+// Image-side filter gradient: dw[(ky, kx, cb), co] = sum over images n and output pixels (i, j) of
+// big[n, 2i+ky, 2j+kx, cb] * small[n, i, j, co] for a `big` tensor with a handful of channels - the
+// encoder's first layer on the uint8 image (nets.py:291-305, Conv2D :547 under GradientTape,
+// tfutils.py:214) and the decoder's image layer (nets.py:308-327).
+//
+// As a contraction M = k*k*Cb is 48 / 108 rows, N = 64, K = n*hs*ws = 2.3 M: the generic implicit
+// GEMM gathers a 4-byte (1-byte) element per (tap, pixel) straight from global memory for every
+// k-tile and ran the two call sites at 41 / 54 TFLOP/s (364 / 577 us for 0.65 / 0.70 GB).  Here
+// the contraction step is ONE output row (<= 32 pixels) of one image:
+//   * the k image rows it touches sit in a rolling 8-row LDS window, split once into bf16 planes
+//     and de-interleaved by column parity / channel and stored once per tap shift s = kx / 2, so
+//     the 8 consecutive output pixels of a tap (image columns 2j + kx) are 16 contiguous, aligned
+//     bytes: the A fragment of v_mfma_f32_16x16x32_bf16 is one ds_read_b128 per plane;
+//   * the 64-channel row is staged [pixel][channel] as three planes and read through
+//     ds_read_tr16_b64 (the transposing read of gemm_core.h's row-contiguous operands);
+//   * a uint8 image is exact in ONE bf16 plane (0..255): three products instead of six, `/255`
+//     applied once to the sum;
+//   * each workgroup keeps its [taps x 64] partial sum in registers over its rows (work item =
+//     half an image, so that consecutive rows reuse the window) and writes one slab; the slabs
+//     are added in workgroup order by the split-K reduce pass (deterministic).
+constexpr int WG_RUN = 40;      // bf16 elements per (parity, channel, shift) run: 32 + zero pad
+constexpr int WG_RW = 8;        // image rows in the window (k + 2 new ones <= 8)
+constexpr int WG_GSTR = 192;    // bytes per pixel of a staged 64-channel plane (128 + pad)
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_w;
+
+template <int K, int CB, typename TI>
+__global__ void __launch_bounds__(256, 2)
+k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, float* __restrict__ slabs,
+                   int hb, int wb, int hs, int ws_, int n_items, int HR, int per, int dbg) {
+  constexpr bool U8 = sizeof(TI) == 1;
+  constexpr int NP = U8 ? 1 : 3;                  // planes of the image operand
+  constexpr int NS = K / 2, NTAP = K * K * CB, MT = (NTAP + 15) / 16;
+  constexpr int ROWEL = 2 * CB * NS * WG_RUN;     // elements per window row and plane
+  constexpr int EPV = U8 ? 4 : 2;                 // image elements per thread-vector (4 bytes / float2: the staging
+                                                  // of a row's 192 elements is spread over 48 / 96 threads)
+  __shared__ __attribute__((aligned(16))) unsigned short iw[NP][WG_RW][ROWEL];
+  __shared__ __attribute__((aligned(16))) unsigned char gp[2][3][32 * WG_GSTR];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rowlen = wb * CB, VPR = rowlen / EPV;           // image row in elements / vectors
+  constexpr int NIV = U8 ? (K > 4 ? 2 : 1) : (K > 4 ? 3 : 2);  // image vectors per thread and output row (K rows x 48 / 96 vectors)
+
+  for (int it = tid; it < NP * WG_RW * ROWEL / 2; it += 256) reinterpret_cast<unsigned*>(&iw[0][0][0])[it] = 0u;
+
+  // this lane's tap of M tile m (A operand row lane & 15): window-row offset ky and the byte
+  // offset of its run (parity, channel, shift) + this lane's 8-pixel chunk
+  int tky[MT], toff[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int tap = min(m * 16 + (lane & 15), NTAP - 1);
+    const int ky = tap / (K * CB), rem = tap - ky * (K * CB), kx = rem / CB, cb = rem - kx * CB;
+    tky[m] = ky;
+    toff[m] = ((((kx & 1) * CB + cb) * NS + (kx >> 1)) * WG_RUN + (lane >> 4) * 8) * 2;
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int item_lo = blockIdx.x * per, item_hi = min(n_items, item_lo + per);
+  // cursor over the output rows of this workgroup's items: (item, i), first = first row of its item
+  struct Cur { int item, i, first, ok; };
+  auto start = [&](int item) {
+    Cur c; c.item = item; c.i = (item & 1) * HR; c.first = 1; c.ok = item < item_hi;
+    return c;
+  };
+  auto next = [&](Cur c) {
+    Cur d = c;
+    const int i_end = min(hs, ((c.item & 1) + 1) * HR);
+    if (c.i + 1 < i_end) { d.i = c.i + 1; d.first = 0; }
+    else d = start(c.item + 1);
+    return d;
+  };
+  uint4 gv[4][2];
+  typename std::conditional<U8, unsigned, uint2>::type iv[4][NIV];
+  auto load = [&](int set, Cur c) {
+    if (!c.ok || IMG_DBG(8)) return;
+    const int n = c.item >> 1;
+    const float* grow = G + (((long)n * hs + c.i) * ws_) * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int id = tid + 256 * u, pix = id >> 4, c4 = (id & 15) * 4;
+      gv[set][u] = pix < ws_ ? *reinterpret_cast<const uint4*>(grow + pix * 64 + c4) : make_uint4(0, 0, 0, 0);
+    }
+    const int r0 = c.first ? 2 * c.i : 2 * c.i + K - 2, nr = c.first ? K : 2;
+    const TI* ibase = img + ((long)n * hb + r0) * rowlen;
+#pragma unroll
+    for (int u = 0; u < NIV; ++u) {
+      const int id = tid + 256 * u, rr = id / VPR, v = id - rr * VPR;
+      const bool okv = rr < nr && r0 + rr < hb;
+      if constexpr (U8) iv[set][u] = okv ? *reinterpret_cast<const unsigned*>(ibase + (long)rr * rowlen + v * EPV) : 0u;
+      else iv[set][u] = okv ? *reinterpret_cast<const uint2*>(ibase + (long)rr * rowlen + v * EPV) : make_uint2(0, 0);
+    }
+  };
+  auto stage = [&](int set, Cur c, int buf) {
+    if (!c.ok) return;
+    // ---- the 64-channel row: [pixel][channel] planes
+    if (!IMG_DBG(16))
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int id = tid + 256 * u, pix = id >> 4, c4 = (id & 15) * 4;
+      unsigned h[4], m[4], l[4];
+      split3(__uint_as_float(gv[set][u].x), h[0], m[0], l[0]);
+      split3(__uint_as_float(gv[set][u].y), h[1], m[1], l[1]);
+      split3(__uint_as_float(gv[set][u].z), h[2], m[2], l[2]);
+      split3(__uint_as_float(gv[set][u].w), h[3], m[3], l[3]);
+      const int o = pix * WG_GSTR + c4 * 2;
+      *reinterpret_cast<uint2*>(&gp[buf][0][o]) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
+      *reinterpret_cast<uint2*>(&gp[buf][1][o]) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
+      *reinterpret_cast<uint2*>(&gp[buf][2][o]) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+    }
+    if (IMG_DBG(4)) return;
+    // ---- the new image rows: planes, de-interleaved, one copy per tap shift
+    const int r0 = c.first ? 2 * c.i : 2 * c.i + K - 2, nr = c.first ? K : 2;
+#pragma unroll
+    for (int u = 0; u < NIV; ++u) {
+      const int id = tid + 256 * u, rr = id / VPR, v = id - rr * VPR;
+      if (rr < nr) {
+        const int slot = (r0 + rr) & (WG_RW - 1);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          float f;
+          if constexpr (U8) f = (float)((iv[set][u] >> (8 * e)) & 255u);
+          else f = __uint_as_float(e == 0 ? iv[set][u].x : iv[set][u].y);
+          unsigned pl[3];
+          split3(f, pl[0], pl[1], pl[2]);
+          const int idx = v * EPV + e, x = idx / CB, cb = idx - x * CB;
+          const int run0 = (((x & 1) * CB + cb) * NS) * WG_RUN, mm = x >> 1;
+#pragma unroll
+          for (int s_ = 0; s_ < NS; ++s_)
+            if (mm - s_ >= 0) {
+#pragma unroll
+              for (int p = 0; p < NP; ++p) iw[p][slot][run0 + s_ * WG_RUN + mm - s_] = (unsigned short)(pl[p] >> 16);
+            }
+        }
+      }
+    }
+  };
+  auto multiply = [&](Cur c, int buf) {
+    if (!c.ok || IMG_DBG(2)) return;
+    typedef __attribute__((address_space(3))) bf16x4_w* lds_p;
+    bf16x8 bf[3];
+    {
+      const int i16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned char* q = &gp[buf][p][(g4 * 8 + (i16 >> 2)) * WG_GSTR + (wave * 16 + 4 * (i16 & 3)) * 2];
+        const bf16x4_w lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(q));
+        const bf16x4_w hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(q + 4 * WG_GSTR));
+        const uint2 a_ = __builtin_bit_cast(uint2, lo), b_ = __builtin_bit_cast(uint2, hi);
+        bf[p] = __builtin_bit_cast(bf16x8, make_uint4(a_.x, a_.y, b_.x, b_.y));
+      }
+    }
+    // all A fragments first, then the products plane pair by plane pair over the M tiles:
+    // consecutive matrix instructions go to different accumulators (a tile's six products
+    // back to back are one dependent chain)
+    bf16x8 af[MT][NP];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int slot = (2 * c.i + tky[m]) & (WG_RW - 1);
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        af[m][p] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&iw[p][slot][0]) + toff[m]);
+    }
+    // (smallest terms first, as every split contraction of the library; uint8: the image plane is
+    // exact, the products with its zero lower planes are left out)
+    constexpr int PA_[6] = {NP - 1, 0, NP > 1 ? 1 : 0, NP > 1 ? 1 : 0, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      if (U8 && !(q == 1 || q == 4 || q == 5)) continue;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][PA_[q]], bf[PB_[q]], acc[m], 0, 0, 0);
+    }
+  };
+
+  Cur c0 = start(item_lo), c1 = next(c0), c2 = next(c1), c3 = next(c2);
+  load(0, c0);
+  load(1, c1);
+  load(2, c2);
+  __syncthreads();            // (the window's zero fill)
+  stage(0, c0, 0);
+  __syncthreads();
+  // (a role-separated form - four waves staging, four multiplying, one barrier per row - was
+  // measured SLOWER, 567 / 331 us: with half the waves issuing loads the stream fell to 1.8 TB/s)
+#define WG_STEP(P)                                                                         \
+  load(((P) + 3) & 3, c3);                                                                 \
+  multiply(c0, (P) & 1);                                                                   \
+  if (c1.first) __syncthreads();   /* a new item overwrites window rows the multiply reads */ \
+  stage(((P) + 1) & 3, c1, ((P) + 1) & 1);                                                 \
+  __syncthreads();                                                                         \
+  c0 = c1; c1 = c2; c2 = c3; c3 = next(c3);
+  while (c0.ok) {
+    WG_STEP(0)
+    if (!c0.ok) break;
+    WG_STEP(1)
+    if (!c0.ok) break;
+    WG_STEP(2)
+    if (!c0.ok) break;
+    WG_STEP(3)
+  }
+#undef WG_STEP
+  // ---- this workgroup's slab: D element (row (lane >> 4) * 4 + r, column lane & 15) of tile m
+  float* slab = slabs + (long)blockIdx.x * NTAP * 64;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tap = m * 16 + (lane >> 4) * 4 + r;
+      if (tap < NTAP) slab[tap * 64 + wave * 16 + (lane & 15)] = acc[m][r];
+    }
+}
+
+}  // namespace
+
+// Image-side filter gradient.  Returns 1 when the geometry is not covered (the caller then takes the
+// generic path), else 0 with *n_slabs partial sums [n_slabs][k*k*Cb][64] at the start of the
+// workspace: the caller adds them (split-K reduce pass; uint8: times in_scale).
+int dd_conv_image_wgrad(const void* big, int big_is_u8, const float* small, int n_img, int hb, int wb,
+                        int Cb, int hs, int ws_, int Cs, int k, float* wsp, size_t ws_bytes,
+                        int* n_slabs, hipStream_t st) {
+  static const int off = getenv("DD_IMG_WGRAD_OFF") ? atoi(getenv("DD_IMG_WGRAD_OFF")) : 0;
+  if (off || Cs != 64 || !(k == 4 || k == 6) || Cb != 3 || wb > 64 || ws_ > 32 || ws_ < 1 || hs < 2 || n_img < 1) return 1;
+  const int rowlen = wb * Cb;
+  if (rowlen % 4 || (((uintptr_t)big | (uintptr_t)small) & 15)) return 1;
+  if (rowlen > 192) return 1;                                          // (image vectors per thread: K rows x 48 / 96)
+  if (2 * (hs - 1) + k > hb || 2 * (ws_ - 1) + k > wb) return 1;
+  const int HR = (hs + 1) / 2;
+  const long items_l = 2l * n_img;
+  if (items_l > (1 << 30)) return 1;
+  const int n_items = (int)items_l;
+  int grid = n_items < 512 ? n_items : 512;
+  const int per = (n_items + grid - 1) / grid;
+  grid = (n_items + per - 1) / per;                                   // every workgroup has at least one item
+#ifdef DD_BUILD_IMGDBG
+  static const int dbg = getenv("DD_IMG_DBG") ? atoi(getenv("DD_IMG_DBG")) : 0;   // 2 no MFMAs, 4 no image staging, 16 no row staging, 8 no loads
+#else
+  const int dbg = 0;
+#endif
+  const size_t need = (size_t)grid * k * k * Cb * 64 * sizeof(float);
+  if (!wsp || ws_bytes < need) return 1;
+#define LW(K_, T_) k_conv_image_wgrad<K_, 3, T_><<<grid, 256, 0, st>>>((const T_*)big, small, wsp, hb, wb, hs, ws_, n_items, HR, per, dbg)
+  if (big_is_u8) { if (k == 4) LW(4, unsigned char); else LW(6, unsigned char); }
+  else { if (k == 4) LW(4, float); else LW(6, float); }
+#undef LW
+  DD_CHECK_LAUNCH("dd_conv2d_s2_wgrad(image)");
+  *n_slabs = grid;
   return 0;
 }

@@ -1,6 +1,10 @@
 // Filter gradient of the stride-2 convolutions.
 #include "gemm_core.h"
 
+int dd_conv_image_wgrad(const void* big, int big_is_u8, const float* small, int n_img, int hb, int wb,
+                        int Cb, int hs, int ws_, int Cs, int k, float* wsp, size_t ws_bytes,
+                        int* n_slabs, hipStream_t st);   // conv_image.hip
+
 extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float* dw,
                                   int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
                                   float in_scale, float beta, float* wsp, size_t ws_bytes,
@@ -8,6 +12,17 @@ extern "C" int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* s
   hipStream_t st = (hipStream_t)stream;
   DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_wgrad: geometry");
   const int M = k * k * Cb, N = Cs, K = n_img * hs * ws_;
+  if (gemm_mode() == 6) {   // image-side layers (3 channels): the dedicated kernel of conv_image.hip
+    int n_slabs = 0;
+    const int rc = dd_conv_image_wgrad(big, big_is_u8, small, n_img, hb, wb, Cb, hs, ws_, Cs, k, wsp, ws_bytes,
+                                       &n_slabs, st);
+    if (rc == 0) {
+      launch_splitk_reduce(wsp, n_slabs, (long)M * N, N, dw, Cs, nullptr, big_is_u8 ? in_scale : 1.f, beta, st);
+      DD_CHECK_LAUNCH("dd_conv2d_s2_wgrad(image reduce)");
+      return 0;
+    }
+    if (rc != 1) return rc;
+  }
   const int kwc = k * Cb;
   const int vb = aligned16(small) && (Cs % 4 == 0);
   if (big_is_u8) {

@@ -257,7 +257,13 @@ CONVS = [  # n, hb, Cb, hs, Cs, k, u8
     # thin image side with 64 feature channels (GEMM + col2im form): the decoder's RGB layer, an
     # encoder-geometry k = 4 layer, an odd kernel on an odd size, one- and two-channel images
     (3, 64, 3, 30, 64, 6, False), (2, 64, 3, 31, 64, 4, False), (2, 33, 3, 15, 64, 5, False),
-    (1, 20, 2, 8, 64, 6, False), (40, 64, 1, 30, 64, 6, False)]
+    (1, 20, 2, 8, 64, 6, False), (40, 64, 1, 30, 64, 6, False),
+    # the image-side filter-gradient kernel (conv_image.hip k_conv_image_wgrad: 3 channels, 64 features,
+    # k 4 / 6): uint8 and float images, one image (two work items), an odd image count, a 32-wide image,
+    # more images than workgroups
+    (3, 64, 3, 31, 64, 4, True), (5, 64, 3, 30, 64, 6, True), (1, 64, 3, 31, 64, 4, True),
+    (7, 32, 3, 14, 64, 6, False), (2, 32, 3, 15, 64, 4, False), (300, 64, 3, 31, 64, 4, True),
+    (270, 16, 3, 6, 64, 6, False)]
 
 
 @pytest.mark.parametrize('n,hb,Cb,hs,Cs,k,u8', CONVS)

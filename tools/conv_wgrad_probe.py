@@ -1,0 +1,22 @@
+import sys, os
+sys.path.insert(0, '.')
+import torch
+from daydreamer_amd import hipops
+ops = hipops.HipOps('cuda:0')
+n = 2500
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def timeit(fn, reps=10):
+  for _ in range(3): fn()
+  torch.cuda.synchronize(); e0.record()
+  for _ in range(reps): fn()
+  e1.record(); torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / reps
+small = torch.randn(n, 30, 30, 64, device='cuda')
+dw6 = torch.zeros(6, 6, 3, 64, device='cuda')
+dz = torch.randn(n, 64, 64, 3, device='cuda')
+a = timeit(lambda: ops.conv_wgrad(dz, small, dw6, 6))
+img = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, device='cuda')
+s31 = torch.randn(n, 31, 31, 64, device='cuda')
+dw4 = torch.zeros(4, 4, 3, 64, device='cuda')
+b = timeit(lambda: ops.conv_wgrad(img, s31, dw4, 4, 1.0 / 255.0))
+print(f'DBG={os.environ.get("DD_IMG_DBG","0")}: f32 k6 {a*1e3:.1f} us   u8 k4 {b*1e3:.1f} us')
