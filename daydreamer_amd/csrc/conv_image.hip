@@ -561,13 +561,25 @@ namespace {
 constexpr int WG_RUN = 40;      // bf16 elements per (parity, channel, shift) run: 32 + zero pad
 constexpr int WG_RW = 8;        // image rows in the window (k + 2 new ones <= 8)
 constexpr int WG_GSTR = 192;    // bytes per pixel of a staged 64-channel plane (128 + pad)
+#ifndef WG_IL_VALU
+#define WG_IL_VALU 6            // VALU instructions of the staging issued behind each matrix instruction
+#endif
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_w;
 
-template <int K, int CB, typename TI>
+// LNB: `G` is the gradient at the OUTPUT of the small-side layer's LayerNorm + ELU (nets.py:585-602,
+// 510-513); its backward (the arithmetic of k_ln_act_bwd_v, rowops.hip) runs on the staged row -
+// a pixel's 64 channels are 16 consecutive lanes - so dz is never written to or read from HBM;
+// the LayerNorm parameter gradients and the bias gradient (column sums of dy * xhat, dy, dz) are
+// kept per thread over the workgroup's rows and leave as one partial row [3][64] per workgroup.
+struct WgradLn {
+  const float* z; const float* stats; const float* gamma; const float* beta; float* partials;
+};
+
+template <int K, int CB, typename TI, bool LNB>
 __global__ void __launch_bounds__(256, 2)
 k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, float* __restrict__ slabs,
-                   int hb, int wb, int hs, int ws_, int n_items, int HR, int per, int dbg) {
+                   int hb, int wb, int hs, int ws_, int n_items, int HR, int per, int dbg, WgradLn ln) {
   constexpr bool U8 = sizeof(TI) == 1;
   constexpr int NP = U8 ? 1 : 3;                  // planes of the image operand
   constexpr int NS = K / 2, NTAP = K * K * CB, MT = (NTAP + 15) / 16;
@@ -612,6 +624,13 @@ k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, floa
     return d;
   };
   uint4 gv[4][2];
+  [[maybe_unused]] uint4 gz[LNB ? 4 : 1][2];
+  [[maybe_unused]] float2 gs[LNB ? 4 : 1][2];
+  [[maybe_unused]] float4 ln_g = make_float4(0.f, 0.f, 0.f, 0.f), ln_b = ln_g, pg = ln_g, pb = ln_g, pz = ln_g;
+  if constexpr (LNB) {
+    ln_g = *reinterpret_cast<const float4*>(ln.gamma + (tid & 15) * 4);
+    ln_b = *reinterpret_cast<const float4*>(ln.beta + (tid & 15) * 4);
+  }
   typename std::conditional<U8, unsigned, uint2>::type iv[4][NIV];
   auto load = [&](int set, Cur c) {
     if (!c.ok || IMG_DBG(8)) return;
@@ -621,6 +640,11 @@ k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, floa
     for (int u = 0; u < 2; ++u) {
       const int id = tid + 256 * u, pix = id >> 4, c4 = (id & 15) * 4;
       gv[set][u] = pix < ws_ ? *reinterpret_cast<const uint4*>(grow + pix * 64 + c4) : make_uint4(0, 0, 0, 0);
+      if constexpr (LNB) {
+        const long prow = ((long)n * hs + c.i) * ws_ + pix;
+        gz[set][u] = pix < ws_ ? *reinterpret_cast<const uint4*>(ln.z + prow * 64 + c4) : make_uint4(0, 0, 0, 0);
+        gs[set][u] = pix < ws_ ? *reinterpret_cast<const float2*>(ln.stats + prow * 2) : make_float2(0.f, 0.f);
+      }
     }
     const int r0 = c.first ? 2 * c.i : 2 * c.i + K - 2, nr = c.first ? K : 2;
     const TI* ibase = img + ((long)n * hb + r0) * rowlen;
@@ -640,10 +664,38 @@ k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, floa
     for (int u = 0; u < 2; ++u) {
       const int id = tid + 256 * u, pix = id >> 4, c4 = (id & 15) * 4;
       unsigned h[4], m[4], l[4];
-      split3(__uint_as_float(gv[set][u].x), h[0], m[0], l[0]);
-      split3(__uint_as_float(gv[set][u].y), h[1], m[1], l[1]);
-      split3(__uint_as_float(gv[set][u].z), h[2], m[2], l[2]);
-      split3(__uint_as_float(gv[set][u].w), h[3], m[3], l[3]);
+      float gvf[4] = {__uint_as_float(gv[set][u].x), __uint_as_float(gv[set][u].y),
+                      __uint_as_float(gv[set][u].z), __uint_as_float(gv[set][u].w)};
+      if constexpr (LNB) {   // dz = LayerNorm + ELU backward of this pixel (k_ln_act_bwd_v's expressions)
+        const float zz[4] = {__uint_as_float(gz[set][u].x), __uint_as_float(gz[set][u].y),
+                             __uint_as_float(gz[set][u].z), __uint_as_float(gz[set][u].w)};
+        const float gm[4] = {ln_g.x, ln_g.y, ln_g.z, ln_g.w}, bt[4] = {ln_b.x, ln_b.y, ln_b.z, ln_b.w};
+        const float mean = gs[set][u].x, rstd = gs[set][u].y;
+        float xh[4], g[4], dy[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[j] = (zz[j] - mean) * rstd;
+          const float y = xh[j] * gm[j] + bt[j];
+          // ELU'(y) = 1 (y > 0) or exp(y): k_ln_act_bwd_v forms it as expm1f(y) + 1; the hardware
+          // exponential agrees with that to a few ulp at a tenth of the instructions
+          dy[j] = gvf[j] * (y > 0.f ? 1.f : __builtin_amdgcn_exp2f(y * 1.44269504088896341f));
+          g[j] = dy[j] * gm[j];
+        }
+        s1 = (g[0] + g[1]) + (g[2] + g[3]);
+        s2 = (g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3]);
+#pragma unroll
+        for (int o_ = 1; o_ < 16; o_ <<= 1) { s1 += __shfl_xor(s1, o_, 64); s2 += __shfl_xor(s2, o_, 64); }
+        s1 /= 64.f; s2 /= 64.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gvf[j] = rstd * (g[j] - s1 - xh[j] * s2);
+        pg.x += dy[0] * xh[0]; pg.y += dy[1] * xh[1]; pg.z += dy[2] * xh[2]; pg.w += dy[3] * xh[3];
+        pb.x += dy[0]; pb.y += dy[1]; pb.z += dy[2]; pb.w += dy[3];
+        pz.x += gvf[0]; pz.y += gvf[1]; pz.z += gvf[2]; pz.w += gvf[3];
+      }
+      split3(gvf[0], h[0], m[0], l[0]);
+      split3(gvf[1], h[1], m[1], l[1]);
+      split3(gvf[2], h[2], m[2], l[2]);
+      split3(gvf[3], h[3], m[3], l[3]);
       const int o = pix * WG_GSTR + c4 * 2;
       *reinterpret_cast<uint2*>(&gp[buf][0][o]) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
       *reinterpret_cast<uint2*>(&gp[buf][1][o]) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
@@ -723,11 +775,25 @@ k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, floa
   __syncthreads();
   // (a role-separated form - four waves staging, four multiplying, one barrier per row - was
   // measured SLOWER, 567 / 331 us: with half the waves issuing loads the stream fell to 1.8 TB/s)
+  // Inside an item the multiply of row r and the staging of row r + 1 touch different LDS (other
+  // buffer, other window rows): one block, the matrix instructions interleaved with the staging's
+  // VALU / LDS work by the scheduler hints (they ran back to back, each about a third of the time).
+  // A new item rewrites window rows the multiply reads: there the staging waits for it.
 #define WG_STEP(P)                                                                         \
   load(((P) + 3) & 3, c3);                                                                 \
-  multiply(c0, (P) & 1);                                                                   \
-  if (c1.first) __syncthreads();   /* a new item overwrites window rows the multiply reads */ \
-  stage(((P) + 1) & 3, c1, ((P) + 1) & 1);                                                 \
+  if (c1.first) {                                                                          \
+    multiply(c0, (P) & 1);                                                                 \
+    __syncthreads();                                                                       \
+    stage(((P) + 1) & 3, c1, ((P) + 1) & 1);                                               \
+  } else {                                                                                 \
+    multiply(c0, (P) & 1);                                                                 \
+    stage(((P) + 1) & 3, c1, ((P) + 1) & 1);                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < MT * (U8 ? 3 : 6); ++i_) {                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+      __builtin_amdgcn_sched_group_barrier(0x002, WG_IL_VALU, 0);                          \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                   \
+    }                                                                                      \
+  }                                                                                        \
   __syncthreads();                                                                         \
   c0 = c1; c1 = c2; c2 = c3; c3 = next(c3);
   while (c0.ok) {
@@ -740,6 +806,22 @@ k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, floa
     WG_STEP(3)
   }
 #undef WG_STEP
+  if constexpr (LNB) {
+    // the threads tid & 15 == q hold the sums of channels 4 q .. 4 q + 3 over their pixels: add the
+    // 16 pixel groups (tid >> 4) through LDS -> one partial row [3][64] of this workgroup
+    float* red = reinterpret_cast<float*>(&gp[0][0][0]);       // [16][3][64]  (the row buffers are free: barrier above)
+    float* r0 = red + (tid >> 4) * 192 + (tid & 15) * 4;
+    *reinterpret_cast<float4*>(r0) = pg;
+    *reinterpret_cast<float4*>(r0 + 64) = pb;
+    *reinterpret_cast<float4*>(r0 + 128) = pz;
+    __syncthreads();
+    if (tid < 192) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += red[i * 192 + tid];
+      ln.partials[(long)blockIdx.x * 192 + tid] = t;
+    }
+  }
   // ---- this workgroup's slab: D element (row (lane >> 4) * 4 + r, column lane & 15) of tile m
   float* slab = slabs + (long)blockIdx.x * NTAP * 64;
 #pragma unroll
@@ -755,16 +837,21 @@ k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, floa
 
 // Image-side filter gradient.  Returns 1 when the geometry is not covered (the caller then takes the
 // generic path), else 0 with *n_slabs partial sums [n_slabs][k*k*Cb][64] at the start of the
-// workspace: the caller adds them (split-K reduce pass; uint8: times in_scale).
+// workspace: the caller adds them (split-K reduce pass; uint8: times in_scale).  With ln_z != NULL
+// `small` is the gradient at the output of the small-side LayerNorm + ELU, whose backward is applied
+// while the rows are staged (k_conv_image_wgrad LNB); the [n_slabs][3][64] partial rows of the
+// LayerNorm scale / offset gradients and the bias gradient follow the slabs in the workspace.
 int dd_conv_image_wgrad(const void* big, int big_is_u8, const float* small, int n_img, int hb, int wb,
                         int Cb, int hs, int ws_, int Cs, int k, float* wsp, size_t ws_bytes,
-                        int* n_slabs, hipStream_t st) {
+                        int* n_slabs, hipStream_t st, const float* ln_z, const float* ln_stats,
+                        const float* ln_gamma, const float* ln_beta) {
   static const int off = getenv("DD_IMG_WGRAD_OFF") ? atoi(getenv("DD_IMG_WGRAD_OFF")) : 0;
   if (off || Cs != 64 || !(k == 4 || k == 6) || Cb != 3 || wb > 64 || ws_ > 32 || ws_ < 1 || hs < 2 || n_img < 1) return 1;
   const int rowlen = wb * Cb;
   if (rowlen % 4 || (((uintptr_t)big | (uintptr_t)small) & 15)) return 1;
   if (rowlen > 192) return 1;                                          // (image vectors per thread: K rows x 48 / 96)
   if (2 * (hs - 1) + k > hb || 2 * (ws_ - 1) + k > wb) return 1;
+  if (ln_z && ((((uintptr_t)ln_z | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) || ((uintptr_t)ln_stats & 7))) return 1;
   const int HR = (hs + 1) / 2;
   const long items_l = 2l * n_img;
   if (items_l > (1 << 30)) return 1;
@@ -777,11 +864,14 @@ int dd_conv_image_wgrad(const void* big, int big_is_u8, const float* small, int 
 #else
   const int dbg = 0;
 #endif
-  const size_t need = (size_t)grid * k * k * Cb * 64 * sizeof(float);
+  const size_t need = (size_t)grid * (k * k * Cb * 64 + (ln_z ? 192 : 0)) * sizeof(float);
   if (!wsp || ws_bytes < need) return 1;
-#define LW(K_, T_) k_conv_image_wgrad<K_, 3, T_><<<grid, 256, 0, st>>>((const T_*)big, small, wsp, hb, wb, hs, ws_, n_items, HR, per, dbg)
-  if (big_is_u8) { if (k == 4) LW(4, unsigned char); else LW(6, unsigned char); }
-  else { if (k == 4) LW(4, float); else LW(6, float); }
+  WgradLn ln{ln_z, ln_stats, ln_gamma, ln_beta, wsp + (size_t)grid * k * k * Cb * 64};
+#define LW(K_, T_, L_) k_conv_image_wgrad<K_, 3, T_, L_><<<grid, 256, 0, st>>>((const T_*)big, small, wsp, hb, wb, hs, ws_, n_items, HR, per, dbg, ln)
+#define LWL(K_, T_) { if (ln_z) LW(K_, T_, true); else LW(K_, T_, false); }
+  if (big_is_u8) { if (k == 4) LWL(4, unsigned char) else LWL(6, unsigned char) }
+  else { if (k == 4) LWL(4, float) else LWL(6, float) }
+#undef LWL
 #undef LW
   DD_CHECK_LAUNCH("dd_conv2d_s2_wgrad(image)");
   *n_slabs = grid;

@@ -917,6 +917,15 @@ int ln_act_bwd_impl(float* dout, long ldd, const float* z, long ldz,
 }
 }  // namespace
 
+// partial rows [rows][3][C] (dgamma, dbeta, column sum of dz: the layout of k_ln_act_bwd_v) ->
+// dgamma, dbeta, dbias (+ b * old); used by the fused image-side filter gradient (conv_wgrad.hip)
+int dd_ln_partials_reduce(const float* partials, int rows, int C, float* dgamma, float* dbeta, float* dbias,
+                          float b, hipStream_t st) {
+  k_col_reduce_n<<<dim3((C + 15) / 16, 3), 256, 0, st>>>(partials, rows, 3L * C, C, dgamma, dbeta, dbias, b);
+  DD_CHECK_LAUNCH("dd_ln_partials_reduce");
+  return 0;
+}
+
 // Parameter gradients only (bulk pass after a scan): dgamma/dbeta from stored
 // dout / out / z / stats of all steps.
 extern "C" int dd_ln_param_grad(const float* dout, long ldd, const float* z, long ldz,

@@ -35,6 +35,7 @@ _SIGS = {
     'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
     'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
+    'dd_conv2d_s2_wgrad_ln': [c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_same': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_z, c_p],
     'dd_conv2d_same_bwd_data': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
     'dd_conv2d_same_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_z, c_p],
@@ -370,6 +371,28 @@ class HipOps:
         big.data_ptr(), int(big.dtype == torch.uint8), small.data_ptr(),
         dw.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale, beta,
         self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_s2_wgrad')
+
+  def conv_wgrad_ln(self, big, dout, z, stats, gamma, beta_ln, dz, dw, dgamma, dbeta, dbias, k, in_scale=1.0):
+    """Filter gradient of an image-side Conv2D + LayerNorm + ELU layer from the gradient at the
+    layer OUTPUT: ln_act_bwd (activation recomputed from z) + conv_wgrad as one pass where the
+    geometry is covered (dd_conv2d_s2_wgrad_ln: dz never travels through HBM and `dz` stays
+    untouched), else the two launches (which write `dz`)."""
+    n, hb, wb, cb = big.shape
+    n2, hs, ws, cs = dout.shape
+    assert n == n2 and big.is_contiguous() and dout.is_contiguous() and z.is_contiguous() and stats.is_contiguous()
+    assert tuple(dw.shape) == (k, k, cb, cs) and dw.is_contiguous() and tuple(z.shape) == tuple(dout.shape)
+    fl = 2.0 * n * hs * ws * k * k * cb * cs
+    rc = self._traced(f'conv_wgrad n{n} {hb}x{cb},{hs}x{cs} k{k} B{big.numel() * big.element_size() + 4 * (2 * dout.numel() + dw.numel())}', fl, lambda: self.lib.dd_conv2d_s2_wgrad_ln(
+        big.data_ptr(), int(big.dtype == torch.uint8), in_scale, dout.data_ptr(), z.data_ptr(), stats.data_ptr(),
+        gamma.data_ptr(), beta_ln.data_ptr(), dw.data_ptr(), 0.0, dgamma.data_ptr(), dbeta.data_ptr(),
+        dbias.data_ptr(), 0, n, hb, wb, cb, hs, ws, cs, k, self.ws.data_ptr(), self.ws_bytes, self.stream))
+    if rc == 1:   # geometry not covered: nothing was launched
+      if self.trace:
+        self.trace.pop()
+      self.ln_act_bwd(dout.view(-1, cs), z.view(-1, cs), None, stats, gamma, dz.view(-1, cs), dgamma, dbeta,
+                      False, True, dbias, beta=beta_ln)
+      return self.conv_wgrad(big, dz, dw, k, in_scale)
+    self._check(rc, 'dd_conv2d_s2_wgrad_ln')
 
   # stride-1 SAME convolutions + 2x2 pooling / repetition (residual encoder / decoder)
 

@@ -468,6 +468,7 @@ class Learner:
                        self.ops.imagine_rollout_supported(D, U, G, self.C, A, ca['units'], ca['layers'],
                                                           self.n_prior, self.discrete))
     self._pipelined_capture = False   # set while capture_pipeline records the phase plans
+    self._fuse_img_ln = bool(self.cfg.get('hip', {}).get('fuse_image_ln', True)) and self.dtype == torch.float32
     # (the one-hot kernel takes the row width as an argument and keeps the padded rows)
     self.TW = F + A if (self.fused_imag and not self.discrete) else (F + A + 3) // 4 * 4
     W = self.TW
@@ -967,6 +968,14 @@ class Learner:
       for i in reversed(range(len(s.enc_convs))):
         cl, a = s.enc_convs[i], self.enc_act[i]
         C = cl.c_small
+        if i == 0 and self._fuse_img_ln and hasattr(ops, 'conv_wgrad_ln'):
+          # the first layer's dz feeds nothing but its own filter gradient (the image is not
+          # differentiated): LayerNorm backward applied while that kernel stages the rows
+          ops.conv_wgrad_ln(b['image'], a['dout'], a['z'], a['stats'], m.p[f'{cl.name}/norm/scale'],
+                            m.p[f'{cl.name}/norm/bias'], a['dz'], m.g[f'{cl.name}/kernel'],
+                            m.g[f'{cl.name}/norm/scale'], m.g[f'{cl.name}/norm/bias'], m.g[f'{cl.name}/bias'],
+                            cl.k, 1.0 / 255.0)
+          continue
         ops.ln_act_bwd(a['dout'].view(-1, C), a['z'].view(-1, C),
                        a['out'].view(-1, C), a['stats'],
                        m.p[f'{cl.name}/norm/scale'], a['dz'].view(-1, C),

@@ -34,7 +34,7 @@ extern "C" {
  * 7 (round 5): dd_video_grid added.  8: dd_reduce_stats_multi added.
  * 9: dd_imagine_rollout_oh_fwd added; dd_imagine_rollout_supported answers discrete = 1 shapes.
  * 10: dd_ln_act_fwd_head / dd_ln_act_bwd_head added.
- * 11 (round 6): dd_gemm_f32_x, dd_imag_set_rows added. */
+ * 11 (round 6): dd_gemm_f32_x, dd_imag_set_rows, dd_conv2d_s2_wgrad_ln added. */
 #define DD_ABI_VERSION 11
 int dd_version(void);
 const char* dd_last_error(void);
@@ -114,6 +114,19 @@ int dd_conv2d_s2_up(const float* small, const float* w, const float* bias, float
 int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float* dw,
                        int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
                        float in_scale, float beta, float* ws, size_t ws_bytes, void* stream);
+
+/* dd_conv2d_s2_wgrad for an image-side layer (big has 3 channels) whose small side is a Conv2D +
+ * LayerNorm + ELU (the encoder's first layer, nets.py:291-305, Norm :585-602): `dout` is the
+ * gradient at the layer OUTPUT [n, hs, ws, Cs]; dd_ln_act_bwd's arithmetic (activation recomputed
+ * from z, stats = [pixels, 2] mean / rstd) runs on the rows as they are staged, so dz is never
+ * written to or read from HBM.  Produces dw (beta * dw + ...), and what dd_ln_act_bwd would:
+ * dgamma, dbeta and dbias = column sum of dz (accumulated when `accumulate`).  Returns 1 with
+ * nothing launched when the geometry is not covered (then: dd_ln_act_bwd + dd_conv2d_s2_wgrad). */
+int dd_conv2d_s2_wgrad_ln(const void* big, int big_is_u8, float in_scale, const float* dout,
+                          const float* z, const float* stats, const float* gamma, const float* beta_ln,
+                          float* dw, float beta, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                          int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
+                          float* ws, size_t ws_bytes, void* stream);
 
 /* Stride-1 SAME convolutions (odd k; NHWC, filter [k,k,Cin,Cout]) of the residual encoder /
  * decoder: ImageEncoderResnet nets.py:330-358, ImageDecoderResnet nets.py:361-391, through

@@ -305,6 +305,45 @@ def test_conv_wgrad(hip, ref, n, hb, Cb, hs, Cs, k, u8):
     close(g, c, what=f'conv_wgrad beta{beta}')
 
 
+@pytest.mark.parametrize('n,hb,hs,k,u8', [(3, 64, 31, 4, True), (5, 64, 30, 6, False), (130, 32, 15, 4, True),
+                                          (2, 64, 31, 4, False), (2, 20, 8, 6, True)])
+def test_conv_wgrad_with_layernorm_backward(hip, ref, n, hb, hs, k, u8):
+  """dd_conv2d_s2_wgrad_ln: the filter gradient of an image-side Conv2D + LayerNorm + ELU layer
+  from the gradient at the layer output, with the LayerNorm backward applied while the rows are
+  staged (k_conv_image_wgrad LNB) - against ln_act_bwd + conv_wgrad of the CPU restatement: filter
+  gradient, LayerNorm scale / offset gradients and the bias gradient.  The last geometry (20-pixel
+  image) is not covered by the kernel: the wrapper's two-launch path."""
+  Cb, Cs = 3, 64
+  if u8:
+    big = torch.randint(0, 256, (n, hb, hb, Cb), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+  else:
+    big = rnd(n, hb, hb, Cb, seed=1)
+  dout, z = rnd(n, hs, hs, Cs, seed=2), rnd(n, hs, hs, Cs, seed=3)
+  gamma, beta = 1.0 + 0.1 * rnd(Cs, seed=4), 0.1 * rnd(Cs, seed=5)
+  zz = z.view(-1, Cs).double()
+  mean, var = zz.mean(1), zz.var(1, unbiased=False)
+  stats = torch.stack([mean, (var + 1e-3).rsqrt()], 1).float()
+  scale = 1.0 / 255.0 if u8 else 1.0
+  # restatement: the two launches
+  dz_c, dw_c = torch.zeros(n, hs, hs, Cs), torch.zeros(k, k, Cb, Cs)
+  dg_c, db_c, dbias_c = torch.zeros(Cs), torch.zeros(Cs), torch.zeros(Cs)
+  out = torch.nn.functional.elu((z.view(-1, Cs) - stats[:, :1]) * stats[:, 1:2] * gamma + beta)
+  ref.ln_act_bwd(dout.view(-1, Cs).clone(), z.view(-1, Cs), out, stats, gamma, dz_c.view(-1, Cs), dg_c, db_c,
+                 False, True, dbias_c, beta=beta)
+  ref.conv_wgrad(big, dz_c, dw_c, k, scale)
+  # fused
+  dev = lambda t: t.cuda()
+  dz_g, dw_g = torch.full((n, hs, hs, Cs), 7.0).cuda(), torch.full((k, k, Cb, Cs), 7.0).cuda()
+  dg_g, db_g, dbias_g = (torch.full((Cs,), 7.0).cuda() for _ in range(3))
+  hip.conv_wgrad_ln(dev(big), dev(dout), dev(z), dev(stats), dev(gamma), dev(beta), dz_g, dw_g, dg_g, db_g, dbias_g,
+                    k, scale)
+  torch.cuda.synchronize()
+  close(dw_g, dw_c, what='fused filter gradient')
+  close(dg_g, dg_c, what='fused dgamma')
+  close(db_g, db_c, what='fused dbeta')
+  close(dbias_g, dbias_c, what='fused dbias')
+
+
 # stride-1 SAME convolutions of the residual encoder / decoder: (n, h, Cin, Cout, k, u8)
 SAME = [
     (3, 8, 16, 32, 3, False), (2, 16, 32, 32, 3, False), (5, 4, 64, 128, 3, False),

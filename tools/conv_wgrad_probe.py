@@ -20,3 +20,16 @@ s31 = torch.randn(n, 31, 31, 64, device='cuda')
 dw4 = torch.zeros(4, 4, 3, 64, device='cuda')
 b = timeit(lambda: ops.conv_wgrad(img, s31, dw4, 4, 1.0 / 255.0))
 print(f'DBG={os.environ.get("DD_IMG_DBG","0")}: f32 k6 {a*1e3:.1f} us   u8 k4 {b*1e3:.1f} us')
+# ---- encoder first layer: LayerNorm backward + filter gradient as two launches vs the fused pass
+z = torch.randn(n, 31, 31, 64, device='cuda')
+zz = z.view(-1, 64)
+stats = torch.stack([zz.mean(1), (zz.var(1, unbiased=False) + 1e-3).rsqrt()], 1).contiguous()
+gamma, beta = torch.ones(64, device='cuda'), torch.zeros(64, device='cuda')
+dzb = torch.empty_like(z)
+dg, db, dbias = (torch.zeros(64, device='cuda') for _ in range(3))
+def two():
+  ops.ln_act_bwd(s31.view(-1, 64), zz, None, stats, gamma, dzb.view(-1, 64), dg, db, False, True, dbias, beta=beta)
+  ops.conv_wgrad(img, dzb, dw4, 4, 1.0 / 255.0)
+c = timeit(two)
+d = timeit(lambda: ops.conv_wgrad_ln(img, s31, z, stats, gamma, beta, dzb, dw4, dg, db, dbias, 4, 1.0 / 255.0))
+print(f'encoder layer 1 backward: ln_act_bwd + conv_wgrad {c*1e3:.1f} us   fused {d*1e3:.1f} us')
