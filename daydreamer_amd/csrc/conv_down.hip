@@ -4,7 +4,8 @@
 // conv_image.hip: the image-side layer (few `big` channels), rows split once into LDS planes
 int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const float* bias, float* small,
                        int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, float in_scale,
-                       float* wsp, size_t ws_bytes, hipStream_t st);
+                       float* wsp, size_t ws_bytes, hipStream_t st, const float* ln_gamma, const float* ln_beta,
+                       float* ln_out, float* ln_stats);
 
 extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const float* bias,
                                  float* small, int n_img, int hb, int wb, int Cb,
@@ -14,7 +15,8 @@ extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w,
   DD_REQUIRE(2 * (hs - 1) + k <= hb && 2 * (ws_ - 1) + k <= wb, "dd_conv2d_s2_down: geometry");
   static const int image_kernel = getenv("DD_DOWN_IMAGE") ? atoi(getenv("DD_DOWN_IMAGE")) : 1;
   if (image_kernel && Cb <= 4 && gemm_mode() == 6) {
-    const int rc = dd_conv_image_down(big, big_is_u8, w, bias, small, n_img, hb, wb, Cb, hs, ws_, Cs, k, in_scale, wsp, ws_bytes, st);
+    const int rc = dd_conv_image_down(big, big_is_u8, w, bias, small, n_img, hb, wb, Cb, hs, ws_, Cs, k, in_scale, wsp, ws_bytes, st,
+                                      nullptr, nullptr, nullptr, nullptr);
     if (rc != 1) return rc;   // (1: geometry not covered)
   }
   const int M = n_img * hs * ws_, N = Cs, K = k * k * Cb;
@@ -43,3 +45,19 @@ extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w,
   return run_mat<true, false>(al, MatRC<false>{w, Cs, Cs, vb}, M, N, K, small, Cs, bias, 1.f, 0.f, wsp, ws_bytes, st, "dd_conv2d_s2_down");
 }
 
+
+// dd_conv2d_s2_down of an image-side layer followed by its LayerNorm + ELU (the encoder's first
+// layer, nets.py:291-305 + Norm :585-602) in one pass: writes the pre-norm rows `small`, the
+// activations `out` and stats [pixels, 2] = mean / rstd (eps 1e-3) - what dd_conv2d_s2_down +
+// dd_ln_act_fwd write, without the second pass over `small`.  Returns 1 with nothing launched
+// when the geometry is not covered.
+extern "C" int dd_conv2d_s2_down_ln(const void* big, int big_is_u8, const float* w, const float* bias,
+                                    const float* gamma, const float* beta_ln, float* small, float* out,
+                                    float* stats, int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs,
+                                    int k, float in_scale, float* wsp, size_t ws_bytes, void* stream) {
+  if (gemm_mode() != 6 || Cb > 4 || Cs != 64 || !gamma || !beta_ln || !out || !stats ||
+      2 * (hs - 1) + k > hb || 2 * (ws_ - 1) + k > wb)
+    return 1;
+  return dd_conv_image_down(big, big_is_u8, w, bias, small, n_img, hb, wb, Cb, hs, ws_, Cs, k, in_scale, wsp, ws_bytes,
+                            (hipStream_t)stream, gamma, beta_ln, out, stats);
+}

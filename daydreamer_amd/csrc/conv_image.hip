@@ -352,11 +352,19 @@ __global__ void k_conv_image_down_wprep(const float* __restrict__ w, int k, int 
   }
 }
 
-template <int KS, int NT, typename TB>
+// LNF: the layer's LayerNorm + ELU (nets.py:585-602, 510-513) in the epilogue - a pixel's 64
+// channels sit in the 16 accumulator registers of four lanes (lane, lane ^ 16, lane ^ 32, lane ^ 48),
+// so its statistics are two shuffles; writes the pre-norm rows (small), the activations (ln.out)
+// and [pixels, 2] mean / rstd - what dd_ln_act_fwd would from a second pass over `small`.
+struct DownLn {
+  const float* gamma; const float* beta; float* out; float* stats;
+};
+
+template <int KS, int NT, typename TB, bool LNF>
 __global__ void __launch_bounds__(256, 2)
 k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, const float* __restrict__ bias,
                   float* __restrict__ small, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, int OPK,
-                  float in_scale, int tiles_j, int tiles_i, int n_tiles, int dbg) {
+                  float in_scale, int tiles_j, int tiles_i, int n_tiles, int dbg, DownLn ln) {
   constexpr int EPV = sizeof(TB) == 1 ? 16 : 4;        // elements per 16-byte vector
   constexpr int RMAX = 12, RSMAX = 264;                // staged rows (k + 6 <= 12), row stride (elements, wb*Cb + 8 <= 264): 19 KB
   __shared__ __attribute__((aligned(16))) unsigned short patch[3][RMAX * RSMAX];
@@ -474,6 +482,56 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
       }
     }
     // ---- epilogue: elements (rows (lane >> 4) * 4 + r = channels, column lane & 15 = output column) of tile (m, t)
+    if constexpr (LNF) {
+      static_assert(!LNF || NT == 4, "LayerNorm epilogue: 64 channels");
+      if (i < hs) {
+        const long prow = (img * hs + i) * (long)ws_;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int j = tj * DJ + m * 16 + (lane & 15);
+          float zv[NT][4];
+          float ps = 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int co = t * 16 + (lane >> 4) * 4;
+            const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            zv[t][0] = in_scale * acc[m][t][0] + bv.x; zv[t][1] = in_scale * acc[m][t][1] + bv.y;
+            zv[t][2] = in_scale * acc[m][t][2] + bv.z; zv[t][3] = in_scale * acc[m][t][3] + bv.w;
+            ps += (zv[t][0] + zv[t][1]) + (zv[t][2] + zv[t][3]);
+          }
+          ps += __shfl_xor(ps, 16, 64);
+          ps += __shfl_xor(ps, 32, 64);
+          const float mean = ps / 64.f;
+          float pv = 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv += (zv[t][r] - mean) * (zv[t][r] - mean);
+          pv += __shfl_xor(pv, 16, 64);
+          pv += __shfl_xor(pv, 32, 64);
+          const float rstd = rsqrtf(pv / 64.f + 1e-3f);
+          if (j < ws_) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const int co = t * 16 + (lane >> 4) * 4;
+              const float4 gm = *reinterpret_cast<const float4*>(ln.gamma + co);
+              const float4 bt = *reinterpret_cast<const float4*>(ln.beta + co);
+              const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+              float o[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float y = (zv[t][r] - mean) * rstd * gmv[r] + btv[r];
+                // (hardware exponential: within 1e-7 absolute of expm1f, a tenth of its instructions)
+                o[r] = y > 0.f ? y : __builtin_amdgcn_exp2f(y * 1.44269504088896341f) - 1.f;
+              }
+              *reinterpret_cast<float4*>(small + (prow + j) * Cs + co) = make_float4(zv[t][0], zv[t][1], zv[t][2], zv[t][3]);
+              *reinterpret_cast<float4*>(ln.out + (prow + j) * Cs + co) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            if ((lane >> 4) == 0) *reinterpret_cast<float2*>(ln.stats + (prow + j) * 2) = make_float2(mean, rstd);
+          }
+        }
+      }
+    } else
     if (i < hs && !IMG_DBG(4)) {
       float* dst = small + ((img * hs + i) * (long)ws_) * Cs;
 #pragma unroll
@@ -499,7 +557,8 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
 // Returns 1 when the geometry is not covered (the caller then takes the generic path).
 int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const float* bias, float* small,
                        int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, float in_scale,
-                       float* wsp, size_t ws_bytes, hipStream_t st) {
+                       float* wsp, size_t ws_bytes, hipStream_t st, const float* ln_gamma, const float* ln_beta,
+                       float* ln_out, float* ln_stats) {
   const int OPK = (k * Cb + 7) / 8, KS = (k * OPK + 3) / 4, NT = Cs / 16;
   const int epv = big_is_u8 ? 16 : 4, rowlen = wb * Cb;
   if (Cb < 1 || Cb > 4 || Cs != 64 || k < 2 || k + 2 * (DI - 1) > 12 || rowlen + 8 > 264) return 1;
@@ -523,15 +582,18 @@ int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const flo
 #else
   const int dbg = 0;
 #endif
+  const DownLn ln{ln_gamma, ln_beta, ln_out, ln_stats};
+  if (ln_out && ((((uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)ln_out) & 15) || ((uintptr_t)ln_stats & 7))) return 1;
+#define LDX(KS_, T_, L_) k_conv_image_down<KS_, 4, T_, L_><<<grid, 256, 0, st>>>(                     \
+        (const T_*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles, dbg, ln)
 #define LD(KS_)                                                                                        \
   if (KS == KS_) {                                                                                     \
-    if (big_is_u8) k_conv_image_down<KS_, 4, unsigned char><<<grid, 256, 0, st>>>(                     \
-        (const unsigned char*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles, dbg); \
-    else k_conv_image_down<KS_, 4, float><<<grid, 256, 0, st>>>(                                       \
-        (const float*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles, dbg); \
+    if (big_is_u8) { if (ln_out) LDX(KS_, unsigned char, true); else LDX(KS_, unsigned char, false); } \
+    else { if (ln_out) LDX(KS_, float, true); else LDX(KS_, float, false); }                           \
   }
   LD(2) LD(3) LD(5)
 #undef LD
+#undef LDX
   DD_CHECK_LAUNCH("dd_conv2d_s2_down(image)");
   return 0;
 }

@@ -35,6 +35,7 @@ _SIGS = {
     'dd_conv2d_s2_down': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
     'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
+    'dd_conv2d_s2_down_ln': [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad_ln': [c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_same': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_z, c_p],
     'dd_conv2d_same_bwd_data': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
@@ -371,6 +372,26 @@ class HipOps:
         big.data_ptr(), int(big.dtype == torch.uint8), small.data_ptr(),
         dw.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale, beta,
         self.ws.data_ptr(), self.ws_bytes, self.stream)), 'dd_conv2d_s2_wgrad')
+
+  def conv_down_ln(self, big, w, bias, gamma, beta_ln, z, out, stats, k, in_scale=1.0):
+    """conv_down + ln_act_fwd (LayerNorm + ELU) of an image-side layer as one pass where the
+    geometry is covered (dd_conv2d_s2_down_ln), else the two launches: writes z (pre-norm), out
+    and stats [pixels, 2] either way."""
+    n, hb, wb, cb = big.shape
+    n2, hs, ws, cs = z.shape
+    assert n == n2 and big.is_contiguous() and z.is_contiguous() and out.is_contiguous() and stats.is_contiguous()
+    assert tuple(w.shape) == (k, k, cb, cs) and w.is_contiguous() and tuple(out.shape) == tuple(z.shape)
+    fl = 2.0 * n * hs * ws * k * k * cb * cs
+    rc = self._traced(f'conv_down n{n} {hb}x{cb}->{hs}x{cs} k{k} B{big.numel() * big.element_size() + 4 * (2 * z.numel() + w.numel())}', fl, lambda: self.lib.dd_conv2d_s2_down_ln(
+        big.data_ptr(), int(big.dtype == torch.uint8), w.data_ptr(), _ptr(bias), gamma.data_ptr(), beta_ln.data_ptr(),
+        z.data_ptr(), out.data_ptr(), stats.data_ptr(), n, hb, wb, cb, hs, ws, cs, k, in_scale,
+        self.ws.data_ptr(), self.ws_bytes, self.stream))
+    if rc == 1:   # geometry not covered
+      if self.trace:
+        self.trace.pop()
+      self.conv_down(big, w, bias, z, k, in_scale)
+      return self.ln_act_fwd(z.view(-1, cs), gamma, beta_ln, out.view(-1, cs), stats, True)
+    self._check(rc, 'dd_conv2d_s2_down_ln')
 
   def conv_wgrad_ln(self, big, dout, z, stats, gamma, beta_ln, dz, dw, dgamma, dbeta, dbias, k, in_scale=1.0):
     """Filter gradient of an image-side Conv2D + LayerNorm + ELU layer from the gradient at the

@@ -921,9 +921,16 @@ class Learner:
       assert rows is None
       self.encoder_res_fwd()
     for i, (cl, a) in enumerate(zip(s.enc_convs, self.enc_act)):
+      C, px = cl.c_small, cl.h_small * cl.h_small
+      if i == 0 and self._fuse_img_ln and hasattr(ops, 'conv_down_ln'):
+        # image-side layer: LayerNorm + ELU in the convolution's epilogue where the kernel covers it
+        ops.conv_down_ln(x, m.p[f'{cl.name}/kernel'], m.p[f'{cl.name}/bias'], m.p[f'{cl.name}/norm/scale'],
+                         m.p[f'{cl.name}/norm/bias'], R(a['z']), R(a['out']), a['stats'][r0 * px:r1 * px],
+                         cl.k, 1.0 / 255.0)
+        x = R(a['out'])
+        continue
       ops.conv_down(x, m.p[f'{cl.name}/kernel'], m.p[f'{cl.name}/bias'], R(a['z']),
                     cl.k, 1.0 / 255.0 if i == 0 else 1.0)
-      C, px = cl.c_small, cl.h_small * cl.h_small
       ops.ln_act_fwd(R(a['z']).view(-1, C), m.p[f'{cl.name}/norm/scale'],
                      m.p[f'{cl.name}/norm/bias'], R(a['out']).view(-1, C),
                      a['stats'][r0 * px:r1 * px], True)

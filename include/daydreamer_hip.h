@@ -34,7 +34,8 @@ extern "C" {
  * 7 (round 5): dd_video_grid added.  8: dd_reduce_stats_multi added.
  * 9: dd_imagine_rollout_oh_fwd added; dd_imagine_rollout_supported answers discrete = 1 shapes.
  * 10: dd_ln_act_fwd_head / dd_ln_act_bwd_head added.
- * 11 (round 6): dd_gemm_f32_x, dd_imag_set_rows, dd_conv2d_s2_wgrad_ln added. */
+ * 11 (round 6): dd_gemm_f32_x, dd_imag_set_rows, dd_conv2d_s2_wgrad_ln,
+ * dd_conv2d_s2_down_ln added. */
 #define DD_ABI_VERSION 11
 int dd_version(void);
 const char* dd_last_error(void);
@@ -115,6 +116,16 @@ int dd_conv2d_s2_wgrad(const void* big, int big_is_u8, const float* small, float
                        int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k,
                        float in_scale, float beta, float* ws, size_t ws_bytes, void* stream);
 
+/* dd_conv2d_s2_down of an image-side layer (big has <= 4 channels, Cs = 64) followed by its
+ * LayerNorm + ELU (the encoder's first layer, nets.py:291-305, Norm :585-602) in one pass: a
+ * pixel's 64 channels are in registers when the contraction ends, so `small` (pre-norm), `out`
+ * (activations) and stats [pixels, 2] = mean / rstd are written without a second pass over
+ * `small` - the results of dd_conv2d_s2_down + dd_ln_act_fwd.  Returns 1 with nothing computed
+ * when the geometry is not covered. */
+int dd_conv2d_s2_down_ln(const void* big, int big_is_u8, const float* w, const float* bias,
+                         const float* gamma, const float* beta_ln, float* small, float* out, float* stats,
+                         int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, float in_scale,
+                         float* ws, size_t ws_bytes, void* stream);
 /* dd_conv2d_s2_wgrad for an image-side layer (big has 3 channels) whose small side is a Conv2D +
  * LayerNorm + ELU (the encoder's first layer, nets.py:291-305, Norm :585-602): `dout` is the
  * gradient at the layer OUTPUT [n, hs, ws, Cs]; dd_ln_act_bwd's arithmetic (activation recomputed

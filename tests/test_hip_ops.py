@@ -305,6 +305,32 @@ def test_conv_wgrad(hip, ref, n, hb, Cb, hs, Cs, k, u8):
     close(g, c, what=f'conv_wgrad beta{beta}')
 
 
+@pytest.mark.parametrize('n,hb,Cb,hs,k,u8', [(3, 64, 3, 31, 4, True), (5, 64, 3, 30, 6, False), (130, 32, 4, 15, 4, True),
+                                             (2, 64, 1, 31, 4, False), (2, 128, 6, 63, 4, True)])
+def test_conv_down_with_layernorm(hip, ref, n, hb, Cb, hs, k, u8):
+  """dd_conv2d_s2_down_ln: image-side convolution + LayerNorm + ELU in one pass (the epilogue of
+  k_conv_image_down) against conv_down + ln_act_fwd of the CPU restatement: pre-norm rows,
+  activations, statistics.  The last geometry (6 channels) takes the wrapper's two-launch path."""
+  Cs = 64
+  if u8:
+    big = torch.randint(0, 256, (n, hb, hb, Cb), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+  else:
+    big = rnd(n, hb, hb, Cb, seed=1)
+  w, bias = rnd(k, k, Cb, Cs, seed=2, scale=0.1), rnd(Cs, seed=3)
+  gamma, beta = 1.0 + 0.1 * rnd(Cs, seed=4), 0.1 * rnd(Cs, seed=5)
+  scale = 1.0 / 255.0 if u8 else 1.0
+  z_c, out_c, st_c = torch.zeros(n, hs, hs, Cs), torch.zeros(n, hs, hs, Cs), torch.zeros(n * hs * hs, 2)
+  ref.conv_down(big, w, bias, z_c, k, scale)
+  ref.ln_act_fwd(z_c.view(-1, Cs), gamma, beta, out_c.view(-1, Cs), st_c, True)
+  z_g, out_g, st_g = (torch.full(t.shape, 7.0).cuda() for t in (z_c, out_c, st_c))
+  hip.conv_down_ln(big.cuda(), w.cuda(), bias.cuda(), gamma.cuda(), beta.cuda(), z_g, out_g, st_g, k, scale)
+  torch.cuda.synchronize()
+  close(z_g, z_c, what='pre-norm rows')
+  close(out_g, out_c, rtol=2e-4, what='activations')
+  close(st_g[:, 0], st_c[:, 0], rtol=2e-4, what='mean')
+  close(st_g[:, 1], st_c[:, 1], rtol=2e-4, what='rstd')
+
+
 @pytest.mark.parametrize('n,hb,hs,k,u8', [(3, 64, 31, 4, True), (5, 64, 30, 6, False), (130, 32, 15, 4, True),
                                           (2, 64, 31, 4, False), (2, 20, 8, 6, True)])
 def test_conv_wgrad_with_layernorm_backward(hip, ref, n, hb, hs, k, u8):

@@ -33,3 +33,13 @@ def two():
 c = timeit(two)
 d = timeit(lambda: ops.conv_wgrad_ln(img, s31, z, stats, gamma, beta, dzb, dw4, dg, db, dbias, 4, 1.0 / 255.0))
 print(f'encoder layer 1 backward: ln_act_bwd + conv_wgrad {c*1e3:.1f} us   fused {d*1e3:.1f} us')
+# ---- encoder first layer forward: conv_down + ln_act_fwd vs the fused pass
+w4 = torch.randn(4, 4, 3, 64, device='cuda') * 0.1
+b4 = torch.zeros(64, device='cuda')
+zf, of = torch.empty_like(z), torch.empty_like(z)
+def two_f():
+  ops.conv_down(img, w4, b4, zf, 4, 1.0 / 255.0)
+  ops.ln_act_fwd(zf.view(-1, 64), gamma, beta, of.view(-1, 64), stats, True)
+e = timeit(two_f)
+f = timeit(lambda: ops.conv_down_ln(img, w4, b4, gamma, beta, zf, of, stats, 4, 1.0 / 255.0))
+print(f'encoder layer 1 forward: conv_down + ln_act_fwd {e*1e3:.1f} us   fused {f*1e3:.1f} us')
