@@ -5,7 +5,9 @@
 int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const float* bias, float* small,
                        int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, float in_scale,
                        float* wsp, size_t ws_bytes, hipStream_t st, const float* ln_gamma, const float* ln_beta,
-                       float* ln_out, float* ln_stats);
+                       float* ln_out, float* ln_stats, const float* ln_z, int* n_partials);
+int dd_ln_partials_reduce(const float* partials, int rows, int C, float* dgamma, float* dbeta, float* dbias,
+                          float b, hipStream_t st);                      // rowops.hip
 
 extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w, const float* bias,
                                  float* small, int n_img, int hb, int wb, int Cb,
@@ -16,7 +18,7 @@ extern "C" int dd_conv2d_s2_down(const void* big, int big_is_u8, const float* w,
   static const int image_kernel = getenv("DD_DOWN_IMAGE") ? atoi(getenv("DD_DOWN_IMAGE")) : 1;
   if (image_kernel && Cb <= 4 && gemm_mode() == 6) {
     const int rc = dd_conv_image_down(big, big_is_u8, w, bias, small, n_img, hb, wb, Cb, hs, ws_, Cs, k, in_scale, wsp, ws_bytes, st,
-                                      nullptr, nullptr, nullptr, nullptr);
+                                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc != 1) return rc;   // (1: geometry not covered)
   }
   const int M = n_img * hs * ws_, N = Cs, K = k * k * Cb;
@@ -59,5 +61,30 @@ extern "C" int dd_conv2d_s2_down_ln(const void* big, int big_is_u8, const float*
       2 * (hs - 1) + k > hb || 2 * (ws_ - 1) + k > wb)
     return 1;
   return dd_conv_image_down(big, big_is_u8, w, bias, small, n_img, hb, wb, Cb, hs, ws_, Cs, k, in_scale, wsp, ws_bytes,
-                            (hipStream_t)stream, gamma, beta_ln, out, stats);
+                            (hipStream_t)stream, gamma, beta_ln, out, stats, nullptr, nullptr);
+}
+
+// dd_conv2d_s2_down as the DATA GRADIENT of an image-side transposed convolution (the decoder's
+// image layer, nets.py:308-327: big = d loss / d image, float) followed by the LayerNorm + ELU
+// backward of the layer in front of it (Conv2D transpose + Norm + ELU): the gradient at that
+// layer's output exists only in the accumulators; `dz` receives d loss / d (its pre-norm rows),
+// and dgamma / dbeta / dbias what dd_ln_act_bwd would produce (accumulated when `accumulate`).
+// Returns 1 with nothing computed when the geometry is not covered.
+extern "C" int dd_conv2d_s2_down_lnbwd(const float* big, const float* w, const float* z, const float* stats,
+                                       const float* gamma, const float* beta_ln, float* dz, float* dgamma,
+                                       float* dbeta, float* dbias, int accumulate, int n_img, int hb, int wb,
+                                       int Cb, int hs, int ws_, int Cs, int k, float* wsp, size_t ws_bytes,
+                                       void* stream) {
+  if (gemm_mode() != 6 || Cb > 4 || Cs != 64 || !z || !stats || !gamma || !beta_ln || !dz || !dgamma || !dbeta ||
+      !dbias || 2 * (hs - 1) + k > hb || 2 * (ws_ - 1) + k > wb)
+    return 1;
+  hipStream_t st = (hipStream_t)stream;
+  int n_partials = 0;
+  const int rc = dd_conv_image_down(big, 0, w, nullptr, dz, n_img, hb, wb, Cb, hs, ws_, Cs, k, 1.f, wsp, ws_bytes, st,
+                                    gamma, beta_ln, nullptr, const_cast<float*>(stats), z, &n_partials);
+  if (rc != 0) return rc;
+  const int OPK = (k * Cb + 7) / 8, KS = (k * OPK + 3) / 4;
+  const size_t pbytes = ((size_t)(Cs / 16) * KS * 3 * 1024 + 255) & ~(size_t)255;
+  return dd_ln_partials_reduce(reinterpret_cast<const float*>(reinterpret_cast<const char*>(wsp) + pbytes), n_partials,
+                               Cs, dgamma, dbeta, dbias, accumulate ? 1.f : 0.f, st);
 }

@@ -356,15 +356,27 @@ __global__ void k_conv_image_down_wprep(const float* __restrict__ w, int k, int 
 // channels sit in the 16 accumulator registers of four lanes (lane, lane ^ 16, lane ^ 32, lane ^ 48),
 // so its statistics are two shuffles; writes the pre-norm rows (small), the activations (ln.out)
 // and [pixels, 2] mean / rstd - what dd_ln_act_fwd would from a second pass over `small`.
+// LNB (EPI = 2): the contraction's result is the gradient at the OUTPUT of the small-side layer's
+// LayerNorm + ELU (the decoder's last hidden layer behind the image layer, nets.py:308-327): its
+// backward (k_ln_act_bwd_v's expressions, activation recomputed from z) runs in the epilogue, `small`
+// receives dz, and the LayerNorm scale / offset and bias gradients leave as one partial row [3][64]
+// per workgroup - the gradient at the layer output is never written to or read from HBM.
 struct DownLn {
   const float* gamma; const float* beta; float* out; float* stats;
+  const float* z; float* partials;
 };
 
-template <int KS, int NT, typename TB, bool LNF>
+template <int KS, int NT, typename TB, int EPI>
 __global__ void __launch_bounds__(256, 2)
 k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, const float* __restrict__ bias,
                   float* __restrict__ small, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, int OPK,
                   float in_scale, int tiles_j, int tiles_i, int n_tiles, int dbg, DownLn ln) {
+  constexpr bool LNF = EPI == 1, LNB = EPI == 2;
+  [[maybe_unused]] float pgs[LNB ? 16 : 1], pbs[LNB ? 16 : 1], pzs[LNB ? 16 : 1];
+  if constexpr (LNB) {
+#pragma unroll
+    for (int q_ = 0; q_ < 16; ++q_) pgs[q_] = pbs[q_] = pzs[q_] = 0.f;
+  }
   constexpr int EPV = sizeof(TB) == 1 ? 16 : 4;        // elements per 16-byte vector
   constexpr int RMAX = 12, RSMAX = 264;                // staged rows (k + 6 <= 12), row stride (elements, wb*Cb + 8 <= 264): 19 KB
   __shared__ __attribute__((aligned(16))) unsigned short patch[3][RMAX * RSMAX];
@@ -482,6 +494,58 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
       }
     }
     // ---- epilogue: elements (rows (lane >> 4) * 4 + r = channels, column lane & 15 = output column) of tile (m, t)
+    if constexpr (LNB) {
+      static_assert(!LNB || NT == 4, "LayerNorm epilogue: 64 channels");
+      if (i < hs) {
+        const long prow = (img * hs + i) * (long)ws_;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int j = tj * DJ + m * 16 + (lane & 15);
+          const bool live = j < ws_;
+          const long pr = prow + min(j, ws_ - 1);
+          const float2 ms = *reinterpret_cast<const float2*>(ln.stats + pr * 2);
+          const float mean = ms.x, rstd = ms.y;
+          float xh[NT][4], g[NT][4], dy[NT][4];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int co = t * 16 + (lane >> 4) * 4;
+            const float4 zz = *reinterpret_cast<const float4*>(ln.z + pr * Cs + co);
+            const float4 gm = *reinterpret_cast<const float4*>(ln.gamma + co);
+            const float4 bt = *reinterpret_cast<const float4*>(ln.beta + co);
+            const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+            const float btv[4] = {bt.x, bt.y, bt.z, bt.w}, bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = live ? in_scale * acc[m][t][r] + bvv[r] : 0.f;
+              xh[t][r] = (zv[r] - mean) * rstd;
+              const float y = xh[t][r] * gmv[r] + btv[r];
+              dy[t][r] = d * (y > 0.f ? 1.f : __builtin_amdgcn_exp2f(y * 1.44269504088896341f));
+              g[t][r] = dy[t][r] * gmv[r];
+              s1 += g[t][r];
+              s2 += g[t][r] * xh[t][r];
+            }
+          }
+          s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+          s1 /= 64.f; s2 /= 64.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int co = t * 16 + (lane >> 4) * 4;
+            float dz[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              dz[r] = rstd * (g[t][r] - s1 - xh[t][r] * s2);
+              pgs[t * 4 + r] += dy[t][r] * xh[t][r];
+              pbs[t * 4 + r] += dy[t][r];
+              pzs[t * 4 + r] += live ? dz[r] : 0.f;
+            }
+            if (live) *reinterpret_cast<float4*>(small + (prow + j) * Cs + co) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+          }
+        }
+      }
+    } else
     if constexpr (LNF) {
       static_assert(!LNF || NT == 4, "LayerNorm epilogue: 64 channels");
       if (i < hs) {
@@ -550,6 +614,27 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
     }
     __syncthreads();     // the patch is free for the next tile
   }
+  if constexpr (LNB) {
+    // lanes with equal lane >> 4 hold the sums of the same 16 channels (t * 16 + (lane >> 4) * 4 + r)
+    // over their pixels: add the 16 lanes, then the four waves through LDS -> [3][64] per workgroup
+    float* red = reinterpret_cast<float*>(&patch[0][0]);       // [4 waves][3][64]
+#pragma unroll
+    for (int q_ = 0; q_ < 16; ++q_) {
+#pragma unroll
+      for (int o_ = 1; o_ < 16; o_ <<= 1) {
+        pgs[q_] += __shfl_xor(pgs[q_], o_, 64); pbs[q_] += __shfl_xor(pbs[q_], o_, 64); pzs[q_] += __shfl_xor(pzs[q_], o_, 64);
+      }
+    }
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int q_ = 0; q_ < 16; ++q_) {
+        const int co = (q_ >> 2) * 16 + (lane >> 4) * 4 + (q_ & 3);
+        red[wave * 192 + co] = pgs[q_]; red[wave * 192 + 64 + co] = pbs[q_]; red[wave * 192 + 128 + co] = pzs[q_];
+      }
+    }
+    __syncthreads();
+    if (tid < 192) ln.partials[(long)blockIdx.x * 192 + tid] = (red[tid] + red[192 + tid]) + (red[384 + tid] + red[576 + tid]);
+  }
 }
 
 }  // namespace
@@ -558,7 +643,7 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
 int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const float* bias, float* small,
                        int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, float in_scale,
                        float* wsp, size_t ws_bytes, hipStream_t st, const float* ln_gamma, const float* ln_beta,
-                       float* ln_out, float* ln_stats) {
+                       float* ln_out, float* ln_stats, const float* ln_z, int* n_partials) {
   const int OPK = (k * Cb + 7) / 8, KS = (k * OPK + 3) / 4, NT = Cs / 16;
   const int epv = big_is_u8 ? 16 : 4, rowlen = wb * Cb;
   if (Cb < 1 || Cb > 4 || Cs != 64 || k < 2 || k + 2 * (DI - 1) > 12 || rowlen + 8 > 264) return 1;
@@ -582,14 +667,19 @@ int dd_conv_image_down(const void* big, int big_is_u8, const float* w, const flo
 #else
   const int dbg = 0;
 #endif
-  const DownLn ln{ln_gamma, ln_beta, ln_out, ln_stats};
-  if (ln_out && ((((uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)ln_out) & 15) || ((uintptr_t)ln_stats & 7))) return 1;
+  // (LayerNorm backward: the partial rows [grid][3][64] follow the weight planes in the workspace)
+  float* partials = reinterpret_cast<float*>(planes + ((pbytes + 255) & ~(size_t)255));
+  if (ln_z && ws_bytes < ((pbytes + 255) & ~(size_t)255) + (size_t)grid * 192 * sizeof(float)) return 1;
+  const DownLn ln{ln_gamma, ln_beta, ln_out, ln_stats, ln_z, partials};
+  if ((ln_out || ln_z) && ((((uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)ln_out | (uintptr_t)ln_z) & 15) || ((uintptr_t)ln_stats & 7))) return 1;
+  const int epi = ln_z ? 2 : (ln_out ? 1 : 0);
+  if (n_partials) *n_partials = grid;
 #define LDX(KS_, T_, L_) k_conv_image_down<KS_, 4, T_, L_><<<grid, 256, 0, st>>>(                     \
         (const T_*)big, planes, bias, small, hb, wb, Cb, hs, ws_, Cs, k, OPK, in_scale, tj, ti, n_tiles, dbg, ln)
 #define LD(KS_)                                                                                        \
   if (KS == KS_) {                                                                                     \
-    if (big_is_u8) { if (ln_out) LDX(KS_, unsigned char, true); else LDX(KS_, unsigned char, false); } \
-    else { if (ln_out) LDX(KS_, float, true); else LDX(KS_, float, false); }                           \
+    if (big_is_u8) { if (epi == 1) LDX(KS_, unsigned char, 1); else if (epi == 0) LDX(KS_, unsigned char, 0); else return 1; } \
+    else { if (epi == 2) LDX(KS_, float, 2); else if (epi == 1) LDX(KS_, float, 1); else LDX(KS_, float, 0); } \
   }
   LD(2) LD(3) LD(5)
 #undef LD

@@ -446,6 +446,21 @@ extern "C" int dd_philox(float* out, long outer, long inner, int cols, long inne
   return 0;
 }
 
+namespace {
+// slot: [0] = number of stamps so far, [1 + i % 8] = the i-th stamp (a ring of the last eight)
+__global__ void k_stamp(unsigned long long* slot) {
+  const unsigned long long i = slot[0];
+  slot[1 + (i & 7)] = wall_clock64();
+  slot[0] = i + 1;
+}
+}
+// measurement aid (tools/phase_timeline.py): the 100 MHz wall clock at this point of the stream
+extern "C" int dd_stamp(unsigned long long* slot, void* stream) {
+  k_stamp<<<1, 1, 0, (hipStream_t)stream>>>(slot);
+  DD_CHECK_LAUNCH("dd_stamp");
+  return 0;
+}
+
 extern "C" int dd_counter_add(unsigned long long* counter, unsigned long long v, void* stream) {
   k_counter_add<<<1, 1, 0, (hipStream_t)stream>>>(counter, v);
   DD_CHECK_LAUNCH("dd_counter_add");

@@ -36,6 +36,7 @@ _SIGS = {
     'dd_conv2d_s2_up': [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad': [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
     'dd_conv2d_s2_down_ln': [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_z, c_p],
+    'dd_conv2d_s2_down_lnbwd': [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_s2_wgrad_ln': [c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_z, c_p],
     'dd_conv2d_same': [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_z, c_p],
     'dd_conv2d_same_bwd_data': [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_z, c_p],
@@ -80,6 +81,7 @@ _SIGS = {
     'dd_onehot_policy_grad': [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p],
     'dd_philox': [c_p, c_l, c_l, c_i, c_l, c_l, c_ull, c_p, c_u, c_i, c_p],
     'dd_counter_add': [c_p, c_ull, c_p],
+    'dd_stamp': [c_p, c_p],
     'dd_reduce_stats_multi': [c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'dd_reduce_stats': [c_p, c_l, c_l, c_p, c_p, c_p],
     'dd_autoadapt_update': [c_p, c_p, c_i, c_d, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_p],
@@ -393,6 +395,28 @@ class HipOps:
       return self.ln_act_fwd(z.view(-1, cs), gamma, beta_ln, out.view(-1, cs), stats, True)
     self._check(rc, 'dd_conv2d_s2_down_ln')
 
+  def conv_down_lnbwd(self, big, w, z, stats, gamma, beta_ln, dout, dz, dgamma, dbeta, dbias, k):
+    """Data gradient of an image-side transposed convolution (big = gradient of the image, float)
+    followed by the LayerNorm + ELU backward of the layer in front of it, as one pass where the
+    geometry is covered (dd_conv2d_s2_down_lnbwd: `dout` stays untouched), else conv_down into
+    `dout` + ln_act_bwd.  Writes dz, dgamma, dbeta, dbias either way."""
+    n, hb, wb, cb = big.shape
+    n2, hs, ws, cs = dz.shape
+    assert n == n2 and big.is_contiguous() and dz.is_contiguous() and z.is_contiguous() and stats.is_contiguous()
+    assert tuple(w.shape) == (k, k, cb, cs) and w.is_contiguous() and big.dtype == torch.float32
+    fl = 2.0 * n * hs * ws * k * k * cb * cs
+    rc = self._traced(f'conv_down n{n} {hb}x{cb}->{hs}x{cs} k{k} B{4 * (big.numel() + 2 * dz.numel() + w.numel())}', fl, lambda: self.lib.dd_conv2d_s2_down_lnbwd(
+        big.data_ptr(), w.data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta_ln.data_ptr(),
+        dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(), 0, n, hb, wb, cb, hs, ws, cs, k,
+        self.ws.data_ptr(), self.ws_bytes, self.stream))
+    if rc == 1:   # geometry not covered
+      if self.trace:
+        self.trace.pop()
+      self.conv_down(big, w, None, dout, k)
+      return self.ln_act_bwd(dout.view(-1, cs), z.view(-1, cs), None, stats, gamma, dz.view(-1, cs), dgamma, dbeta,
+                             False, True, dbias, beta=beta_ln)
+    self._check(rc, 'dd_conv2d_s2_down_lnbwd')
+
   def conv_wgrad_ln(self, big, dout, z, stats, gamma, beta_ln, dz, dw, dgamma, dbeta, dbias, k, in_scale=1.0):
     """Filter gradient of an image-side Conv2D + LayerNorm + ELU layer from the gradient at the
     layer OUTPUT: ln_act_bwd (activation recomputed from z) + conv_wgrad as one pass where the
@@ -611,6 +635,11 @@ class HipOps:
   def imagine_rollout_supported(self, D, U, G, C, A, actor_units, actor_layers, prior_layers, discrete):
     return bool(self.lib.dd_imagine_rollout_supported(D, U, G, C, A, actor_units, actor_layers,
                                                       prior_layers, int(bool(discrete))))
+
+  def stamp(self, buf, slot):
+    """buf[9 * slot] counts, buf[9 * slot + 1 + i % 8] (int64 device tensor) = the device wall clock
+    (100 MHz) when the stream got here the i-th time."""
+    self._check(self.lib.dd_stamp(buf.data_ptr() + 8 * 9 * slot, self.stream), 'dd_stamp')
 
   def imag_set_rows(self, rows):
     """Rows of the imagination batch per workgroup of the fused forward rollout (process-wide):

@@ -468,6 +468,8 @@ class Learner:
                        self.ops.imagine_rollout_supported(D, U, G, self.C, A, ca['units'], ca['layers'],
                                                           self.n_prior, self.discrete))
     self._pipelined_capture = False   # set while capture_pipeline records the phase plans
+    self.stamps = (torch.zeros(16 * 9, dtype=torch.int64, device=self.device)
+                   if os.environ.get('DD_STAMPS') == '1' and hasattr(self.ops, 'stamp') else None)
     self._fuse_img_ln = bool(self.cfg.get('hip', {}).get('fuse_image_ln', True)) and self.dtype == torch.float32
     # (the one-hot kernel takes the row width as an argument and keeps the padded rows)
     self.TW = F + A if (self.fused_imag and not self.discrete) else (F + A + 3) // 4 * 4
@@ -1054,10 +1056,13 @@ class Learner:
     if s.dec_res:
       self.decoder_res_bwd(feat, dfeat, beta)
     elif s.dec_convs:
+      fused_ln = None     # the layer whose LayerNorm backward ran in the epilogue of the data gradient behind it
       for i in reversed(range(len(s.dec_convs))):
         cl, a = s.dec_convs[i], self.dec_act[i]
         C = cl.c_big
-        if cl.norm:
+        if cl.norm and fused_ln == i:
+          pass
+        elif cl.norm:
           ops.ln_act_bwd(a['dout'].view(-1, C), a['z'].view(-1, C),
                          a['out'].view(-1, C), a['stats'],
                          m.p[f'{cl.name}/norm/scale'], a['dz'].view(-1, C),
@@ -1070,8 +1075,18 @@ class Learner:
           prev = self.dec_act[i - 1]
           run(lambda o, a=a, prev=prev, cl=cl: o.conv_wgrad(
               a['dz'], prev['out'], m.g[f'{cl.name}/kernel'], cl.k))
-          ops.conv_down(a['dz'], m.p[f'{cl.name}/kernel'], None, prev['dout'],
-                        cl.k)
+          pl = s.dec_convs[i - 1]
+          if (not cl.norm and pl.norm and cl.c_big <= 4 and self._fuse_img_ln and
+              hasattr(ops, 'conv_down_lnbwd')):
+            # image layer: its data gradient + the LayerNorm backward of the layer in front of it
+            ops.conv_down_lnbwd(a['dz'], m.p[f'{cl.name}/kernel'], prev['z'], prev['stats'],
+                                m.p[f'{pl.name}/norm/scale'], m.p[f'{pl.name}/norm/bias'], prev['dout'],
+                                prev['dz'], m.g[f'{pl.name}/norm/scale'], m.g[f'{pl.name}/norm/bias'],
+                                m.g[f'{pl.name}/bias'], cl.k)
+            fused_ln = i - 1
+          else:
+            ops.conv_down(a['dz'], m.p[f'{cl.name}/kernel'], None, prev['dout'],
+                          cl.k)
         else:
           kk = cl.k * cl.k
           dzv = a['dz'].view(N, -1)
@@ -1537,6 +1552,7 @@ class Learner:
     ops.copy2d(post[:, self.T - 1], b['carry'])
     ops.copy2d(b['post'], b['traj'][0][:, :self.F])
     ops.copy2d(b['cont'].view(1, -1), b['cont_b'].view(1, -1))
+    self._stamp(3)
 
   def imagine_rollout(self, on_state=None):
     """WorldModel.imagine (reference agent.py:234-254): H img_steps from the start states in
@@ -1612,6 +1628,7 @@ class Learner:
     t += [pl['stats'][1], P['img_stats'].bias, self.ai_img_stats.z]
     if getattr(self, 'imag_stamps', None) is not None:   # measurement aid (tools/imag_time.py)
       t.append(self.imag_stamps)
+    self._stamp(5)
     if hasattr(ops, 'imag_set_rows'):
       # rows per workgroup: 32 holds half the CUs for 1.23 x the time - it pays where another
       # stream has work for the freed CUs (the pipelined schedule: -0.4 ms per step at configs[1])
@@ -1621,6 +1638,7 @@ class Learner:
       ops.imag_set_rows(rows)
     ops.imagine_rollout_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'],
                             self.unimix, ca['minstd'], ca['maxstd'], t, t0, t1)
+    self._stamp(6)
 
   def _imagine_rollout_fused_onehot(self, t0=0, t1=None):
     """dd_imagine_rollout_oh_fwd (csrc/imag_oh.hip): the one-hot / REINFORCE rollout at deter =
@@ -2003,11 +2021,20 @@ class Learner:
 
   # --------------------------------------------------------------- train step
 
+  def _stamp(self, slot):
+    """Measurement aid (DD_STAMPS=1, tools/phase_timeline.py): the device clock at this point of
+    the launch sequence, captured with it."""
+    if self.stamps is not None:
+      self.ops.stamp(self.stamps, slot)
+
   def phase_a1(self, use_carry=True):
     """World-model phase up to the gradients."""
+    self._stamp(0)
     self.phase_prep()
     self.phase_wm_fwd(use_carry)
+    self._stamp(1)
     self.phase_wm_bwd()
+    self._stamp(2)
 
   def phase_b(self):
     """Behaviour phase: imagination, critic update, slow-critic copy, actor update.
@@ -2016,10 +2043,13 @@ class Learner:
     self.comm = self.comm_b
     self._in_b = True
     try:
+      self._stamp(4)
       self.phase_prep_b()
       self.phase_imagine()
+      self._stamp(7)
       self.plan.cut(self.update_slow)
       self.phase_actor()
+      self._stamp(8)
     finally:
       self.ops = self.ops_a
       self.comm = self.comm_a

@@ -35,7 +35,7 @@ extern "C" {
  * 9: dd_imagine_rollout_oh_fwd added; dd_imagine_rollout_supported answers discrete = 1 shapes.
  * 10: dd_ln_act_fwd_head / dd_ln_act_bwd_head added.
  * 11 (round 6): dd_gemm_f32_x, dd_imag_set_rows, dd_conv2d_s2_wgrad_ln,
- * dd_conv2d_s2_down_ln added. */
+ * dd_conv2d_s2_down_ln, dd_conv2d_s2_down_lnbwd, dd_stamp added. */
 #define DD_ABI_VERSION 11
 int dd_version(void);
 const char* dd_last_error(void);
@@ -126,6 +126,16 @@ int dd_conv2d_s2_down_ln(const void* big, int big_is_u8, const float* w, const f
                          const float* gamma, const float* beta_ln, float* small, float* out, float* stats,
                          int n_img, int hb, int wb, int Cb, int hs, int ws_, int Cs, int k, float in_scale,
                          float* ws, size_t ws_bytes, void* stream);
+/* dd_conv2d_s2_down as the data gradient of the decoder's image layer (big = d loss / d image,
+ * float, <= 4 channels; Cs = 64) followed by the LayerNorm + ELU backward of the layer in front of
+ * it (nets.py:308-327, Norm :585-602): the gradient at that layer's OUTPUT exists only in the
+ * accumulators; dz = d loss / d (its pre-norm rows) and dgamma / dbeta / dbias are what
+ * dd_conv2d_s2_down + dd_ln_act_bwd (activation recomputed from z) produce.  Returns 1 with nothing
+ * computed when the geometry is not covered. */
+int dd_conv2d_s2_down_lnbwd(const float* big, const float* w, const float* z, const float* stats,
+                            const float* gamma, const float* beta_ln, float* dz, float* dgamma,
+                            float* dbeta, float* dbias, int accumulate, int n_img, int hb, int wb, int Cb,
+                            int hs, int ws_, int Cs, int k, float* ws, size_t ws_bytes, void* stream);
 /* dd_conv2d_s2_wgrad for an image-side layer (big has 3 channels) whose small side is a Conv2D +
  * LayerNorm + ELU (the encoder's first layer, nets.py:291-305, Norm :585-602): `dout` is the
  * gradient at the layer OUTPUT [n, hs, ws, Cs]; dd_ln_act_bwd's arithmetic (activation recomputed
@@ -411,6 +421,9 @@ int dd_philox(float* out, long outer, long inner, int cols, long inner_global,
               long inner_offset, unsigned long long seed,
               const unsigned long long* step_dev, unsigned site, int kind, void* stream);
 int dd_counter_add(unsigned long long* counter, unsigned long long v, void* stream);
+/* measurement aid: slot[0] counts the stamps, slot[1 + i % 8] = the device's 100 MHz wall clock when
+ * the stream reached this point the i-th time (nine words per slot) */
+int dd_stamp(unsigned long long* slot, void* stream);
 /* sums = {sum, sum sq, sum abs} (fp64), maxs = {max, max(-x), max|x|}. */
 int dd_reduce_stats(const float* x, long n, long stride, double* sums, float* maxs, void* stream);
 /* dd_reduce_stats of `count` <= 16 vectors in one launch (HOST arrays of device pointers / sizes;

@@ -331,6 +331,36 @@ def test_conv_down_with_layernorm(hip, ref, n, hb, Cb, hs, k, u8):
   close(st_g[:, 1], st_c[:, 1], rtol=2e-4, what='rstd')
 
 
+@pytest.mark.parametrize('n,hb,Cb,hs,k', [(3, 64, 3, 30, 6), (130, 32, 4, 15, 4), (2, 64, 1, 31, 4), (600, 16, 3, 6, 6),
+                                          (2, 128, 6, 63, 4)])
+def test_conv_down_with_layernorm_backward(hip, ref, n, hb, Cb, hs, k):
+  """dd_conv2d_s2_down_lnbwd: the data gradient of an image-side transposed convolution with the
+  LayerNorm + ELU backward of the layer in front of it in the epilogue, against conv_down +
+  ln_act_bwd of the CPU restatement: dz, dgamma, dbeta, dbias.  The last geometry (6 channels) takes
+  the wrapper's two-launch path."""
+  Cs = 64
+  big, w = rnd(n, hb, hb, Cb, seed=1), rnd(k, k, Cb, Cs, seed=2, scale=0.1)
+  z = rnd(n, hs, hs, Cs, seed=3)
+  gamma, beta = 1.0 + 0.1 * rnd(Cs, seed=4), 0.1 * rnd(Cs, seed=5)
+  zz = z.view(-1, Cs).double()
+  stats = torch.stack([zz.mean(1), (zz.var(1, unbiased=False) + 1e-3).rsqrt()], 1).float()
+  out = torch.nn.functional.elu((z.view(-1, Cs) - stats[:, :1]) * stats[:, 1:2] * gamma + beta)
+  dout_c, dz_c = torch.zeros(n, hs, hs, Cs), torch.zeros(n, hs, hs, Cs)
+  dg_c, db_c, dbias_c = torch.zeros(Cs), torch.zeros(Cs), torch.zeros(Cs)
+  ref.conv_down(big, w, None, dout_c, k)
+  ref.ln_act_bwd(dout_c.view(-1, Cs), z.view(-1, Cs), out, stats, gamma, dz_c.view(-1, Cs), dg_c, db_c,
+                 False, True, dbias_c, beta=beta)
+  dout_g, dz_g = torch.full((n, hs, hs, Cs), 7.0).cuda(), torch.full((n, hs, hs, Cs), 7.0).cuda()
+  dg_g, db_g, dbias_g = (torch.full((Cs,), 7.0).cuda() for _ in range(3))
+  hip.conv_down_lnbwd(big.cuda(), w.cuda(), z.cuda(), stats.cuda(), gamma.cuda(), beta.cuda(), dout_g, dz_g,
+                      dg_g, db_g, dbias_g, k)
+  torch.cuda.synchronize()
+  close(dz_g, dz_c, what='dz')
+  close(dg_g, dg_c, what='dgamma')
+  close(db_g, db_c, what='dbeta')
+  close(dbias_g, dbias_c, what='dbias')
+
+
 @pytest.mark.parametrize('n,hb,hs,k,u8', [(3, 64, 31, 4, True), (5, 64, 30, 6, False), (130, 32, 15, 4, True),
                                           (2, 64, 31, 4, False), (2, 20, 8, 6, True)])
 def test_conv_wgrad_with_layernorm_backward(hip, ref, n, hb, hs, k, u8):

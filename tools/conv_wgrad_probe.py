@@ -43,3 +43,15 @@ def two_f():
 e = timeit(two_f)
 f = timeit(lambda: ops.conv_down_ln(img, w4, b4, gamma, beta, zf, of, stats, 4, 1.0 / 255.0))
 print(f'encoder layer 1 forward: conv_down + ln_act_fwd {e*1e3:.1f} us   fused {f*1e3:.1f} us')
+# ---- decoder: data gradient of the image layer + LayerNorm backward of the layer in front of it
+z30 = torch.randn(n, 30, 30, 64, device='cuda')
+zz30 = z30.view(-1, 64)
+st30 = torch.stack([zz30.mean(1), (zz30.var(1, unbiased=False) + 1e-3).rsqrt()], 1).contiguous()
+do30, dz30 = torch.empty_like(z30), torch.empty_like(z30)
+w6 = torch.randn(6, 6, 3, 64, device='cuda') * 0.1
+def two_d():
+  ops.conv_down(dz, w6, None, do30, 6)
+  ops.ln_act_bwd(do30.view(-1, 64), zz30, None, st30, gamma, dz30.view(-1, 64), dg, db, False, True, dbias, beta=beta)
+g_ = timeit(two_d)
+h_ = timeit(lambda: ops.conv_down_lnbwd(dz, w6, z30, st30, gamma, beta, do30, dz30, dg, db, dbias, 6))
+print(f'decoder image layer data gradient + LayerNorm backward: two launches {g_*1e3:.1f} us   fused {h_*1e3:.1f} us')
