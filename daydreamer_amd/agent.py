@@ -377,6 +377,8 @@ class Pipeline:
     self.tuned = not tune or os.environ.get('DD_PIPE_TUNE', '1') == '0' or env is not None
     self.k_tune, self.ticks = 0, []
     self.ev_in = torch.cuda.Event()
+    self.stages = [None, None]           # input staging buffers by step parity (Pipeline.stage)
+    self.ev_commit = [torch.cuda.Event(), torch.cuda.Event()]
     self.ev_a = torch.cuda.Event()
     self.ev_b = [torch.cuda.Event(), torch.cuda.Event()]
     live = learner.metric_tensors()
@@ -409,10 +411,24 @@ class Pipeline:
         # cleared here, in stream order, so that the next step's snapshot holds its own errors only
         self.L.scan_sync[1:2].zero_()
 
-  def step(self):
+  def stage(self):
+    """The input staging buffers of the step about to be enqueued (two sets, by step parity), ready
+    to be written on the caller's current stream: that stream waits for the copy that last read
+    them (the commit of the step before the previous one - long done)."""
+    par = self.k & 1
+    if self.stages[par] is None:
+      self.stages[par] = self.L.input_stage()
+    torch.cuda.current_stream(self.device).wait_event(self.ev_commit[par])
+    return self.stages[par]
+
+  def step(self, staged=False):
     """Enqueue one step; returns its metrics as a LazyMetrics.  The previous step's metrics
     are fetched here (after this step's world-model phase has been enqueued), if the caller has
-    not looked at them yet.  The caller's current stream holds the uploaded inputs."""
+    not looked at them yet.  The caller's current stream holds the uploaded inputs: in the
+    learner's input buffers, or (staged) in stage() - then they are copied into the input buffers
+    here, on the world-model stream behind the previous step's optimizer: the upload itself did
+    not have to wait for the previous world-model phase to finish reading them (it used to, and
+    the next world-model phase started ~1 ms after the behaviour phase it runs next to)."""
     cur = torch.cuda.current_stream(self.device)
     if not self.tuned:
       self._tune_step()   # (the stream pair of this step, while the pairs are being measured)
@@ -421,6 +437,10 @@ class Pipeline:
     s1.wait_stream(cur)                    # inputs / carry reset issued by the caller
     if self.k > 0:
       s1.wait_event(self.ev_a)             # (the previous step may have used other streams)
+    if staged:
+      with torch.cuda.stream(s1):
+        self.L.commit_inputs(self.stages[par])
+      self.ev_commit[par].record(s1)
     self.pa1.replay_on(s1)
     self.ev_in.record(s1)
     # A2 = [data-parallel all-reduce of the world-model gradients] + [grad norm, Adam, hand-over].
@@ -444,7 +464,8 @@ class Pipeline:
       tick = torch.cuda.Event(enable_timing=True)
       tick.record(s2)
       self.ticks.append(tick)
-    cur.wait_event(self.ev_in)             # the next upload must not overtake A1's reads
+    if not staged:
+      cur.wait_event(self.ev_in)           # the next upload must not overtake A1's reads
     # this step's handle is in place BEFORE the previous one is resolved: if that raises (a loss
     # of step k - 1 is not finite) the step just enqueued keeps its metrics and the pipeline its
     # bookkeeping - the next call, flush(), save() ... go on from a consistent state
@@ -776,9 +797,6 @@ class Agent:
       # reset_carry reads world-model weights and writes the carried state on this
       # stream: order it after the world-model phase still in flight
       torch.cuda.current_stream(self.device).wait_stream(self._pipe.s1)
-    L.upload(self._shard(data))
-    if not carry:
-      L.reset_carry()
     if self._adaptive:
       if self._touched:
         self._streak_touched, self._streak_clean = self._streak_touched + 1, 0
@@ -789,13 +807,20 @@ class Agent:
         self._prefer_seq = True
       elif self._streak_clean >= self.ADAPT:
         self._prefer_seq = False
-    if self._pipeline and not self._prefer_seq and self._train_calls >= 1 and 'key' not in data:
+    use_pipe = self._pipeline and not self._prefer_seq and self._train_calls >= 1 and 'key' not in data
+    # (pipelined: the minibatch goes into the step's staging buffers - see Pipeline.step)
+    staged = (use_pipe and self._pipe is not None and self.device.type == 'cuda' and
+              os.environ.get('DD_STAGE_INPUTS', '1') == '1')
+    L.upload(self._shard(data), dst=self._pipe.stage() if staged else None)
+    if not carry:
+      L.reset_carry()
+    if use_pipe:
       if self._pipe is None:
         self._pipe = Pipeline(L, self.device, self.comm_m,
                               tune=bool(self.cfg.get('hip', {}).get('tune_pipeline', True)))
         self._pipe.keys = tuple(self._last_metrics)   # (the first call of a learner is eager)
       self._plan = self._pipe
-      metrics = self._last_metrics = self._pipe.step()   # this call's metrics, fetched lazily
+      metrics = self._last_metrics = self._pipe.step(staged=staged)   # this call's metrics, fetched lazily
       self._train_calls += 1
       return {}, TrainState(L), metrics
     self.flush()

@@ -998,10 +998,10 @@ int dd_conv_image_wgrad(const void* big, int big_is_u8, const float* small, int 
                         int* n_slabs, hipStream_t st, const float* ln_z, const float* ln_stats,
                         const float* ln_gamma, const float* ln_beta) {
   static const int off = getenv("DD_IMG_WGRAD_OFF") ? atoi(getenv("DD_IMG_WGRAD_OFF")) : 0;
-  if (off || Cs != 64 || !(k == 4 || k == 6) || Cb != 3 || wb > 64 || ws_ > 32 || ws_ < 1 || hs < 2 || n_img < 1) return 1;
+  if (off || Cs != 64 || !(k == 4 || k == 6) || !(Cb == 3 || Cb == 4) || wb > 64 || ws_ > 32 || ws_ < 1 || hs < 2 || n_img < 1) return 1;
   const int rowlen = wb * Cb;
   if (rowlen % 4 || (((uintptr_t)big | (uintptr_t)small) & 15)) return 1;
-  if (rowlen > 192) return 1;                                          // (image vectors per thread: K rows x 48 / 96)
+  if (rowlen > 256) return 1;                                          // (image vectors per thread: K rows x <= 64 / 128)
   if (2 * (hs - 1) + k > hb || 2 * (ws_ - 1) + k > wb) return 1;
   if (ln_z && ((((uintptr_t)ln_z | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) || ((uintptr_t)ln_stats & 7))) return 1;
   const int HR = (hs + 1) / 2;
@@ -1019,8 +1019,9 @@ int dd_conv_image_wgrad(const void* big, int big_is_u8, const float* small, int 
   const size_t need = (size_t)grid * (k * k * Cb * 64 + (ln_z ? 192 : 0)) * sizeof(float);
   if (!wsp || ws_bytes < need) return 1;
   WgradLn ln{ln_z, ln_stats, ln_gamma, ln_beta, wsp + (size_t)grid * k * k * Cb * 64};
-#define LW(K_, T_, L_) k_conv_image_wgrad<K_, 3, T_, L_><<<grid, 256, 0, st>>>((const T_*)big, small, wsp, hb, wb, hs, ws_, n_items, HR, per, dbg, ln)
-#define LWL(K_, T_) { if (ln_z) LW(K_, T_, true); else LW(K_, T_, false); }
+#define LW(K_, T_, L_) { if (Cb == 3) k_conv_image_wgrad<K_, 3, T_, L_><<<grid, 256, 0, st>>>((const T_*)big, small, wsp, hb, wb, hs, ws_, n_items, HR, per, dbg, ln); \
+                         else k_conv_image_wgrad<K_, 4, T_, L_><<<grid, 256, 0, st>>>((const T_*)big, small, wsp, hb, wb, hs, ws_, n_items, HR, per, dbg, ln); }
+#define LWL(K_, T_) { if (ln_z) LW(K_, T_, true) else LW(K_, T_, false) }
   if (big_is_u8) { if (k == 4) LWL(4, unsigned char) else LWL(6, unsigned char) }
   else { if (k == 4) LWL(4, float) else LWL(6, float) }
 #undef LWL

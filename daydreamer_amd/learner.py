@@ -1360,11 +1360,36 @@ class Learner:
 
   # ------------------------------------------------------------------ phases
 
-  def upload(self, data):
-    """Stage one replay minibatch (wire format) into the learner's HBM buffers.
+  INPUT_KEYS = ('image', 'vec_in', 'vec_tgt', 'action', 'reward', 'is_first', 'is_terminal')
+
+  def input_stage(self):
+    """A second set of the input buffers (same shapes / dtypes as b[...]): the pipelined agent
+    uploads step k + 1's minibatch into it while step k's world-model phase still reads b[...],
+    and commit_inputs copies it over in stream order (agent.Pipeline)."""
+    st = {}
+    for k in self.INPUT_KEYS:
+      v = self.b.get(k)
+      if isinstance(v, dict):
+        st[k] = {kk: torch.empty_like(vv) for kk, vv in v.items()}
+      elif v is not None:
+        st[k] = torch.empty_like(v)
+    return st
+
+  def commit_inputs(self, stage):
+    """b[...] <- the staged minibatch (device-to-device, on the current stream)."""
+    for k, v in stage.items():
+      if isinstance(v, dict):
+        for kk, vv in v.items():
+          self.b[k][kk].copy_(vv)
+      else:
+        self.b[k].copy_(v)
+
+  def upload(self, data, dst=None):
+    """Stage one replay minibatch (wire format) into the learner's HBM buffers (dst: into a
+    set of buffers from input_stage() instead).
     Values are host numpy arrays (copied over PCIe) or device tensors, e.g. from
     replay.DeviceReplay.sample_batch (device-to-device)."""
-    s, b = self.spec, self.b
+    s, b = self.spec, (dst if dst is not None else self.b)
     dev = self.device
     def tens(x):
       if isinstance(x, torch.Tensor):
@@ -1634,7 +1659,8 @@ class Learner:
       # stream has work for the freed CUs (the pipelined schedule: -0.4 ms per step at configs[1])
       # and costs 0.7 ms where the step waits for the rollout (sequential plan, eager steps)
       rows = self.cfg.get('hip', {}).get('imag_rows', 'auto')
-      rows = (32 if self._pipelined_capture else 16) if str(rows) == 'auto' else int(rows)
+      # (few rows: the 16-row form's shorter step wins - 8 instead of 16 workgroups free nothing)
+      rows = (32 if (self._pipelined_capture and self.N >= 1024) else 16) if str(rows) == 'auto' else int(rows)
       ops.imag_set_rows(rows)
     ops.imagine_rollout_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'],
                             self.unimix, ca['minstd'], ca['maxstd'], t, t0, t1)

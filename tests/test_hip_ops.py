@@ -263,7 +263,7 @@ CONVS = [  # n, hb, Cb, hs, Cs, k, u8
     # more images than workgroups
     (3, 64, 3, 31, 64, 4, True), (5, 64, 3, 30, 64, 6, True), (1, 64, 3, 31, 64, 4, True),
     (7, 32, 3, 14, 64, 6, False), (2, 32, 3, 15, 64, 4, False), (300, 64, 3, 31, 64, 4, True),
-    (270, 16, 3, 6, 64, 6, False)]
+    (270, 16, 3, 6, 64, 6, False), (3, 64, 4, 31, 64, 4, True), (3, 64, 4, 30, 64, 6, False), (40, 64, 4, 31, 64, 4, False)]
 
 
 @pytest.mark.parametrize('n,hb,Cb,hs,Cs,k,u8', CONVS)
