@@ -509,30 +509,8 @@ k_imagine_rollout(ImagArgs a) {
 // Writes what the per-layer launch sequence (learner._actor_backprop.scan_step) leaves behind:
 // dtraj[t][:, :D] = the total gradient of deter_t, dtraj[t-1][:, D:] += the step's contribution.
 
-struct LayerB {            // backward view of a Linear + LayerNorm + ELU layer
-  const char* planes;      // W^T as fragment-major planes [K_fwd/16 tiles][N_fwd/32 k-steps]
-  const float* gamma;
-  const float* z;
-  const float* st;
-  const float* out;
-};
-
-struct ImagBwdArgs {
-  int N, H;
-  float unimix;
-  const float* traj;       // [H+1, N, F + A]
-  float* dtraj;            // [H+1, N, F + A]
-  const float* xs;         // [H*N, S] raw statistics
-  const char* stats_planes;  // W_stats^T: K = S, N = U
-  LayerB img_out[3];
-  const char* gru_planes;    // W_gru^T: K = 3D, N = D + U
-  const float* gru_gamma;
-  const float* gru_beta;
-  const float* z3;         // [H*N, 3D]
-  const float* gstats;     // [H*N, 2]
-  LayerB img_in;           // planes: W_in^T: K = U, N = S + A
-  unsigned long long* dbg;
-};
+using LayerB = DDImagLayerB;
+using ImagBwdArgs = DDImagBwdArgs;
 
 // LayerNorm + ELU backward of this thread's chunks: dout rows in zb (columns col0 ..), z / out /
 // statistics of the forward pass from global (requested by load() BEFORE the contraction that
@@ -937,6 +915,22 @@ bool imag_device_ok() {
 }
 }
 
+// rows per workgroup of the forward rollout: 16 (k_imagine_rollout) or 32 (k_imagine_rollout32)
+static int g_imag_rows = -1;
+static int imag_rows() {
+  if (g_imag_rows < 0) {
+    const char* e = getenv("DD_IMAG_ROWS");
+    g_imag_rows = (e && atoi(e) == 16) ? 16 : 32;
+  }
+  return g_imag_rows;
+}
+extern "C" int dd_imag_set_rows(int rows) {
+  const int prev = imag_rows();
+  DD_REQUIRE(rows == 16 || rows == 32, "dd_imag_set_rows: 16 or 32");
+  g_imag_rows = rows;
+  return prev;
+}
+
 // ptrs (device pointers, in this order):
 //   0 traj  1 dtraj  2 raw statistics  3 img_stats^T planes
 //   4.. img_out l = 0..2: W^T planes, gamma, z, stats, out               (5 each -> 4..18)
@@ -960,8 +954,13 @@ extern "C" int dd_imagine_rollout_bwd(int N, int H, int D, int U, int G, int C, 
   a.img_in.planes = (const char*)p[24]; a.img_in.gamma = (const float*)p[25]; a.img_in.z = (const float*)p[26];
   a.img_in.st = (const float*)p[27]; a.img_in.out = (const float*)p[28];
   a.dbg = n_ptrs == 30 ? (unsigned long long*)p[29] : nullptr;
-  const int blocks = (N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
+  if (imag_rows() == 32) {      // 32 rows per workgroup (imag32.hip)
+    const int rc = dd_imag32_bwd_launch(a, D, U, G, C, A, st);
+    if (rc == 0) { DD_CHECK_LAUNCH("dd_imagine_rollout_bwd(32 rows)"); return 0; }
+    if (rc != 1) return rc;
+  }
+  const int blocks = (N + 15) / 16;
   bool launched = false;
 #define XB(d, u, g, c, a_)                                                                       \
   if (!launched && D == d && U == u && G == g && C == c && A == a_) {                            \
@@ -990,22 +989,6 @@ extern "C" int dd_imag_wprep(const float* W, long ld, int K, int n, int col0, vo
   k_imag_wprep<<<blocks, 256, 0, (hipStream_t)stream>>>(W, ld, K, n, col0, (char*)planes);
   DD_CHECK_LAUNCH("dd_imag_wprep");
   return 0;
-}
-
-// rows per workgroup of the forward rollout: 16 (k_imagine_rollout) or 32 (k_imagine_rollout32)
-static int g_imag_rows = -1;
-static int imag_rows() {
-  if (g_imag_rows < 0) {
-    const char* e = getenv("DD_IMAG_ROWS");
-    g_imag_rows = (e && atoi(e) == 16) ? 16 : 32;
-  }
-  return g_imag_rows;
-}
-extern "C" int dd_imag_set_rows(int rows) {
-  const int prev = imag_rows();
-  DD_REQUIRE(rows == 16 || rows == 32, "dd_imag_set_rows: 16 or 32");
-  g_imag_rows = rows;
-  return prev;
 }
 
 // compiled shapes (deter, units, groups, classes, action dims, actor units); actor layers = 4,

@@ -86,13 +86,15 @@ struct Stream2 {
     }
   }
   // (k-steps 0 and 1 already requested by prefetch(wp))
-  __device__ __forceinline__ void run(const char* wp, const char* abuf, f32x4 (&acc)[2][NT]) {
+  __device__ __forceinline__ void run(const char* wp, const char* abuf, f32x4 (&acc)[2][NT], bool zero = true) {
     static_assert(KS % 2 == 0, "k-steps in pairs");
     if (!DD_I32_PRE) { load(0, wp, 0); load(1, wp, 1); }
+    if (zero) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks += 2) {
       step(0, abuf, ks, acc);
@@ -568,6 +570,329 @@ k_imagine_rollout32(ImagArgs a) {
   }
 }
 
+
+// ============================================================================================
+// Reverse pass at 32 rows per workgroup: k_imagine_reverse (imag.hip; reference agent.py:355-356 -
+// tape.gradient through WorldModel.imagine) with two 16-row operand tiles per streamed weight
+// fragment.  Same steps, same arithmetic per row; LDS as in the forward kernel: the z buffer (32
+// rows x 512 columns) aliases the operand planes' k-steps 8..15, the carried deter gradient
+// [32][260] and the GRU scale / offset stay in LDS (152 KB).
+using LayerB = DDImagLayerB;
+using ImagBwdArgs = DDImagBwdArgs;
+constexpr int HS2 = 260;
+constexpr int DHB_OFF = ZB_OFF + R32 * ZS2 * 4;
+constexpr int PAR_OFF = DHB_OFF + R32 * HS2 * 4;
+constexpr int IMAG32_BWD_LDS = PAR_OFF + 6 * 256 * 4;
+
+template <int NC>
+struct LnBwd2 {
+  float z[NC][8], o[NC][8], gm[NC][8];
+  float2 ms;
+  __device__ __forceinline__ void load(const LayerB& L, long grow, int q) {
+    constexpr int NCOL = NC * 128;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int k = (q + 16 * i) * 8;
+      ld8(L.z + grow * NCOL + k, z[i]);
+      ld8(L.out + grow * NCOL + k, o[i]);
+      ld8(L.gamma + k, gm[i]);
+    }
+    ms = *reinterpret_cast<const float2*>(L.st + grow * 2);
+  }
+  __device__ __forceinline__ void run(const float* zb, int col0, char* abuf, int ks0, int row, int q) {
+    constexpr int NCOL = NC * 128;
+    const float mean = ms.x, rstd = ms.y;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      float d[8];
+      ld8(zb + row * ZS2 + col0 + (q + 16 * i) * 8, d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dy = d[j] * (o[i][j] > 0.f ? 1.f : o[i][j] + 1.f);
+        z[i][j] = (z[i][j] - mean) * rstd;          // x hat
+        gm[i][j] = dy * gm[i][j];                   // g
+        s1 += gm[i][j];
+        s2 += gm[i][j] * z[i][j];
+      }
+    }
+    s1 = row16_sum(s1) / (float)NCOL;
+    s2 = row16_sum(s2) / (float)NCOL;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      float dz[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dz[j] = rstd * (gm[i][j] - s1 - z[i][j] * s2);
+      put_operand2(abuf, ks0, row, q, i, dz);
+    }
+  }
+};
+
+#define TSB(i) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && t == a.H - 1) a.dbg[i] = wall_clock64()
+
+template <int D, int U, int G, int C, int A>
+__global__ void __launch_bounds__(512, 1)
+k_imagine_reverse32(ImagBwdArgs a) {
+  constexpr int S = G * C, F = D + S, W = F + A;
+  static_assert(D == 256 && U == 256 && C == 32 && G == 32 && A <= 16, "compiled shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* abuf = smem;                                               // [16 k-steps][3][2][1 KB]
+  float* zb = reinterpret_cast<float*>(smem + ZB_OFF);             // [32][ZS2], over k-steps 8..15 and beyond
+  float* dhb = reinterpret_cast<float*>(smem + DHB_OFF);           // [32][HS2] gradient of deter carried to step t - 1
+  float* par = reinterpret_cast<float*>(smem + PAR_OFF);           // GRU scale [3D], offset [3D]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = a.N, H = a.H;
+  const long row0 = (long)blockIdx.x * R32;
+  const int gr0 = tid >> 4, gq0 = tid & 15;
+  const long gg0 = min(row0 + gr0, (long)N - 1);
+  const bool glive = row0 + gr0 < N;
+
+  for (int i = tid; i < 3 * D; i += 512) { par[i] = a.gru_gamma[i]; par[3 * D + i] = a.gru_beta[i]; }
+  for (int i = tid; i < R32 * HS2; i += 512) dhb[i] = 0.f;
+  __syncthreads();
+
+  for (int t = H; t >= 1; --t) {
+    // (opaque per-step copies of the row / chunk indices: see k_imagine_rollout32)
+    int gr = gr0, gq = gq0;
+    long gg = gg0;
+    asm volatile("" : "+v"(gr), "+v"(gq), "+v"(gg));
+    const long mrow = (long)(t - 1) * N + gg;          // this thread's row of step t - 1 in the [H*N, ..] buffers
+    float* dcur = a.dtraj + ((long)t * N) * W;
+    float* dprev = a.dtraj + ((long)(t - 1) * N) * W;
+    const float* tprev = a.traj + ((long)(t - 1) * N) * W;
+    TSB(0);
+    // ================= draw backward + img_stats^T: K = S in two halves of 16 groups
+    LnBwd2<U / 128> lnb;
+    lnb.load(a.img_out[2], mrow, gq);
+    f32x4 accs[2][2];
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      {
+        // item = (row r, group g): one thread, serial over the 32 classes (32 rows x 16 groups)
+        const int r = tid & 31, gl = tid >> 5, g = h * 16 + gl;
+        const long gw = min(row0 + r, (long)N - 1);
+        const float* xp = a.xs + ((long)(t - 1) * N + gw) * S + g * C;
+        const float* dp_ = dcur + gw * W + D + g * C;
+        float x[32], ds[32];
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(xp + c);
+          const float4 e = *reinterpret_cast<const float4*>(dp_ + c);
+          x[c] = q.x; x[c + 1] = q.y; x[c + 2] = q.z; x[c + 3] = q.w;
+          ds[c] = e.x; ds[c + 1] = e.y; ds[c + 2] = e.z; ds[c + 3] = e.w;
+        }
+        float m = x[0];
+#pragma unroll
+        for (int c = 1; c < 32; ++c) m = fmaxf(m, x[c]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { x[c] = fexp_(x[c] - m); sum += x[c]; }
+        const float inv = 1.f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          x[c] *= inv;                                  // p
+          ds[c] *= (1.f - a.unimix);                    // dp
+          dot += ds[c] * x[c];
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+          float dx[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dx[j] = x[c8 * 8 + j] * (ds[c8 * 8 + j] - dot);
+          uint4 pl[3];
+          split8(dx, pl);
+          // class chunk c8 of group gl: k-step gl, row tile r >> 4, fragment lane c8 * 16 + (r & 15)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(abuf + (((gl * 3 + p) * 2 + (r >> 4)) * 64 + c8 * 16 + (r & 15)) * 16) = pl[p];
+        }
+      }
+      __syncthreads();
+      Stream2<2, 16, false, 32> sT;
+      sT.run(a.stats_planes + (long)(wave * 2) * (32 * 3072) + h * 16 * 3072, abuf, accs, h == 0);
+      __syncthreads();
+    }
+    tiles_to_z2<2, false>(accs, zb, wave * 32, nullptr);
+    __syncthreads();
+    TSB(1);
+    // ================= img_out 2 .. 0: LayerNorm / ELU backward, W^T
+#pragma unroll 1
+    for (int l = 2; l >= 0; --l) {
+      lnb.run(zb, 0, abuf, 0, gr, gq);
+      __syncthreads();
+      if (l > 0) lnb.load(a.img_out[l - 1], mrow, gq);      // the next layer's activations travel during the contraction
+      Stream2<2, 8, false> sO;
+      f32x4 acc[2][2];
+      sO.run(a.img_out[l].planes + (long)(wave * 2) * Stream2<2, 8, false>::TILE_BYTES, abuf, acc);
+      tiles_to_z2<2, false>(acc, zb, wave * 32, nullptr);
+      __syncthreads();
+    }
+    TSB(2);
+    // ================= GRU backward
+    {
+      constexpr int NC = 3 * D / 128, ND = D / 128;
+      float v[NC][8], dy[NC][8];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) ld8(a.z3 + mrow * (3 * D) + (gq + 16 * i) * 8, v[i]);
+      const float2 ms = *reinterpret_cast<const float2*>(a.gstats + mrow * 2);
+      const float mean = ms.x, rstd = ms.y;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int d = (gq + 16 * i) * 8;
+        float hp[8], dd[8], carry[8], rec[8], dhd[8];
+        ld8(tprev + gg * W + d, hp);
+        ld8(dcur + gg * W + d, dd);
+        ld8(dhb + gr * HS2 + d, carry);
+        ld8(zb + gr * ZS2 + d, rec);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dd[j] = (dd[j] + carry[j]) + rec[j];     // total gradient of deter_t
+        if (glive) st8(dcur + gg * W + d, dd);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xr = (v[i][j] - mean) * rstd, xc = (v[i + ND][j] - mean) * rstd, xu = (v[i + 2 * ND][j] - mean) * rstd;
+          const float yr = xr * par[d + j] + par[3 * D + d + j];
+          const float yc = xc * par[D + d + j] + par[4 * D + d + j];
+          const float yu = xu * par[2 * D + d + j] + par[5 * D + d + j];
+          const float r = sigmoidf_(yr);
+          const float cand = tanhf(r * yc);
+          const float u = sigmoidf_(yu - 1.f);
+          const float du = dd[j] * (cand - hp[j]);
+          const float dc = dd[j] * u;
+          dhd[j] = dd[j] * (1.f - u);
+          const float dpre = dc * (1.f - cand * cand);
+          const float dyc = dpre * r, dyr = dpre * yc * r * (1.f - r), dyu = du * u * (1.f - u);
+          dy[i][j] = dyr * par[d + j]; dy[i + ND][j] = dyc * par[D + d + j]; dy[i + 2 * ND][j] = dyu * par[2 * D + d + j];
+          s1 += dy[i][j] + dy[i + ND][j] + dy[i + 2 * ND][j];
+          s2 += dy[i][j] * xr + dy[i + ND][j] * xc + dy[i + 2 * ND][j] * xu;
+        }
+        st8(dhb + gr * HS2 + d, dhd);          // direct path (1 - update) * dh'; the W^T part is added below
+      }
+      s1 = row16_sum(s1) / (float)(3 * D);
+      s2 = row16_sum(s2) / (float)(3 * D);
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dy[i][j] = rstd * (dy[i][j] - s1 - (v[i][j] - mean) * rstd * s2);   // dz3
+      // [dh | dx1] = dz3 @ W_gru^T, K = 3D in two parts (the operand buffer holds 16 k-steps)
+      __syncthreads();                     // zb (rec) and abuf free
+#pragma unroll
+      for (int i = 0; i < 4; ++i) put_operand2(abuf, 0, gr, gq, i, dy[i]);
+      __syncthreads();
+      lnb.load(a.img_in, mrow, gq);        // img_in's activations travel during the contraction
+      f32x4 acc[2][4];
+      const char* wg = a.gru_planes + (long)(wave * 4) * (24 * 3072);
+      {
+        Stream2<4, 16, false, 24> sG;
+        sG.run(wg, abuf, acc, true);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 4; i < NC; ++i) put_operand2(abuf, -16, gr, gq, i, dy[i]);
+      __syncthreads();
+      {
+        Stream2<4, 8, false, 24> sG2;
+        sG2.run(wg + 16 * 3072, abuf, acc, false);
+      }
+      tiles_to_z2<4, false>(acc, zb, wave * 64, nullptr);   // (the second part read k-steps 0..7 only: below the z buffer)
+    }
+    __syncthreads();
+    TSB(3);
+    // ================= dh carry, img_in backward
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) {
+      const int d = (gq + 16 * i) * 8;
+      float x[8], y[8];
+      ld8(dhb + gr * HS2 + d, x);
+      ld8(zb + gr * ZS2 + d, y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] += y[j];
+      st8(dhb + gr * HS2 + d, x);
+    }
+    lnb.run(zb, D, abuf, 0, gr, gq);
+    __syncthreads();
+    TSB(4);
+    // [dstoch_{t-1} | daction_{t-1}] += dz1 @ W_in^T : S columns in two passes of 4 tiles per wave
+#pragma unroll 1
+    for (int ps_ = 0; ps_ < S / 512; ++ps_) {
+      Stream2<4, 8, false> sI;
+      f32x4 acc[2][4];
+      sI.run(a.img_in.planes + (long)(ps_ * 32 + wave * 4) * Stream2<4, 8, false>::TILE_BYTES, abuf, acc);
+      __syncthreads();          // zb readers of the previous pass / of ln_bwd are done
+      tiles_to_z2<4, false>(acc, zb, wave * 64, nullptr);
+      __syncthreads();
+      if (glive) {
+        float o[4][8], d[4][8];
+        float* dst = dprev + gg * W + D + ps_ * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ld8(dst + (gq + 16 * i) * 8, o[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ld8(zb + gr * ZS2 + (gq + 16 * i) * 8, d[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[i][j] += d[i][j];
+          st8(dst + (gq + 16 * i) * 8, o[i]);
+        }
+      }
+    }
+    if (wave < 2) {   // the action columns: one tile (tile S / 16 of the cache), wave = row tile
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(a.img_in.planes + (long)(S / 16) * Stream2<4, 8, false>::TILE_BYTES), 0, 0x7fffffff, 0x00020000);
+      uint4 bq[8][3];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)lane * 16u, (ks * 3 + p) * 1024, 0);
+          bq[ks][p] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 av[3], b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          av[p] = *reinterpret_cast<const bf16x8*>(abuf + (((ks * 3 + p) * 2 + wave) * 64 + lane) * 16);
+          b[p] = __builtin_bit_cast(bf16x8, bq[ks][p]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[0], acc, 0, 0, 0);
+      }
+      const int col = lane & 15;
+      if (col < A) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long rw = row0 + wave * 16 + (lane >> 4) * 4 + r;
+          if (rw < N) dprev[rw * W + F + col] += acc[r];
+        }
+      }
+    }
+    __syncthreads();   // the next step reads dtraj[t - 1] (written above) and reuses abuf / zb
+    TSB(5);
+  }
+  // the gradient of the start states' deter (nothing consumes it; written for the launch
+  // sequence's dtraj[0], which it leaves complete)
+  if (glive) {
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) {
+      const int d = (gq0 + 16 * i) * 8;
+      float x[8], y[8];
+      ld8(a.dtraj + gg0 * W + d, x);
+      ld8(dhb + gr0 * HS2 + d, y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] += y[j];
+      st8(a.dtraj + gg0 * W + d, x);
+    }
+  }
+}
+
 int imag32_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -576,7 +901,7 @@ int imag32_device() {
 
 }  // namespace
 
-int dd_imag32_lds_bytes() { return IMAG32_LDS; }
+int dd_imag32_lds_bytes() { return IMAG32_LDS > IMAG32_BWD_LDS ? IMAG32_LDS : IMAG32_BWD_LDS; }
 
 template <bool PRE_>
 static int imag32_launch_t(const DDImagArgs& a, int D, int U, int G, int C, int A, int AU, hipStream_t st) {
@@ -605,4 +930,25 @@ int dd_imag32_launch(const DDImagArgs& a, int D, int U, int G, int C, int A, int
   // phase as in the 16-row kernel, needs 96-144 more live registers than a wave has at two waves
   // per SIMD: 370 spilled registers, 4.98 instead of 3.34 ms at configs[1] - not instantiated)
   return imag32_launch_t<false>(a, D, U, G, C, A, AU, st);
+}
+
+int dd_imag32_bwd_launch(const DDImagBwdArgs& a, int D, int U, int G, int C, int A, hipStream_t st) {
+  const int blocks = (a.N + R32 - 1) / R32;
+  bool launched = false;
+#define XB(d, u, g, c, a_)                                                                       \
+  if (!launched && D == d && U == u && G == g && C == c && A == a_) {                            \
+    static unsigned long long attr = 0;   /* one bit per device: the attribute is per device */  \
+    const unsigned long long bit = 1ull << (imag32_device() & 63);                               \
+    if (!(attr & bit)) {                                                                         \
+      hipError_t e = hipFuncSetAttribute((const void*)k_imagine_reverse32<d, u, g, c, a_>,       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, IMAG32_BWD_LDS); \
+      if (e != hipSuccess) { dd_set_error("dd_imagine_rollout_bwd(attr, 32 rows)", e); return (int)e; } \
+      attr |= bit;                                                                               \
+    }                                                                                            \
+    k_imagine_reverse32<d, u, g, c, a_><<<blocks, 512, IMAG32_BWD_LDS, st>>>(a);                 \
+    launched = true;                                                                             \
+  }
+  XB(256, 256, 32, 32, 16) XB(256, 256, 32, 32, 6)
+#undef XB
+  return launched ? 0 : 1;
 }

@@ -40,9 +40,36 @@ struct DDImagArgs {
   unsigned long long* dbg; // optional: time stamps of step 1 on block 0 (100 MHz wall clock)
 };
 
+// ---- arguments of the fused reverse pass ----
+struct DDImagLayerB {            // backward view of a Linear + LayerNorm + ELU layer
+  const char* planes;      // W^T as fragment-major planes [K_fwd/16 tiles][N_fwd/32 k-steps]
+  const float* gamma;
+  const float* z;
+  const float* st;
+  const float* out;
+};
+
+struct DDImagBwdArgs {
+  int N, H;
+  float unimix;
+  const float* traj;       // [H+1, N, F + A]
+  float* dtraj;            // [H+1, N, F + A]
+  const float* xs;         // [H*N, S] raw statistics
+  const char* stats_planes;  // W_stats^T: K = S, N = U
+  DDImagLayerB img_out[3];
+  const char* gru_planes;    // W_gru^T: K = 3D, N = D + U
+  const float* gru_gamma;
+  const float* gru_beta;
+  const float* z3;         // [H*N, 3D]
+  const float* gstats;     // [H*N, 2]
+  DDImagLayerB img_in;           // planes: W_in^T: K = U, N = S + A
+  unsigned long long* dbg;
+};
+
 // the 32-row form (imag32.hip); returns 0 when it launched the shape, 1 when it does not cover it
 int dd_imag32_launch(const DDImagArgs& a, int D, int U, int G, int C, int A, int AU, hipStream_t st);
 int dd_imag32_lds_bytes();
+int dd_imag32_bwd_launch(const DDImagBwdArgs& a, int D, int U, int G, int C, int A, hipStream_t st);
 
 namespace {
 

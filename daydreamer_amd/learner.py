@@ -1626,6 +1626,17 @@ class Learner:
         if on_state:
           on_state(t + 1)
 
+  def _imag_rows(self, ops):
+    """Rows per workgroup of the fused continuous-action rollout and its reverse pass (process-wide
+    switch, set before each launch): 32 holds half the CUs for 1.23 x the time - it pays where
+    another stream has work for the freed CUs (the pipelined schedule: -0.4 ms per step at
+    configs[1]) and costs 0.7 ms where the step waits for the rollout (sequential plan, eager
+    steps); with few rows the 16-row form's shorter step wins (8 instead of 16 workgroups free nothing)."""
+    if hasattr(ops, 'imag_set_rows'):
+      rows = self.cfg.get('hip', {}).get('imag_rows', 'auto')
+      rows = (32 if (self._pipelined_capture and self.N >= 1024) else 16) if str(rows) == 'auto' else int(rows)
+      ops.imag_set_rows(rows)
+
   def imagine_rollout_fused(self, t0=0, t1=None, prep=True):
     """The H img_steps and H + 1 policy evaluations as one persistent launch
     (dd_imagine_rollout_fwd): same buffers as the launch sequence above, same values up to the
@@ -1654,14 +1665,7 @@ class Learner:
     if getattr(self, 'imag_stamps', None) is not None:   # measurement aid (tools/imag_time.py)
       t.append(self.imag_stamps)
     self._stamp(5)
-    if hasattr(ops, 'imag_set_rows'):
-      # rows per workgroup: 32 holds half the CUs for 1.23 x the time - it pays where another
-      # stream has work for the freed CUs (the pipelined schedule: -0.4 ms per step at configs[1])
-      # and costs 0.7 ms where the step waits for the rollout (sequential plan, eager steps)
-      rows = self.cfg.get('hip', {}).get('imag_rows', 'auto')
-      # (few rows: the 16-row form's shorter step wins - 8 instead of 16 workgroups free nothing)
-      rows = (32 if (self._pipelined_capture and self.N >= 1024) else 16) if str(rows) == 'auto' else int(rows)
-      ops.imag_set_rows(rows)
+    self._imag_rows(ops)
     ops.imagine_rollout_fwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, ca['units'],
                             self.unimix, ca['minstd'], ca['maxstd'], t, t0, t1)
     self._stamp(6)
@@ -1703,6 +1707,7 @@ class Learner:
     t += [plt['img_in'][1], P['img_in'].gamma, ai.z, ai.stats, ai.out]
     if getattr(self, 'imag_stamps_b', None) is not None:   # measurement aid (tools/imag_time.py)
       t.append(self.imag_stamps_b)
+    self._imag_rows(ops)
     ops.imagine_rollout_bwd(self.N, self.H, self.D, self.U, self.G, self.C, self.A, self.unimix, t)
 
   HEAD_CHUNK = 4  # time rows per chunk of the overlapped head evaluation

@@ -381,8 +381,10 @@ def test_fused_onehot_rollout_equals_launch_sequence(hip):
     torch.cuda.empty_cache()
 
 
-def test_fused_imagination_reverse_equals_launch_sequence(hip):
-  """csrc/imag.hip k_imagine_reverse: the data gradient of the imagined rollout (steps H .. 1 of
+@pytest.mark.parametrize('rows', [16, 32])
+def test_fused_imagination_reverse_equals_launch_sequence(hip, rows):
+  """(rows: of the imagination batch per workgroup - csrc/imag.hip 16, csrc/imag32.hip 32.)
+  csrc/imag.hip k_imagine_reverse: the data gradient of the imagined rollout (steps H .. 1 of
   draw / img_stats / img_out / GRU / img_in backward) as ONE persistent launch against the
   per-layer launch sequence, inside a whole train step with the same (fused) forward rollout:
   the gradient of every imagined state and action (dtraj) and the actor's parameter gradients
@@ -393,7 +395,7 @@ def test_fused_imagination_reverse_equals_launch_sequence(hip):
         cfg, image=64, vector=16, action=adim, terminals=0.02, smooth=True)
     Ls = []
     for fused in (True, False):
-      plain2 = dict(plain, hip=dict(plain.get('hip', {}), fused_imag_bwd=fused))
+      plain2 = dict(plain, hip=dict(plain.get('hip', {}), fused_imag_bwd=fused, imag_rows=rows))
       sp2 = type(sp)(**{**sp.__dict__, 'cfg': plain2})
       L = learner_mod.Learner(sp2, hip, 'cuda:0', B, T, params=params, noise_seed=7)
       assert L.fused_imag and L.fused_imag_bwd == fused

@@ -11,6 +11,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 cfg = helpers.make_config(('a1_vision',), batch_size=B, replay_chunk=T, imag_horizon=H)
+import os
+if os.environ.get('DD_IMAG_ROWS'):   # rows per workgroup of the fused kernels (16 / 32)
+  cfg = cfg.update({'hip.imag_rows': int(os.environ['DD_IMAG_ROWS'])})
 plain = config_mod.to_plain(cfg)
 obs, act = synthetic.config_spaces('a1_vision')
 sp = spec_mod.build_spec(plain, {k: v.shape for k, v in obs.items()}, 16, False)
