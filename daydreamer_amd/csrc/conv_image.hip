@@ -729,7 +729,7 @@ struct WgradLn {
 };
 
 template <int K, int CB, typename TI, bool LNB>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (K == 6 && CB == 4 && sizeof(TI) == 4) ? 1 : 2)   // (that window + row buffers: 83 KB of LDS)
 k_conv_image_wgrad(const TI* __restrict__ img, const float* __restrict__ G, float* __restrict__ slabs,
                    int hb, int wb, int hs, int ws_, int n_items, int HR, int per, int dbg, WgradLn ln) {
   constexpr bool U8 = sizeof(TI) == 1;

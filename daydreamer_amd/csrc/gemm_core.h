@@ -1026,19 +1026,23 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
     if (k0 + BK <= ke) gload(k0, ra, rb, std::true_type());
     else gload(k0, ra, rb, std::false_type());
   };
-  auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4]) {
+  // xs = 1 / 2: the staged tile of A / B lies in the operand's exact range - only its high plane is
+  // written (the values are bf16-exact: the rounded plane IS the value; the multiply of such a
+  // tile reads nothing else), no split arithmetic, a third of that operand's LDS stores
+  auto sstore = [&](int buf, float (&ra)[NA][4], float (&rb)[NB][4], auto xs_tag) {
+    constexpr int XS = decltype(xs_tag)::value;
     if (a_on) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         int r, k; LA::coord(tid, u, r, k);
-        LA::template store<NPL>(As[buf], ra[u], r, k);
+        LA::template store<(XS == 1 ? 1 : NPL)>(As[buf], ra[u], r, k);
       }
     }
     if (b_on) {
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         int r, k; LB::coord(tid, u, r, k);
-        LB::template store<NPL>(Bs[buf], rb[u], r, k);
+        LB::template store<(XS == 2 ? 1 : NPL)>(Bs[buf], rb[u], r, k);
       }
     }
   };
@@ -1118,7 +1122,7 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
 #pragma unroll
   for (int s_ = 0; s_ < ST; ++s_)
     if (s_ < nk) gload_rt(kb + s_ * BK, ra_[s_], rb_[s_]);
-  if (nk > 0) sstore(0, ra_[0], rb_[0]);
+  if (nk > 0) sstore(0, ra_[0], rb_[0], std::integral_constant<int, 0>());
   __syncthreads();
   // one steady-state iteration group (ST k-tiles) with the product set XS
   auto steady = [&](int t0, auto xs_tag) {
@@ -1132,7 +1136,12 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
       __builtin_amdgcn_sched_barrier(0);
       compute(t & 1, xs_tag);
       if (!IL) __builtin_amdgcn_sched_barrier(0);
-      sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+      if constexpr (XS != 0) {   // (tile t + 1 of an exact segment is exact too, except behind its last tile)
+        if (t + 1 < tx1) sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST], xs_tag);
+        else sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST], std::integral_constant<int, 0>());
+      } else {
+        sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST], std::integral_constant<int, 0>());
+      }
       if (IL) {  // tile t+1 arrived an iteration ago: split + stage it under the MFMAs
         constexpr int NMF = TM * TN * (XS ? 3 : NP) * (BK / 16);
 #pragma unroll
@@ -1166,7 +1175,7 @@ k_mfma_gemm_s3(AL al, BL bl, EP ep, int K, int kps, int tiles_m) {
         } else {
           compute(t & 1, std::integral_constant<int, 0>());
         }
-        if (t + 1 < nk) sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST]);
+        if (t + 1 < nk) sstore((t & 1) ^ 1, ra_[(s_ + 1) % ST], rb_[(s_ + 1) % ST], std::integral_constant<int, 0>());
         __syncthreads();
       }
     }
