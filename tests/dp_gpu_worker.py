@@ -39,8 +39,14 @@ def main():
   BG = int(os.environ.get('DD_DP_BATCH', 6))
   dev = f'cuda:{local}'
   print(f'rank {rank}/{world}: device {dev} of {torch.cuda.device_count()}, backend {backend}', flush=True)
-  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=BG, replay_chunk=8, imag_horizon=4)
-  obs, act = synthetic.make_spaces(64, 5, 3)
+  # DD_DP_CONFIG=xarm: the configs[2] family (image + depth + five proprio keys, one-hot 6-way action,
+  # REINFORCE, deter = units = 512 at full width) instead of the a1_vision debug block
+  if os.environ.get('DD_DP_CONFIG') == 'xarm':
+    cfg = helpers.make_config(('xarm',), batch_size=BG, replay_chunk=8, imag_horizon=4)
+    obs, act = synthetic.config_spaces('xarm')
+  else:
+    cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=BG, replay_chunk=8, imag_horizon=4)
+    obs, act = synthetic.make_spaces(64, 5, 3)
   batches = [synthetic.make_batch(obs, act, BG, 8, seed=s, smooth_images=True, terminals=0.1)
              for s in range(3)]
   res = {}

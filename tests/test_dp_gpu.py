@@ -35,10 +35,10 @@ def free_port():
   return p
 
 
-def launch(tmp_path, backend, tune=False, ranks=2, batch=6):
+def launch(tmp_path, backend, tune=False, ranks=2, batch=6, config='a1_vision'):
   distinct = torch.cuda.device_count() >= ranks
   env = dict(os.environ, DD_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0',
-             DD_DP_TUNE='1' if tune else '0',
+             DD_DP_TUNE='1' if tune else '0', DD_DP_CONFIG=config,
              DD_DP_DISTINCT='1' if distinct else '0', DD_DP_BATCH=str(batch))
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks),
          '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
@@ -47,10 +47,14 @@ def launch(tmp_path, backend, tune=False, ranks=2, batch=6):
                         timeout=420)
 
 
-def single_rank_reference(batch=6):
+def single_rank_reference(batch=6, config='a1_vision'):
   from daydreamer_amd import agent as agent_mod, synthetic
-  cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=batch, replay_chunk=8, imag_horizon=4)
-  obs, act = synthetic.make_spaces(64, 5, 3)
+  if config == 'xarm':
+    cfg = helpers.make_config(('xarm',), batch_size=batch, replay_chunk=8, imag_horizon=4)
+    obs, act = synthetic.config_spaces('xarm')
+  else:
+    cfg = helpers.make_config(('a1_vision', 'debug'), batch_size=batch, replay_chunk=8, imag_horizon=4)
+    obs, act = synthetic.make_spaces(64, 5, 3)
   batches = [synthetic.make_batch(obs, act, batch, 8, seed=s, smooth_images=True, terminals=0.1)
              for s in range(3)]
   ag = agent_mod.Agent(obs, act, None, cfg)
@@ -60,9 +64,9 @@ def single_rank_reference(batch=6):
   return ag.save(), m
 
 
-def compare(tmp_path, batch=6):
+def compare(tmp_path, batch=6, config='a1_vision'):
   got = dict(np.load(tmp_path / 'dp_gpu.npz'))
-  want, mets = single_rank_reference(batch)
+  want, mets = single_rank_reference(batch, config)
   worst = max((helpers.rel_err(got[f'p/{k}'], np.asarray(v)), k) for k, v in want.items()
               if k.startswith('params/'))
   print('2 ranks vs 1 rank: worst parameter rel err', worst)
@@ -70,17 +74,25 @@ def compare(tmp_path, batch=6):
   assert worst[0] < 5e-3, worst
   for k in ('model_loss', 'actor_loss', 'extr_critic_loss', 'model_grad_norm', 'wmkl_scale_mean',
             'actent_scale_mean', 'kl_loss_mean', 'image_loss_mean'):
+    if k not in mets:     # (names of the other action type)
+      continue
     a, o = float(got[f'm/{k}']), float(mets[k])
     assert abs(a - o) <= 1e-4 * max(1.0, abs(o)), (k, a, o)
   for k in ('state/slow_updates', 'opt/model/step', 'state/noise_step'):
     assert np.array_equal(got[f'p/{k}'], np.asarray(want[k])), k
 
 
-def test_two_ranks_on_hip_kernels_gloo(hip, tmp_path):
-  r = launch(tmp_path, 'gloo')
+@pytest.mark.parametrize('config', ['a1_vision', 'xarm'])
+def test_two_ranks_on_hip_kernels_gloo(hip, tmp_path, config):
+  """Two ranks sharing the GPU, both schedules: the worker exits non-zero unless the pipelined
+  schedule (hip.pipeline: true under data parallelism, its three communicators, the early
+  all-reduce of the sequential one) leaves parameters and metrics bit-identical to the sequential
+  schedule; 2 ranks == 1 rank (which runs the shipped pipelined schedule) on the global batch.
+  xarm: the configs[2] family at full width (one-hot actions, REINFORCE, deter = units = 512)."""
+  r = launch(tmp_path, 'gloo', config=config)
   print(r.stdout[-3000:])
   assert r.returncode == 0, r.stdout[-3000:]
-  compare(tmp_path)
+  compare(tmp_path, config=config)
 
 
 @pytest.mark.parametrize('ranks,batch', [(2, 6), (4, 8), (8, 8)])
