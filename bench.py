@@ -82,11 +82,17 @@ def make_config(name):
   return config_mod.Config(cfgs['defaults']).update(cfgs[name])
 
 
-def cpu_baseline(cfg, name, batch, T, threads=16, reps=3):
+def cpu_baseline(cfg, name, batch, T, threads=16, reps=5):
   """The CPU restatement of the reference graph AS WRITTEN (oracle/dreamer_ref.py, fp32,
   PyTorch-CPU) on the workload's full per-GPU batch: 1 warm-up + `reps` timed train steps.
   16 threads: measured on the MI355X host (256 cores) 16 threads beat 32 / 64 / 256 at batch
-  5, 25 and 50 because the graph is dominated by small sequential ops."""
+  5, 25 and 50 because the graph is dominated by small sequential ops.
+  Eager only: SURVEY 8(d) also asks for a torch.compile'd variant with the faster one reported, but
+  inductor's CPU backend needs 52 s here to compile f(x, w) = elu(layer_norm(x @ w)) alone (one g++
+  invocation per fused kernel), and the train step is ~1 500 such operations unrolled over the T = 50
+  observe scan and the H = 15 rollout, under autograd, with Python-side controller state
+  (AutoAdapt, Normalize, the hand-written Adam): not compilable inside a benchmark that has to
+  finish in minutes (docs/LABLOG.md, round 6)."""
   from oracle import dreamer_ref
   from daydreamer_amd import spec as spec_mod
   threads = min(threads or os.cpu_count(), os.cpu_count())
