@@ -3,8 +3,8 @@
 # kernel stats of the train loop (default schedule and pipeline), PMC HBM traffic, phase / scan /
 # imagination / call-site timings, the other BASELINE config shards.  Writes gpurun_out/<tag>_*;
 # copy what is to be judged into profiles/.
-#   gpurun --timeout 2400 -- 'bash tools/evidence.sh r05'
-tag=${1:-r05}
+#   gpurun --timeout 2400 -- 'bash tools/evidence.sh r06'
+tag=${1:-r06}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rA 2>&1 | tail -260 > gpurun_out/${tag}_pytest_gpu.log)
 (timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1)
@@ -21,14 +21,17 @@ for mode in 0 1; do
   DB=$(ls /tmp/prof$mode/*/*.db /tmp/prof$mode/*.db 2>/dev/null | head -1)
   # (the child run makes max(W, 3) + K train calls and nothing else)
   python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $DB $((K + W)) $W > $GRAFT_REPO_ROOT/gpurun_out/${tag}_rocprof_kernel_stats_pipeline$mode.csv 2>> /tmp/prof$mode.log
+  python $GRAFT_REPO_ROOT/tools/timeline.py $DB $((K + W)) $W 2>/dev/null | grep -v columns | head -40 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_timeline_pipeline$mode.txt
 done
 cd $GRAFT_REPO_ROOT
 bash tools/pmc_bench.sh > gpurun_out/${tag}_pmc_hbm_traffic.txt 2>&1
 (timeout 200 python tools/phase_times.py > gpurun_out/${tag}_phase_times.txt 2>&1)
 (timeout 200 python tools/scan_time.py > gpurun_out/${tag}_fused_scan_times.txt 2>&1)
 (timeout 200 python tools/trace_shapes.py > gpurun_out/${tag}_contraction_call_sites.txt 2>&1)
-(timeout 200 python tools/imag_time.py > gpurun_out/${tag}_fused_imagination_times.txt 2>&1)
 (timeout 200 python tools/ln_bench.py > gpurun_out/${tag}_ln_bandwidth.txt 2>&1)
+(timeout 200 python tools/conv_wgrad_probe.py 2>&1 | grep -v amdgpu > gpurun_out/${tag}_image_layer_probe.txt)
+(timeout 200 python tools/phase_timeline.py 2>&1 | grep -v amdgpu > gpurun_out/${tag}_phase_timeline_pipelined.txt)
+(for r in 16 32; do echo "rows per workgroup: $r"; DD_IMAG_ROWS=$r timeout 200 python tools/imag_time.py 2>&1 | grep -v amdgpu; done > gpurun_out/${tag}_fused_imagination_times.txt)
 (timeout 200 python bench.py --cnn resnet --steps 4 --warmup 2 --no-cpu-baseline --pmc off > gpurun_out/${tag}_bench_resnet.json 2>/dev/null)
 (timeout 120 python tools/graph_stress.py --iters 45 > gpurun_out/${tag}_graph_stress.log 2>&1)
 (timeout 300 python tools/dp_preflight.py --gpus 1 2>&1 | grep -a preflight > gpurun_out/${tag}_dp_preflight_1rank_rccl.log)
