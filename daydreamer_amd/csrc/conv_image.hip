@@ -431,8 +431,10 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
           split3(f[e + 1], h1, m1, l1);
           const int o = r * RS + c + e;
           *reinterpret_cast<unsigned*>(&patch[0][o]) = pack_hi(h0, h1);
-          *reinterpret_cast<unsigned*>(&patch[1][o]) = pack_hi(m0, m1);
-          *reinterpret_cast<unsigned*>(&patch[2][o]) = pack_hi(l0, l1);
+          if constexpr (sizeof(TB) != 1) {
+            *reinterpret_cast<unsigned*>(&patch[1][o]) = pack_hi(m0, m1);
+            *reinterpret_cast<unsigned*>(&patch[2][o]) = pack_hi(l0, l1);
+          }
         }
       }
     }
@@ -476,7 +478,7 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
         const int e0 = (2 * wave + ky) * RS + 2 * j * Cb + oc * 8;      // even element index (RS, Cb*2j, oc*8 even)
         bf16x8 af[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < (sizeof(TB) == 1 ? 1 : 3); ++p) {
           const unsigned* src = reinterpret_cast<const unsigned*>(&patch[p][e0]);
           af[p] = __builtin_bit_cast(bf16x8, make_uint4(src[0], src[1], src[2], src[3]));
         }
@@ -484,10 +486,12 @@ k_conv_image_down(const TB* __restrict__ big, const char* __restrict__ planes, c
         // (filter fragment as the ROW operand: the result tile is [channel][pixel], so a lane ends
         // up with four consecutive channels of one pixel = one 16-byte store)
         for (int t = 0; t < NT; ++t) {
-          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[2], acc[m][t], 0, 0, 0);
+          // (a uint8 image - 0..255, the `/255` is in_scale in the epilogue - is exact in its high
+          // plane: the three products with its all-zero lower planes are left out, bit-identical)
+          if constexpr (sizeof(TB) != 1) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[2], acc[m][t], 0, 0, 0);
           acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][2], af[0], acc[m][t], 0, 0, 0);
-          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][1], af[1], acc[m][t], 0, 0, 0);
-          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[1], acc[m][t], 0, 0, 0);
+          if constexpr (sizeof(TB) != 1) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][1], af[1], acc[m][t], 0, 0, 0);
+          if constexpr (sizeof(TB) != 1) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[1], acc[m][t], 0, 0, 0);
           acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][1], af[0], acc[m][t], 0, 0, 0);
           acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][0], af[0], acc[m][t], 0, 0, 0);
         }
