@@ -72,3 +72,35 @@ def test_fused_imagination_shape_queries():
   assert q(4096, 256, 64, 64, 16, 512, 4, 3, 0) == 0     # a1_scaled
   assert q(256, 256, 32, 32, 16, 512, 2, 3, 0) == 0      # debug block: 2 actor layers
   assert q(256, 256, 32, 32, 16, 256, 4, 3, 0) == 0
+
+
+def test_exact_column_registry_follows_views():
+  """hipops.mark_exact / _exact_cols (host logic of dd_gemm_f32_x): a contraction operand that is a
+  view into a registered buffer - row slices, column slices, the flattened [M, W] view of the
+  [H+1, N, W] trajectory - gets the exact column range translated into ITS columns; another
+  leading dimension, another tensor or a collected owner gets none."""
+  import torch
+  from daydreamer_amd import hipops
+  keep = list(hipops._EXACT)
+  hipops._EXACT[:] = []
+  try:
+    traj = torch.zeros(4, 10, 48)            # [H+1, N, W]: deter 8 | stoch 32 | action 8
+    hipops.mark_exact(traj, 8, 40)
+    def q(t):
+      return hipops._exact_cols(t.data_ptr(), t.stride(0), t.shape[1])
+    flat = traj.view(40, 48)
+    assert q(flat) == (8, 40)
+    assert q(flat[:, :40]) == (8, 40)         # feat = [deter | stoch]
+    assert q(flat[10:30, :40]) == (8, 40)     # a row range
+    assert q(flat[:, 8:40]) == (0, 32)        # the stoch columns alone
+    assert q(flat[:, 16:48]) == (0, 24)       # starts inside the range, runs past it
+    assert q(flat[:, 40:]) == (0, 0)          # the action columns
+    other = torch.zeros(40, 48)
+    assert q(other) == (0, 0)
+    assert q(traj.view(80, 24)) == (0, 0)     # another leading dimension: not a row of the buffer
+    del traj, flat
+    import gc
+    gc.collect()
+    assert q(other) == (0, 0) and not hipops._EXACT      # the dead entry is dropped on lookup
+  finally:
+    hipops._EXACT[:] = keep
