@@ -461,6 +461,7 @@ def main():
     res = {}
     def run_other():
       try:
+        torch.cuda.set_device(local)   # (the current device is per thread: HIP launches of this thread go to this rank's GPU)
         res['dt'] = measure_other()
       except Exception as e:   # noqa: BLE001 - reported, the headline stands
         res['err'] = repr(e)
