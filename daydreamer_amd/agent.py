@@ -376,6 +376,7 @@ class Pipeline:
     # 31.4 ms on the pair the first one had measured at 29.4, tools/interleaved_loop.py)
     self.tuned = not tune or os.environ.get('DD_PIPE_TUNE', '1') == '0' or env is not None
     self.k_tune, self.ticks = 0, []
+    self._drained = False   # flush() ran since the previous step: restart the current trial
     self.ev_in = torch.cuda.Event()
     self.stages = [None, None]           # input staging buffers by step parity (Pipeline.stage)
     self.ev_commit = [torch.cuda.Event(), torch.cuda.Event()]
@@ -479,6 +480,15 @@ class Pipeline:
   def _tune_step(self):
     """Stream pair of the step about to be enqueued while the selection is being measured."""
     c, r = divmod(self.k_tune, self.TRIAL)
+    if self._drained:
+      # the pipeline was drained since the previous step (policy / report / save between two train
+      # calls): the period of this trial would include the host's idle gap - start the trial over
+      # on the same pair, only back-to-back steps are timed
+      self._drained = False
+      if r != 0:
+        self.k_tune += 1 - r
+        self.ticks = []
+        return
     self.k_tune += 1
     if r != 0:
       return
@@ -563,6 +573,8 @@ class Pipeline:
       # (a failure the caller has already been handed - it looked at the metrics - is not raised again)
       mets = self.handle.resolve() if self.pending is not None and not self.handle.failed else None
     finally:
+      if self.pending is not None and not self.tuned:
+        self._drained = True
       self.pending = self.handle = None
       cur = torch.cuda.current_stream(self.device)
       cur.wait_stream(self.s1)
