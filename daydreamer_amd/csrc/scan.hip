@@ -1132,6 +1132,28 @@ extern "C" int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* p
   return 0;
 }
 
+// Barrier counters back to zero before a scan launch: word 0 (all workgroups) and the four
+// row-block counters at 576 + 128 * block.  A KERNEL, not hipMemsetAsync: inside a captured graph
+// the memset nodes were the one thing in front of the scan that is not a kernel launch, and
+// (docs/LABLOG.md, end of round 6) a replayed scan was seen to run its row-block barriers on
+// counters that had not been cleared - barriers that let every workgroup through.
+__global__ void k_scan_reset(unsigned* sync2) {
+  if (threadIdx.x == 0) sync2[0] = 0;
+  sync2[576 + threadIdx.x] = 0;
+}
+static int reset_counters(unsigned* sync2, hipStream_t st, const char* what) {
+  static const int use_memset = getenv("DD_SCAN_MEMSET") ? atoi(getenv("DD_SCAN_MEMSET")) : 0;   // (A/B: the old form)
+  if (use_memset) {
+    hipError_t e = hipMemsetAsync(sync2, 0, sizeof(unsigned), st);
+    if (e == hipSuccess) e = hipMemsetAsync(sync2 + 576, 0, 512 * sizeof(unsigned), st);
+    if (e != hipSuccess) { dd_set_error(what, e); return (int)e; }
+    return 0;
+  }
+  k_scan_reset<<<1, 512, 0, st>>>(sync2);
+  DD_CHECK_LAUNCH(what);
+  return 0;
+}
+
 // The grid barrier needs all NWG workgroups resident at once (one per CU): on a device (or a
 // compute partition, e.g. CPX mode: 32 CUs) with fewer CUs the persistent kernels would spin
 // into their timeout, so such a device reports "unsupported" and the caller keeps the per-layer
@@ -1166,9 +1188,7 @@ extern "C" int dd_observe_scan_bwd(
   a.g3 = g3; a.gg = gg; a.bg = bg; a.g1 = g1;
   a.dfeat = dfeat; a.dxq = dxq; a.dxo = dxo; a.dzo = dzo; a.dz3 = dz3; a.dy3 = dy3; a.dgin = dgin;
   a.dz1 = dz1; a.dxs = dxs; a.ctr = sync2;
-  hipError_t e = hipMemsetAsync(sync2, 0, sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(sync2 + 576, 0, 512 * sizeof(unsigned), st);   // row-block counters
-  if (e != hipSuccess) { dd_set_error("dd_observe_scan_bwd(memset)", e); return (int)e; }
+  if (int rc = reset_counters(sync2, st, "dd_observe_scan_bwd(counters)")) return rc;
   if (D == 256 && U == 256 && G == 32 && C == 32)
     k_observe_scan_bwd<256, 256, 32, 32><<<NWG, 256, 0, st>>>(a);
   else
@@ -1215,6 +1235,8 @@ extern "C" int dd_observe_scan_fwd(
   a.B = B; a.T = T; a.D = D; a.U = U; a.G = G; a.C = C; a.A = A; a.S = G * C;
   a.XK = a.S + A; a.XKp = (a.XK + 31) / 32 * 32;
   a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 510); a.unimix = unimix;
+  static const int dbg_flags = getenv("DD_SCAN_FLAGS") ? atoi(getenv("DD_SCAN_FLAGS")) & 384 : 0;   // barrier protocol A/B (bits 7, 8)
+  a.use_carry |= dbg_flags;
   a.first = first; a.carry = carry; a.init_deter = init_deter; a.init_stoch = init_stoch;
   a.u_post = u_post;
   a.wt1 = (const unsigned short*)wt1; a.wt2 = (const unsigned short*)wt2;
@@ -1226,9 +1248,7 @@ extern "C" int dd_observe_scan_fwd(
   const long N = (long)B * T;
   a.idx = idx_ws; a.idx_carry = idx_ws + N * G; a.idx_init = idx_ws + (N + B) * G;
   a.nwg = NWG;
-  hipError_t e = hipMemsetAsync(sync2, 0, sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(sync2 + 576, 0, 512 * sizeof(unsigned), st);   // row-block counters
-  if (e != hipSuccess) { dd_set_error("dd_observe_scan_fwd(memset)", e); return (int)e; }
+  if (int rc = reset_counters(sync2, st, "dd_observe_scan_fwd(counters)")) return rc;
   if (a.use_carry & 1) {
     k_onehot_argmax<<<(B * G + 255) / 256, 256, 0, st>>>(carry + D, D + a.S, idx_ws + N * G, B, G, C, sync2 + 1);
     DD_CHECK_LAUNCH("dd_observe_scan_fwd(argmax carry)");

@@ -49,6 +49,7 @@ _EXECS = set()  # every live graph executable of the process: (device index, han
 _RETIRED = []   # executables of dropped plans, destroyed by the next capture on their device
 RECLAIM_THRESHOLD = int(os.environ.get('DD_GRAPH_RECLAIM', 32))
 _DESTROYED = [0]
+_DBG_SYNC = int(os.environ.get('DD_GRAPH_DBG_SYNC', 0))   # debugging: 1 drain after every graph segment, 2 after every cut function
 
 
 def stream(device, role):
@@ -221,11 +222,15 @@ class GraphPlan:
     for kind, item in self.items[start:stop]:
       if kind == 'graph':
         self._launch(item, stream)
+        if _DBG_SYNC & 1:
+          stream.synchronize()
       elif kind == 'cond':
         if item[0]():
           self._launch(item[1], stream)
       else:
         item()
+        if _DBG_SYNC & 2:
+          stream.synchronize()
 
   def replay(self):
     with API_LOCK:

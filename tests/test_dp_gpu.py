@@ -119,3 +119,19 @@ def test_two_ranks_pick_the_same_stream_pair(hip, tmp_path):
   print(r.stdout[-3000:])
   assert r.returncode == 0, r.stdout[-3000:]
   assert 'stream pair' in r.stdout
+
+
+@pytest.mark.parametrize('config', ['a1_vision', 'xarm'])
+def test_dp_training_reproducible_under_host_synchronisation(config):
+  """Two ranks sharing the GPU, 8 steps, ten agents in a row - the later ones drain the null
+  stream after every step: all ten end on the same losses and gradient norm, bit for bit.  (With the
+  fused observe scan's barrier counters cleared by hipMemsetAsync nodes inside the captured graph
+  this failed for 9 of 10: a replayed scan met counters of the launch before and its barriers
+  let every workgroup through; they are cleared by a kernel now - scan.hip reset_counters,
+  docs/LABLOG.md.)"""
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PERTURB='allsync', REPS='10', CFG=config)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', str(free_port()), str(ROOT / 'tools' / 'dp_repro.py')]
+  r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+  assert r.returncode == 0, r.stdout[-3000:]
+  assert '1 distinct outcome(s) in 10 runs' in r.stdout, r.stdout[-3000:]
