@@ -186,22 +186,30 @@ __device__ __forceinline__ float row_reduce(float s, float (*ws)[16]) {
 // bf16 planes) and the weight planes bq of every tile come from the caller (the planes are loaded
 // while the grid barrier before the phase completes); 6 MFMAs per k-step and tile; the four
 // waves' partial tiles are summed through LDS in wave order.  out[j] = the complete element (row ((t&63)>>4)*4 + (t>>6), col t&15) of tile j.
+// Plane layout (k_scan_wprep / k_scan_wprep_rows), FRAGMENT-MAJOR: [column tile n / 16][k-step of
+// 128][plane][thread 0..255] x 16 bytes - thread (wave w, lane l) finds the eight k values
+// k-step * 128 + w * 32 + (l >> 4) * 8 .. + 7 of column tile * 16 + (l & 15), i.e. its MFMA B fragment.
+// One load instruction of a wave reads 1 KB contiguous (8 full cache lines); with [plane][n][k] rows
+// it was 16 half lines, and the streamed phases at deter = units = 512 ran at 38 GB/s per CU where
+// the L2 -> CU path gives 130-180 with contiguous blocks (tools/probes/stream_probe.hip).
+__device__ __forceinline__ long plane_index(int n, int k, int p, int Kp) {
+  const int tile = n >> 4, r = n & 15, it = k >> 7, kk = k & 127, w = kk >> 5, q = (kk & 31) >> 3, e = kk & 7;
+  return ((((long)(tile * (Kp >> 7) + it) * 3 + p) * 4 + w) * 64 + (q * 16 + r)) * 8 + e;
+}
+
+// k-steps it0 .. it0 + NIT - 1 of the column tile that starts at n0
 template <int NIT>
-__device__ __forceinline__ void load_planes(uint4 (&bq)[NIT][3], const unsigned short* wt, long plane,
-                                            int KP, int n0) {
-  // wave-uniform base (tile, plane: scalar registers) + one 32-bit lane offset + immediates: the
-  // per-(tile, plane) 64-bit vector addresses this replaces were hoisted out of the time loop by
-  // the compiler and, for every tile of every phase, filled the register file
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned lane_off = (unsigned)(((lane & 15) * KP + (lane >> 4) * 8 + wave * 32) * 2);
+__device__ __forceinline__ void load_planes(uint4 (&bq)[NIT][3], const unsigned short* wt, int KP, int n0, int it0 = 0) {
+  // wave-uniform base (tile, k-step, plane: scalar registers) + one 32-bit thread offset: per-(tile,
+  // plane) 64-bit vector addresses would be hoisted out of the time loop by the compiler and, for
+  // every tile of every phase, fill the register file
+  const unsigned uoff = __builtin_amdgcn_readfirstlane((unsigned)(((n0 >> 4) * (KP >> 7) + it0) * (3 * 4096)));
+  const char* base = reinterpret_cast<const char*>(wt) + uoff;
+  const unsigned lane_off = threadIdx.x * 16u;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    // (32-bit scalar arithmetic: a 64-bit multiply has no scalar form and would drag the base into vector registers)
-    const unsigned uoff = __builtin_amdgcn_readfirstlane((unsigned)(n0 * KP + p * (int)plane) * 2u);
-    const char* base = reinterpret_cast<const char*>(wt) + uoff;
+  for (int it = 0; it < NIT; ++it)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) bq[it][p] = *reinterpret_cast<const uint4*>(base + lane_off + it * 256);
-  }
+    for (int p = 0; p < 3; ++p) bq[it][p] = *reinterpret_cast<const uint4*>(base + (it * 3 + p) * 4096 + lane_off);
 }
 
 template <int KP, int MAXT>
@@ -240,27 +248,33 @@ __device__ __forceinline__ void tiles_gemm(const bf16x8 (&af)[KP / 128][3], cons
 // (loaded during the grid barrier) - for phases whose tiles' planes together exceed the register
 // file (deter = units = 512: the GRU contraction has six 1024-deep tiles per workgroup).
 // n0[j]: first column of tile j.
-template <int KP, int MAXT, int NITC>
-__device__ __forceinline__ void tiles_gemm_stream(const bf16x8 (&af)[KP / 128][3], uint4 (&bq)[2][NITC][3],
-                                                  const unsigned short* wt, long plane,
+template <int KP, int MAXT, int NITC, int DEPTH = 2>
+__device__ __forceinline__ void tiles_gemm_stream(const bf16x8 (&af)[KP / 128][3], uint4 (&bq)[DEPTH][NITC][3],
+                                                  const unsigned short* wt,
                                                   const int (&n0)[MAXT], float (*red)[4][256],
                                                   float (&out)[MAXT]) {
+  // DEPTH units in registers: unit u + DEPTH - 1 is requested while unit u runs its MFMAs (a unit is
+  // 12 KB per wave).  With the fragment-major planes two units reach the L2 -> CU rate (590 KB of
+  // Q3's planes in 5.0 us = 118 GB/s per CU); deeper only costs registers.
   constexpr int NIT = KP / 128, H = NIT / NITC, NU = MAXT * H;
   static_assert(NIT % NITC == 0, "k-steps per unit");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();   // red[] free (the previous phase's readers are done)
+#pragma unroll
+  for (int v = 1; v < DEPTH - 1; ++v)
+    if (v < NU) load_planes<NITC>(bq[v], wt, KP, n0[v / H], (v % H) * NITC);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int j = u / H, h = u % H;
-    if (u + 1 < NU)
-      load_planes<NITC>(bq[(u + 1) & 1], wt + ((u + 1) % H) * NITC * 128, plane, KP, n0[(u + 1) / H]);
-    __builtin_amdgcn_sched_barrier(0);   // (no further hoisting: one unit ahead is what the registers hold)
+    const int j = u / H, h = u % H, v = u + DEPTH - 1;
+    if (v < NU)
+      load_planes<NITC>(bq[v % DEPTH], wt, KP, n0[v / H], (v % H) * NITC);
+    __builtin_amdgcn_sched_barrier(0);   // (no further hoisting: DEPTH - 1 units ahead is what the registers hold)
 #pragma unroll
     for (int it = 0; it < NITC; ++it) {
       bf16x8 b[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bq[u & 1][it][p]);
+      for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bq[u % DEPTH][it][p]);
       const int ia = h * NITC + it;
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ia][2], b[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ia][0], b[2], acc, 0, 0, 0);
@@ -286,6 +300,20 @@ constexpr int NWG = 64, NSTR = NWG / 4;   // 4 row blocks of 16 batch rows x 16 
 // row block has its own counter (sync2[576 + 128 m], 128 words apart behind the debug stamps; the
 // error word stays at sync2[1]).  Flag bit 7 of use_carry / flags selects the grid-wide counter
 // sync2[0] instead (A/B measurements, tools/scan_time.py).
+// Workgroup -> (row block, column stride).  Workgroups go to the 8 XCDs round-robin (wg % 8) and
+// every XCD has its own 4 MB L2.  Each XCD gets all four row blocks of TWO column strides, so it
+// streams 2 / 16 of every weight matrix: at deter = units = 512 that is 2.1 MB of planes per time
+// step, which stays in its L2 from step to step; with wg -> (wg & 3, wg >> 2) (flag bit 9) an XCD
+// held one row block and 8 strides, 8.6 MB per step - every step's weights came over the fabric
+// again (Q3 of the reverse scan: 16 us of its 26).  The 16 workgroups of a row block sit on all 8
+// XCDs either way they exchange through write-through stores.
+__device__ __forceinline__ void scan_wg_map(int wg, int old_map, int& mblk, int& nstr) {
+  if (old_map) { mblk = wg & 3; nstr = wg >> 2; return; }
+  const int x = wg & 7, k = wg >> 3;
+  mblk = k & 3;
+  nstr = x * 2 + (k >> 2);
+}
+
 #define RB_CTR(mblk) (bar_rb ? 576 + 128 * (mblk) : 0)
 #define RB_N (bar_rb ? NSTR : NWG)
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
@@ -304,6 +332,15 @@ __device__ __forceinline__ void store_chunks(const float (&v)[NIT][8], float* ro
       *reinterpret_cast<float4*>(q) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
       *reinterpret_cast<float4*>(q + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
     }
+  }
+}
+
+// one k-step of store_chunks
+__device__ __forceinline__ void store_chunk1(const float (&v)[8], float* rowp, int it, int kq, int nstr, bool live) {
+  if (live && ((it * 16 + (kq >> 3)) % NSTR) == nstr) {
+    float* q = rowp + it * 128 + kq;
+    *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
 }
 
@@ -349,7 +386,8 @@ k_observe_scan_fwd(ScanArgs a) {
   }
   if (threadIdx.x < G) cls_init[threadIdx.x] = a.idx_init[threadIdx.x];
   const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mblk = wg & 3, nstr = wg >> 2;
+  int mblk, nstr;
+  scan_wg_map(wg, a.use_carry & 512, mblk, nstr);
   const int T = a.T;
   const int orow = ((lane >> 4) * 4) + (tid >> 6), ocol = tid & 15;   // element of a finished tile
   const int ob = mblk * 16 + orow;                                    // its batch row
@@ -357,7 +395,6 @@ k_observe_scan_fwd(ScanArgs a) {
   const int ab = min(mblk * 16 + (lane & 15), a.B - 1);               // batch row of the A operand
   const bool alive = mblk * 16 + (lane & 15) < a.B;
   const int kq = (lane >> 4) * 8 + wave * 32;                         // this lane's k offset in a k-step
-  const long pl2 = (long)3 * D * (D + U), pl3 = (long)U * D, pl4 = (long)S * U;
   const bool bar_rb = !(a.use_carry & 128), bar_wt = !(a.use_carry & 256);
   unsigned gen = 0;
   if (a.use_carry & 2) {   // measurement aid: the barriers alone (4 per step), no work
@@ -457,9 +494,9 @@ k_observe_scan_fwd(ScanArgs a) {
     grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
       if constexpr (ALL2) {
 #pragma unroll
-        for (int j = 0; j < T2; ++j) load_planes<NIT2>(bq2[j], a.wt2, pl2, D + U, (nstr + NSTR * j) * 16);
+        for (int j = 0; j < T2; ++j) load_planes<NIT2>(bq2[j], a.wt2, D + U, (nstr + NSTR * j) * 16);
       } else {
-        load_planes<NITC2>(bq2[0], a.wt2, pl2, D + U, nstr * 16);
+        load_planes<NITC2>(bq2[0], a.wt2, D + U, nstr * 16);
       }
     });
     TS(2);
@@ -520,7 +557,7 @@ k_observe_scan_fwd(ScanArgs a) {
       float out[T2];
       TS(4);
       if constexpr (ALL2) tiles_gemm<KP, T2>(afr, bq2, red, out);
-      else tiles_gemm_stream<KP, T2, NITC2>(afr, bq2, a.wt2, pl2, n0, red, out);
+      else tiles_gemm_stream<KP, T2, NITC2>(afr, bq2, a.wt2, n0, red, out);
       TS(5);
 #pragma unroll
       for (int j = 0; j < T2; ++j)
@@ -530,7 +567,7 @@ k_observe_scan_fwd(ScanArgs a) {
     uint4 bq3[T3][NIT3][3];
     grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
 #pragma unroll
-      for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.wt3, pl3, D, (nstr + NSTR * j) * 16);
+      for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.wt3, D, (nstr + NSTR * j) * 16);
     });
     TS(7);
 
@@ -608,9 +645,9 @@ k_observe_scan_fwd(ScanArgs a) {
       if constexpr (ALL4) {
 #pragma unroll
         for (int j = 0; j < T4; ++j)
-          load_planes<NIT4>(bq4[j], a.wt4, pl4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
+          load_planes<NIT4>(bq4[j], a.wt4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
       } else {
-        load_planes<NITC4>(bq4[0], a.wt4, pl4, U, nstr * C);
+        load_planes<NITC4>(bq4[0], a.wt4, U, nstr * C);
       }
     });
     TS(12);
@@ -668,7 +705,7 @@ k_observe_scan_fwd(ScanArgs a) {
       float out[T4];
       TS(14);
       if constexpr (ALL4) tiles_gemm<U, T4>(afr, bq4, red, out);
-      else tiles_gemm_stream<U, T4, NITC4>(afr, bq4, a.wt4, pl4, n0, red, out);
+      else tiles_gemm_stream<U, T4, NITC4>(afr, bq4, a.wt4, n0, red, out);
       TS(15);
 #pragma unroll
       for (int j = 0; j < T4; ++j) {
@@ -820,12 +857,20 @@ __global__ void __launch_bounds__(256, 1)
 k_observe_scan_bwd(ScanBwdArgs a) {
   constexpr int S = G * C, F = D + S;
   static_assert(D % 128 == 0 && U % 128 == 0 && C % 16 == 0, "dims");
-  static_assert(U / 16 == NSTR && D / 16 == NSTR && G % NSTR == 0,
-                "one column tile per workgroup in Q1 / Q2, whole groups in Q4");
+  static_assert(U % (16 * NSTR) == 0 && D % (16 * NSTR) == 0 && G % NSTR == 0,
+                "whole column tiles per workgroup in Q1 / Q2, whole groups in Q4");
+  constexpr int T1 = U / 16 / NSTR, T2 = D / 16 / NSTR;   // Q1 / Q2 column tiles per workgroup
   constexpr int T3 = (D + U) / 16 / NSTR;        // Q3 column tiles per workgroup ([dh | dx1])
   constexpr int TPG = C / 16, GPP = G / NSTR, T4 = GPP * TPG;
-  constexpr int TMAX = cmax_(T3, T4);
+  constexpr int TMAX = cmax_(cmax_(T1, T2), cmax_(T3, T4));
   constexpr int NIT1 = S / 128, NIT2 = U / 128, NIT3 = 3 * D / 128, NIT4 = U / 128, ND = D / 128;
+  // weight planes of a phase: every tile in registers if they fit (deter = units = 256: all four
+  // phases), else streamed in units of four k-steps, two units in flight (tiles_gemm_stream;
+  // deter = units = 512: Q1, Q3, Q4 - Q3 alone would be 576 registers)
+  constexpr bool ALL1 = T1 * NIT1 <= 12, ALL2 = T2 * NIT2 <= 12, ALL3 = T3 * NIT3 <= 12, ALL4 = T4 * NIT4 <= 12;
+  constexpr int NITC1 = NIT1 % 4 == 0 ? 4 : NIT1, NITC3 = NIT3 % 4 == 0 ? 4 : NIT3, NITC4 = NIT4 % 4 == 0 ? 4 : NIT4;
+  static_assert(ALL2, "Q2's planes are expected to fit");
+  constexpr int DEPTH3 = 2;   // units of Q3's stream in registers (3: 36 spilled registers, 4: 100 - both slower: 1.15 / 1.18 / 1.35 ms at xarm's T = 32)
   __shared__ float red[TMAX][4][256];
   constexpr int O_G3 = 0, O_GG = U, O_BG = O_GG + 3 * D, O_G1 = O_BG + 3 * D, NPAR = O_G1 + U;
   __shared__ __attribute__((aligned(16))) float par[NPAR];
@@ -840,7 +885,8 @@ k_observe_scan_bwd(ScanBwdArgs a) {
     par[i] = v;
   }
   const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mblk = wg & 3, nstr = wg >> 2;
+  int mblk, nstr;
+  scan_wg_map(wg, a.flags & 512, mblk, nstr);
   const int T = a.T;
   const int orow = ((lane >> 4) * 4) + (tid >> 6), ocol = tid & 15;
   const int ob = mblk * 16 + orow;
@@ -848,13 +894,20 @@ k_observe_scan_bwd(ScanBwdArgs a) {
   const int ab = min(mblk * 16 + (lane & 15), a.B - 1);
   const bool alive = mblk * 16 + (lane & 15) < a.B;
   const int kq = (lane >> 4) * 8 + wave * 32;
-  const long pl1 = (long)U * S, pl2 = (long)D * U, pl3 = (long)(D + U) * 3 * D, pl4 = (long)S * U;
   const float um = 1.f - a.unimix;
   const bool bar_rb = !(a.flags & 128), bar_wt = !(a.flags & 256);
   unsigned gen = 0;
   __syncthreads();
-  uint4 bq1[1][NIT1][3];
-  load_planes<NIT1>(bq1[0], a.w1, pl1, S, nstr * 16);
+  uint4 bq1[ALL1 ? T1 : 2][ALL1 ? NIT1 : NITC1][3];
+  auto load_q1 = [&] {
+    if constexpr (ALL1) {
+#pragma unroll
+      for (int j = 0; j < T1; ++j) load_planes<NIT1>(bq1[j], a.w1, S, (nstr + NSTR * j) * 16);
+    } else {
+      load_planes<NITC1>(bq1[0], a.w1, S, nstr * 16);
+    }
+  };
+  load_q1();
   for (int t = T - 1; t >= 0; --t) {
     const long arow = (long)ab * T + t;
     const long oidx = (long)ob * T + t;
@@ -867,13 +920,22 @@ k_observe_scan_bwd(ScanBwdArgs a) {
       bf16x8 afr[NIT1][3];
 #pragma unroll
       for (int it = 0; it < NIT1; ++it) split8(raw[it], afr[it]);
-      float out[1];
-      tiles_gemm<S, 1>(afr, bq1, red, out);
-      if (olive) st_wt(a.dxo + oidx * U + nstr * 16 + ocol, out[0]);
+      int n0[T1];
+#pragma unroll
+      for (int j = 0; j < T1; ++j) n0[j] = (nstr + NSTR * j) * 16;
+      float out[T1];
+      if constexpr (ALL1) tiles_gemm<S, T1>(afr, bq1, red, out);
+      else tiles_gemm_stream<S, T1, NITC1>(afr, bq1, a.w1, n0, red, out);
+#pragma unroll
+      for (int j = 0; j < T1; ++j)
+        if (olive) st_wt(a.dxo + oidx * U + n0[j] + ocol, out[j]);
     }
     TSB(1);
-    uint4 bq2[1][NIT2][3];
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] { load_planes<NIT2>(bq2[0], a.w2, pl2, U, nstr * 16); });
+    uint4 bq2[T2][NIT2][3];
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
+#pragma unroll
+      for (int j = 0; j < T2; ++j) load_planes<NIT2>(bq2[j], a.w2, U, (nstr + NSTR * j) * 16);
+    });
     TSB(2);
 
     // ---------------- Q2: dzo = LN-ELU'(dxo);  ddeter_t += dzo @ W_out_h^T
@@ -885,21 +947,29 @@ k_observe_scan_bwd(ScanBwdArgs a) {
         ld8(a.dxo + arow * U + k, dy[it]); ld8(a.zo + arow * U + k, z[it]); ld8(a.xo + arow * U + k, o[it]);
       }
       const float2 st = *reinterpret_cast<const float2*>(a.st3 + arow * 2);
-      const float dold = olive ? a.dfeat[oidx * F + nstr * 16 + ocol] : 0.f;
+      float dold[T2];
+#pragma unroll
+      for (int j = 0; j < T2; ++j) dold[j] = olive ? a.dfeat[oidx * F + (nstr + NSTR * j) * 16 + ocol] : 0.f;
       ln_elu_bwd<U, NIT2>(dy, z, o, st.x, st.y, par + O_G3, kq, ws_a, dz);
       store_chunks<NIT2>(dz, a.dzo + arow * U, kq, nstr, alive);
       bf16x8 afr[NIT2][3];
 #pragma unroll
       for (int it = 0; it < NIT2; ++it) split8(dz[it], afr[it]);
-      float out[1];
-      tiles_gemm<U, 1>(afr, bq2, red, out);
-      if (olive) st_wt(a.dfeat + oidx * F + nstr * 16 + ocol, dold + out[0]);
+      float out[T2];
+      tiles_gemm<U, T2>(afr, bq2, red, out);
+#pragma unroll
+      for (int j = 0; j < T2; ++j)
+        if (olive) st_wt(a.dfeat + oidx * F + (nstr + NSTR * j) * 16 + ocol, dold[j] + out[j]);
     }
     TSB(3);
-    uint4 bq3[T3][NIT3][3];
+    uint4 bq3[ALL3 ? T3 : DEPTH3][ALL3 ? NIT3 : NITC3][3];
     grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
+      if constexpr (ALL3) {
 #pragma unroll
-      for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.w3, pl3, 3 * D, (nstr + NSTR * j) * 16);
+        for (int j = 0; j < T3; ++j) load_planes<NIT3>(bq3[j], a.w3, 3 * D, (nstr + NSTR * j) * 16);
+      } else {
+        load_planes<NITC3>(bq3[0], a.w3, 3 * D, nstr * 16);
+      }
     });
     TSB(4);
 
@@ -923,12 +993,12 @@ k_observe_scan_bwd(ScanBwdArgs a) {
         const int col = (nstr + NSTR * j) * 16 + ocol;
         dprev[j] = (olive && t > 0 && col < D) ? a.dfeat[(oidx - 1) * F + col] : 0.f;
       }
-      float dy[NIT3][8], xh[NIT3][8], g[NIT3][8], dhd[ND][8];   // index q * ND + it: gate q
+      float xh[NIT3][8], g[NIT3][8];   // index q * ND + it: gate q
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int it = 0; it < ND; ++it) {
         const int k = it * 128 + kq;
-        float g0[8], g1_[8], g2[8], b0[8], b1_[8], b2[8];
+        float g0[8], g1_[8], g2[8], b0[8], b1_[8], b2[8], dhd[8], dyr_[8], dyc_[8], dyu_[8];
         ld8(par + O_GG + k, g0); ld8(par + O_GG + D + k, g1_); ld8(par + O_GG + 2 * D + k, g2);
         ld8(par + O_BG + k, b0); ld8(par + O_BG + D + k, b1_); ld8(par + O_BG + 2 * D + k, b2);
 #pragma unroll
@@ -939,37 +1009,51 @@ k_observe_scan_bwd(ScanBwdArgs a) {
           const float r = fsigmoid_(yr), cand = ftanh_(r * yc), u = fsigmoid_(yu - 1.f);
           const float dd = d[it][j];
           const float du = dd * (cand - hp[it][j]), dc = dd * u;
-          dhd[it][j] = dd * (1.f - u);
+          dhd[j] = dd * (1.f - u);
           const float dpre = dc * (1.f - cand * cand);
           const float dyc = dpre * r, dyr = dpre * yc * r * (1.f - r), dyu = du * u * (1.f - u);
-          dy[it][j] = dyr; dy[ND + it][j] = dyc; dy[2 * ND + it][j] = dyu;
+          dyr_[j] = dyr; dyc_[j] = dyc; dyu_[j] = dyu;
           xh[it][j] = xr; xh[ND + it][j] = xc; xh[2 * ND + it][j] = xu;
           g[it][j] = dyr * g0[j]; g[ND + it][j] = dyc * g1_[j]; g[2 * ND + it][j] = dyu * g2[j];
           s1 += (g[it][j] + g[ND + it][j]) + g[2 * ND + it][j];
           s2 += (g[it][j] * xr + g[ND + it][j] * xc) + g[2 * ND + it][j] * xu;
         }
+        // (side outputs leave the registers at once: at deter = 512 the row-wise arrays of this
+        // phase are 96 registers each)
+        store_chunk1(dyr_, a.dy3 + arow * 3 * D, it, kq, nstr, alive);
+        store_chunk1(dyc_, a.dy3 + arow * 3 * D, ND + it, kq, nstr, alive);
+        store_chunk1(dyu_, a.dy3 + arow * 3 * D, 2 * ND + it, kq, nstr, alive);
+        // the direct path (1 - update) * dhn of the whole row block, for the tile epilogue (the
+        // previous step's readers are behind a grid barrier; the contraction's barriers order
+        // these writes before this step's reads)
+        float* q = &dh_lds[lane & 15][k];
+        *reinterpret_cast<float4*>(q) = make_float4(dhd[0], dhd[1], dhd[2], dhd[3]);
+        *reinterpret_cast<float4*>(q + 4) = make_float4(dhd[4], dhd[5], dhd[6], dhd[7]);
       }
-      store_chunks<NIT3>(dy, a.dy3 + arow * 3 * D, kq, nstr, alive);
+      TSB(9);
       row_reduce2(s1, s2, ws_b);
       s1 /= (float)(3 * D); s2 /= (float)(3 * D);
-      float dz[NIT3][8];
       bf16x8 afr[NIT3][3];
 #pragma unroll
       for (int i = 0; i < NIT3; ++i) {
+        float dz[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dz[i][j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
-        split8(dz[i], afr[i]);
+        for (int j = 0; j < 8; ++j) dz[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        split8(dz, afr[i]);
+        store_chunk1(dz, a.dz3 + arow * 3 * D, i, kq, nstr, alive);
       }
-      store_chunks<NIT3>(dz, a.dz3 + arow * 3 * D, kq, nstr, alive);
-      // the direct path (1 - update) * dhn of the whole row block, for the tile epilogue
-#pragma unroll
-      for (int it = 0; it < ND; ++it) {
-        float* q = &dh_lds[lane & 15][it * 128 + kq];
-        *reinterpret_cast<float4*>(q) = make_float4(dhd[it][0], dhd[it][1], dhd[it][2], dhd[it][3]);
-        *reinterpret_cast<float4*>(q + 4) = make_float4(dhd[it][4], dhd[it][5], dhd[it][6], dhd[it][7]);
-      }
+      TSB(10);
       float out[T3];
-      tiles_gemm<3 * D, T3>(afr, bq3, red, out);   // (its barriers order the dh_lds writes before the reads)
+      // (the contraction's barriers order the dh_lds writes before the reads)
+      if constexpr (ALL3) {
+        tiles_gemm<3 * D, T3>(afr, bq3, red, out);
+      } else {
+        int n0[T3];
+#pragma unroll
+        for (int j = 0; j < T3; ++j) n0[j] = (nstr + NSTR * j) * 16;
+        tiles_gemm_stream<3 * D, T3, NITC3, DEPTH3>(afr, bq3, a.w3, n0, red, out);
+      }
+      TSB(11);
 #pragma unroll
       for (int j = 0; j < T3; ++j) {
         const int col = (nstr + NSTR * j) * 16 + ocol;
@@ -985,11 +1069,15 @@ k_observe_scan_bwd(ScanBwdArgs a) {
       }
     }
     TSB(5);
-    uint4 bq4[T4][NIT4][3];
+    uint4 bq4[ALL4 ? T4 : 2][ALL4 ? NIT4 : NITC4][3];
     grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] {
+      if constexpr (ALL4) {
 #pragma unroll
-      for (int j = 0; j < T4; ++j)
-        load_planes<NIT4>(bq4[j], a.w4, pl4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
+        for (int j = 0; j < T4; ++j)
+          load_planes<NIT4>(bq4[j], a.w4, U, (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16);
+      } else {
+        load_planes<NITC4>(bq4[0], a.w4, U, nstr * C);
+      }
     });
     TSB(6);
 
@@ -1020,7 +1108,14 @@ k_observe_scan_bwd(ScanBwdArgs a) {
 #pragma unroll
       for (int it = 0; it < NIT4; ++it) split8(dz[it], afr[it]);
       float out[T4];
-      tiles_gemm<U, T4>(afr, bq4, red, out);
+      if constexpr (ALL4) {
+        tiles_gemm<U, T4>(afr, bq4, red, out);
+      } else {
+        int n0[T4];
+#pragma unroll
+        for (int j = 0; j < T4; ++j) n0[j] = (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16;
+        tiles_gemm_stream<U, T4, NITC4>(afr, bq4, a.w4, n0, red, out);
+      }
 #pragma unroll
       for (int j = 0; j < T4; ++j) {
         const int col = (nstr + NSTR * (j / TPG)) * C + (j % TPG) * 16 + ocol;
@@ -1064,7 +1159,7 @@ k_observe_scan_bwd(ScanBwdArgs a) {
       }
     }
     TSB(7);
-    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, [&] { load_planes<NIT1>(bq1[0], a.w1, pl1, S, nstr * 16); });
+    grid_barrier(a.ctr + RB_CTR(mblk), a.ctr + 1, ++gen * RB_N, bar_wt, load_q1);
     TSB(8);
   }
 }
@@ -1089,24 +1184,25 @@ __global__ void k_onehot_argmax(const float* __restrict__ x, long ldx, int* __re
   idx[i] = ones == 1 ? best : -1;
 }
 
-// Weight cache: W [K, N] fp32 (row stride ld) -> three bf16 planes [3][N][Kp], exact 3-way
-// split, zero beyond K.
+// Weight cache: W [K, N] fp32 (row stride ld) -> three bf16 planes of N x Kp values, exact 3-way
+// split, zero beyond K, in the fragment-major order of plane_index (N % 16 == 0, Kp % 128 == 0).
 __global__ void k_scan_wprep(const float* __restrict__ W, long ld, int K, int N, int Kp,
                              unsigned short* __restrict__ out) {
   const long total = (long)N * Kp;
+  // (consecutive threads: consecutive n of one k - W's rows are read coalesced)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
+    const int k = (int)(i / N), n = (int)(i - (long)k * N);
     const float x = k < K ? W[(long)k * ld + n] : 0.f;
     unsigned h, m, l;
     split3(x, h, m, l);
-    out[i] = (unsigned short)(h >> 16);
-    out[total + i] = (unsigned short)(m >> 16);
-    out[2 * total + i] = (unsigned short)(l >> 16);
+    out[plane_index(n, k, 0, Kp)] = (unsigned short)(h >> 16);
+    out[plane_index(n, k, 1, Kp)] = (unsigned short)(m >> 16);
+    out[plane_index(n, k, 2, Kp)] = (unsigned short)(l >> 16);
   }
 }
 
 // Weight cache of the reverse scan: W [N, K] fp32 (row stride ld; the backward contraction
-// multiplies by W^T, so the cache rows are W's rows) -> three bf16 planes [3][N][K].
+// multiplies by W^T, so the cache's columns are W's rows) -> three bf16 planes, same order.
 __global__ void k_scan_wprep_rows(const float* __restrict__ W, long ld, int N, int K,
                                   unsigned short* __restrict__ out) {
   const long total = (long)N * K;
@@ -1114,16 +1210,16 @@ __global__ void k_scan_wprep_rows(const float* __restrict__ W, long ld, int N, i
     const int n = (int)(i / K), k = (int)(i - (long)n * K);
     unsigned h, m, l;
     split3(W[(long)n * ld + k], h, m, l);
-    out[i] = (unsigned short)(h >> 16);
-    out[total + i] = (unsigned short)(m >> 16);
-    out[2 * total + i] = (unsigned short)(l >> 16);
+    out[plane_index(n, k, 0, K)] = (unsigned short)(h >> 16);
+    out[plane_index(n, k, 1, K)] = (unsigned short)(m >> 16);
+    out[plane_index(n, k, 2, K)] = (unsigned short)(l >> 16);
   }
 }
 
 }  // namespace
 
 extern "C" int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* planes, void* stream) {
-  DD_REQUIRE(N > 0 && K > 0 && K % 8 == 0, "dd_scan_wprep_rows: shape");
+  DD_REQUIRE(N > 0 && K > 0 && K % 128 == 0 && N % 16 == 0, "dd_scan_wprep_rows: N multiple of 16, K multiple of 128");
   const long total = (long)N * K;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
@@ -1140,6 +1236,11 @@ extern "C" int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* p
 __global__ void k_scan_reset(unsigned* sync2) {
   if (threadIdx.x == 0) sync2[0] = 0;
   sync2[576 + threadIdx.x] = 0;
+}
+// DD_SCAN_FLAGS: A/B of the barrier protocol (bits 7, 8) and of the workgroup map (bit 9)
+static int scan_dbg_flags() {
+  static const int f = getenv("DD_SCAN_FLAGS") ? atoi(getenv("DD_SCAN_FLAGS")) & 896 : 0;
+  return f;
 }
 static int reset_counters(unsigned* sync2, hipStream_t st, const char* what) {
   static const int use_memset = getenv("DD_SCAN_MEMSET") ? atoi(getenv("DD_SCAN_MEMSET")) : 0;   // (A/B: the old form)
@@ -1166,7 +1267,7 @@ static bool scan_device_ok() {
 }
 
 extern "C" int dd_observe_scan_bwd_supported(int B, int D, int U, int G, int C) {
-  return B >= 1 && B <= 64 && D == 256 && U == 256 && G == 32 && C == 32 && scan_device_ok();
+  return B >= 1 && B <= 64 && ((D == 256 && U == 256) || (D == 512 && U == 512)) && G == 32 && C == 32 && scan_device_ok();
 }
 
 extern "C" int dd_observe_scan_bwd(
@@ -1188,9 +1289,12 @@ extern "C" int dd_observe_scan_bwd(
   a.g3 = g3; a.gg = gg; a.bg = bg; a.g1 = g1;
   a.dfeat = dfeat; a.dxq = dxq; a.dxo = dxo; a.dzo = dzo; a.dz3 = dz3; a.dy3 = dy3; a.dgin = dgin;
   a.dz1 = dz1; a.dxs = dxs; a.ctr = sync2;
+  a.flags |= scan_dbg_flags();
   if (int rc = reset_counters(sync2, st, "dd_observe_scan_bwd(counters)")) return rc;
   if (D == 256 && U == 256 && G == 32 && C == 32)
     k_observe_scan_bwd<256, 256, 32, 32><<<NWG, 256, 0, st>>>(a);
+  else if (D == 512 && U == 512 && G == 32 && C == 32)
+    k_observe_scan_bwd<512, 512, 32, 32><<<NWG, 256, 0, st>>>(a);
   else
     DD_REQUIRE(false, "dd_observe_scan_bwd: shape not compiled");
   DD_CHECK_LAUNCH("dd_observe_scan_bwd");
@@ -1198,7 +1302,7 @@ extern "C" int dd_observe_scan_bwd(
 }
 
 extern "C" int dd_scan_wprep(const float* W, long ld, int K, int N, int Kp, void* planes, void* stream) {
-  DD_REQUIRE(Kp >= K && Kp % 32 == 0 && N % 16 == 0, "dd_scan_wprep: Kp multiple of 32 >= K, N multiple of 16");
+  DD_REQUIRE(Kp >= K && Kp % 128 == 0 && N % 16 == 0, "dd_scan_wprep: Kp multiple of 128 >= K, N multiple of 16");
   const long total = (long)N * Kp;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -1234,9 +1338,8 @@ extern "C" int dd_observe_scan_fwd(
   ScanArgs a;
   a.B = B; a.T = T; a.D = D; a.U = U; a.G = G; a.C = C; a.A = A; a.S = G * C;
   a.XK = a.S + A; a.XKp = (a.XK + 31) / 32 * 32;
-  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 510); a.unimix = unimix;
-  static const int dbg_flags = getenv("DD_SCAN_FLAGS") ? atoi(getenv("DD_SCAN_FLAGS")) & 384 : 0;   // barrier protocol A/B (bits 7, 8)
-  a.use_carry |= dbg_flags;
+  a.use_carry = ((use_carry & 1) && carry != nullptr ? 1 : 0) | (use_carry & 1022); a.unimix = unimix;
+  a.use_carry |= scan_dbg_flags();
   a.first = first; a.carry = carry; a.init_deter = init_deter; a.init_stoch = init_stoch;
   a.u_post = u_post;
   a.wt1 = (const unsigned short*)wt1; a.wt2 = (const unsigned short*)wt2;

@@ -52,7 +52,7 @@ def test_persistent_scan_shape_queries():
   assert fwd(64, 256, 256, 32, 32, 16) == 1 and fwd(1, 256, 256, 32, 32, 6) == 1
   assert fwd(65, 256, 256, 32, 32, 16) == 0 and bwd(65, 256, 256, 32, 32) == 0      # > 4 row blocks of 16
   assert fwd(0, 256, 256, 32, 32, 16) == 0
-  assert fwd(25, 512, 512, 32, 32, 6) == 1 and bwd(25, 512, 512, 32, 32) == 0       # xarm / ur5: forward only
+  assert fwd(25, 512, 512, 32, 32, 6) == 1 and bwd(25, 512, 512, 32, 32) == 1       # xarm / ur5: weight planes streamed
   assert fwd(32, 4096, 256, 64, 64, 16) == 0 and bwd(32, 4096, 256, 64, 64) == 0    # a1_scaled: launch sequence
   assert fwd(16, 128, 128, 8, 32, 6) == 0
 

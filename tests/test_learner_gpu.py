@@ -425,13 +425,21 @@ def test_fused_imagination_reverse_equals_launch_sequence(hip, rows):
 def test_fused_reverse_scan_equals_launch_sequence(hip):
   """csrc/scan.hip k_observe_scan_bwd: the data gradient of the T obs_steps as ONE persistent
   launch against the per-layer launch sequence, on the same forward state and the same incoming
-  gradients (random dfeat / KL gradients), at the full configs[1] size and on a ragged batch:
+  gradients (random dfeat / KL gradients), at the full configs[1] size, on a ragged batch and at
+  deter = units = 512 (the xarm / ur5 blocks; weight planes streamed):
   every buffer the bulk weight-gradient contractions read and the resulting parameter
   gradients agree to float reassociation (and the hardware exp2 / reciprocal forms of the gates)."""
-  for (B, T, first_mid) in ((50, 50, False), (21, 7, True), (64, 3, False), (1, 2, False)):
-    cfg = helpers.make_config(('a1_vision',), batch_size=B, replay_chunk=T)
-    plain, sp, shapes, params, data, _, _ = helpers.make_problem(
-        cfg, image=64, vector=16, action=16, terminals=0.02, smooth=True)
+  for (name, B, T, first_mid) in (('a1_vision', 50, 50, False), ('a1_vision', 21, 7, True), ('a1_vision', 64, 3, False),
+                                  ('a1_vision', 1, 2, False), ('xarm', 25, 50, False), ('xarm', 21, 7, True)):
+    cfg = helpers.make_config((name,), batch_size=B, replay_chunk=T)
+    if name == 'xarm':   # deter = units = 512: the variant of the kernel that streams its weight planes
+      cfg = cfg.update({'encoder.mlp_keys': 'vector', 'decoder.mlp_keys': 'vector',
+                        'encoder.cnn_keys': 'image', 'decoder.cnn_keys': 'image'})
+      plain, sp, shapes, params, data, _, _ = helpers.make_problem(
+          cfg, image=64, vector=20, action=6, terminals=0.02, smooth=True, discrete=True)
+    else:
+      plain, sp, shapes, params, data, _, _ = helpers.make_problem(
+          cfg, image=64, vector=16, action=16, terminals=0.02, smooth=True)
     if first_mid:
       data['is_first'][3, 4] = True
       data['is_first'][20, 2] = True
@@ -465,7 +473,7 @@ def test_fused_reverse_scan_equals_launch_sequence(hip):
     for k in got[0]:
       x, y = got[0][k].double(), got[1][k].double()
       err = float((x - y).abs().max() / (y.abs().max() + 1e-30))
-      print(f'reverse scan B{B} T{T} {k}: {err:.2e}')
+      print(f'reverse scan {name} B{B} T{T} {k}: {err:.2e}')
       assert err < 2e-5, (k, err)
     del L, got
     torch.cuda.empty_cache()

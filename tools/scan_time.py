@@ -49,7 +49,7 @@ def scan(flag):
       P['img_in'].W, L.scan_idx, L.scan_sync)
 
 
-timed('weight planes (4 x dd_scan_wprep)', lambda: [ops.scan_wprep(W, p, k) for W, p, k in L.scan_w])
+timed('weight planes (3 x dd_scan_wprep)', lambda: [ops.scan_wprep(W, p, k) for W, p, k in L.scan_w[1:]])
 timed('fused scan, full (T = %d steps)' % T, lambda: scan(1))
 timed('fused scan, full, grid-wide barrier counter (flag 128)', lambda: scan(1 | 128))
 timed('fused scan, full, release fence at every arrival (flag 256)', lambda: scan(1 | 256))
@@ -81,7 +81,7 @@ arr = L.scan_sync[64:64 + 2 * 4 * 64].view(torch.int64).cpu().numpy().reshape(64
 print('arrival of the workgroups at the 4 barriers of step 10 (us after the first arrival): median / last; slowest workgroup')
 for i in range(4):
   d = (arr[:, i] - arr[:, i].min()) / 100
-  print(f'  barrier {i + 1}: {np.median(d):5.2f} {d.max():5.2f}  wg {int(d.argmax())} (row block {int(d.argmax()) & 3}, stride {int(d.argmax()) >> 2});'
+  print(f'  barrier {i + 1}: {np.median(d):5.2f} {d.max():5.2f}  wg {int(d.argmax())} (wg {int(d.argmax())});'
         f' released {(ts[[2, 7, 12, 18][i]] - arr[:, i].max()) / 100:5.2f} us after the last arrival')
 
 
@@ -125,9 +125,11 @@ for fused in (False, True):
 reseed()
 scan_bwd(64)
 torch.cuda.synchronize()
-ts = L.scan_sync[2:2 + 20].view(torch.int64).cpu().numpy()
+ts = L.scan_sync[2:2 + 24].view(torch.int64).cpu().numpy()
 names = ['start', 'Q1 dxo', 'barrier 1', 'Q2 ln + dgrad', 'barrier 2', 'Q3 gru + dgrad', 'barrier 3', 'Q4 ln + dgrad + stats', 'barrier 4']
 print('reverse scan, step 10, workgroup 0 (us since step start / delta):')
 for i in range(1, 9):
   print(f'  {names[i]:24s} {(ts[i] - ts[0]) / 100:7.2f} {(ts[i] - ts[i - 1]) / 100:6.2f}')
+print(f'  inside Q3: loads + gate derivatives {(ts[9] - ts[4]) / 100:.2f}, row sums + operand split {(ts[10] - ts[9]) / 100:.2f}, '
+      f'contraction {(ts[11] - ts[10]) / 100:.2f}, epilogue {(ts[5] - ts[11]) / 100:.2f} us')
 print('error word', int(L.scan_sync[1]))
