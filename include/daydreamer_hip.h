@@ -252,13 +252,18 @@ int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, long ldz,
  * z1 / st1 / gin (= [hprev | x1]), z3 / gst, post (= [deter | stoch]), zo / xo / st3, xq,
  * post_logit.  The draw is the shared sampler (latent_core.h): same indices as
  * dd_stats_sample_fwd / dd_onehot_sample_host given the same statistics.
- * wt1..wt4: weight caches from dd_scan_wprep for img_in [U][pad32(S+A)], gru_out [3D][D+U],
- * obs_out[:D] [U][D], obs_stats [S][U].  sync2: 1088 zero-initialised device words - [0] grid-wide
+ * wt2..wt4: weight caches from dd_scan_wprep for gru_out (N = 3D columns, Kp = D+U), obs_out[:D]
+ * (U, D), obs_stats (S, U); wt1 is not read (img_in's one-hot part is a gather of w_in's rows).
+ * The cache holds three bf16 planes (exact 3-way split of the fp32 weight) in FRAGMENT-MAJOR order:
+ * [column tile n/16][k-step k/128][plane][thread 0..255] x 8 values, thread (wave w, lane l) holding
+ * k = k-step*128 + w*32 + (l>>4)*8 .. +7 of column tile*16 + (l&15) - a wave's 16-byte load is 1 KB
+ * contiguous.  N % 16 == 0, Kp % 128 == 0, 3*N*Kp values.  sync2: 1088 zero-initialised device words - [0] grid-wide
  * barrier counter (use_carry bit 7 selects it; bit 8: release fence at every arrival instead of
  * write-through stores - measurement aids), [1] error word, [2, 576) time
  * stamps of the measurement flag, [576 + 128 m] the barrier counter of row block m (a phase only
  * consumes what the 16 workgroups of its own 16-row block produced, so the blocks synchronise
- * separately).  The launch resets the counters only; the error word is sticky (bit 0: a
+ * separately; use_carry bit 9: the older workgroup -> (row block, stride) map, a measurement aid).
+ * The launch resets the counters only (by a kernel - never a memset node in a captured graph); the error word is sticky (bit 0: a
  * bounded grid-barrier spin timed out, bit 1: a carried / initial stoch group was not one-hot):
  * the host reads it after the step, raises on non-zero and clears it.  w_in: the
  * img_in kernel itself [S+A, U] (the one-hot stoch part of that layer is a gather of its rows);
@@ -280,8 +285,9 @@ int dd_observe_scan_fwd(
     float* xo, float* st3, float* xq, float* post_logit, const float* w_in, int* idx_ws,
     unsigned* sync2, void* stream);
 
-/* Weight cache of the reverse scan: W [N, K] fp32 (row stride ld) -> bf16 planes [3][N][K]
- * (the backward contractions multiply by W^T: cache rows = W's rows). */
+/* Weight cache of the reverse scan: W [N, K] fp32 (row stride ld) -> three bf16 planes in the
+ * fragment-major order of dd_scan_wprep with column n = W's row n (the backward contractions
+ * multiply by W^T); N % 16 == 0, K % 128 == 0. */
 int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* planes, void* stream);
 
 /* Fused reverse observe scan: the data gradient of the T obs_steps (what tf.GradientTape derives
@@ -293,8 +299,8 @@ int dd_scan_wprep_rows(const float* W, long ld, int N, int K, void* planes, void
  * dz3, dy3, dgin = [dh | dx1], dz1, dxs hold what the bulk weight-gradient contractions read.
  * w1..w4: dd_scan_wprep_rows planes of obs_stats [U,S], obs_out (deter rows) [D,U], gru [D+U,3D],
  * img_in (stoch rows) [S,U].  flags bit 6: time stamps (measurement aid).  sync2: as in the
- * forward scan.  Shapes: dd_observe_scan_bwd_supported (deter = units = 256, 32 x 32 latents;
- * the forward scan is also compiled for 512). */
+ * forward scan.  Shapes: dd_observe_scan_bwd_supported (deter = units = 256 or 512, 32 x 32 latents;
+ * at 512 the planes of three of the four phases are streamed instead of held in registers). */
 int dd_observe_scan_bwd_supported(int B, int D, int U, int G, int C);
 int dd_observe_scan_bwd(
     int B, int T, int D, int U, int G, int C, int flags, float unimix, const float* first,
