@@ -10,6 +10,7 @@
 //     while the process runs (round-2 crash: executables dropped by one agent, then capture +
 //     replay by the next agent died inside hipGraphLaunch).
 #include "dd_common.h"
+#include <vector>
 #include "../../include/daydreamer_hip.h"
 #include <execinfo.h>
 #include <signal.h>
@@ -64,6 +65,41 @@ extern "C" int dd_graph_capture_end(void* stream, void** exec_out, int* nodes_ou
     return (int)e;
   }
   if (nodes_out) *nodes_out = (int)n;
+  // A captured segment holds kernel launches only (and the empty nodes of stream joins).  A memset
+  // or copy node is refused: replayed next to a second process on the GPU, a memset node in front
+  // of a kernel was not reliably complete before it (the fused observe scan's barrier counters,
+  // docs/LABLOG.md end of round 6) - such work belongs in a kernel.  DD_GRAPH_ALLOW_NONKERNEL=1
+  // turns the refusal into a message on stderr.
+  if (n > 0) {
+    std::vector<hipGraphNode_t> nodes(n);
+    size_t m = n;
+    e = hipGraphGetNodes(graph, nodes.data(), &m);
+    int other = 0, first_type = -1;
+    for (size_t i = 0; e == hipSuccess && i < m; ++i) {
+      hipGraphNodeType ty = hipGraphNodeTypeKernel;
+      e = hipGraphNodeGetType(nodes[i], &ty);
+      if (e == hipSuccess && ty != hipGraphNodeTypeKernel && ty != hipGraphNodeTypeEmpty) {
+        if (!other) first_type = (int)ty;
+        ++other;
+      }
+    }
+    if (e != hipSuccess) {
+      (void)hipGraphDestroy(graph);
+      dd_set_error("dd_graph_capture_end(node types)", e);
+      return (int)e;
+    }
+    if (other) {
+      static const int allow = getenv("DD_GRAPH_ALLOW_NONKERNEL") ? atoi(getenv("DD_GRAPH_ALLOW_NONKERNEL")) : 0;
+      char msg[160];
+      snprintf(msg, sizeof(msg), "dd_graph_capture_end: %d of %zu captured nodes are not kernel launches (first: hipGraphNodeType %d)",
+               other, m, first_type);
+      if (!allow) {
+        (void)hipGraphDestroy(graph);
+        DD_REQUIRE(false, msg);
+      }
+      fprintf(stderr, "libdaydreamer_hip: %s\n", msg);
+    }
+  }
   if (n > 0) {
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

@@ -179,9 +179,17 @@ class GraphPlan:
         self._begin()
         try:
           fn()
-        finally:
+        except BaseException:
+          # close the capture without hiding what went wrong (a failed _end inside cut() has already
+          # ended it: a second end would raise "illegal state" over the real message)
           self.capturing = False
-          self._end()
+          try:
+            self._end()
+          except Exception:  # noqa: BLE001
+            pass
+          raise
+        self.capturing = False
+        self._end()
       torch.cuda.current_stream(self.device).wait_stream(self.stream)
       if check:
         after = torch.cuda.memory_stats(self.device).get('allocation.all.allocated', 0)

@@ -546,7 +546,9 @@ int dd_imagine_rollout_oh_fwd(int N, int H, int t0, int t1, int D, int U, int G,
  * step is captured once and replayed.  Streams are created per role by the library (never a
  * handle of a shared pool); a graph executable lives until dd_graph_destroy, which is only
  * safe after a device synchronisation.  dd_graph_capture_end returns *exec_out = NULL for a
- * segment without nodes; dd_graph_launch(NULL, ..) is a no-op. */
+ * segment without nodes; dd_graph_launch(NULL, ..) is a no-op.  A segment may hold kernel launches
+ * (and the empty nodes of stream joins) only: dd_graph_capture_end fails on a memset / copy node
+ * unless DD_GRAPH_ALLOW_NONKERNEL=1 (then it reports them on stderr). */
 int dd_stream_create(void** stream_out);
 int dd_stream_destroy(void* stream);
 int dd_graph_capture_begin(void* stream);

@@ -175,3 +175,27 @@ def test_scan_error_word_is_sticky_and_raises(hip):
     with pytest.raises(RuntimeError, match='grid-barrier timeout'):
       ag.train(data, state)
     assert helpers.metrics_finite(ag.flush())
+
+
+def test_captured_segments_hold_kernel_launches_only():
+  """dd_graph_capture_end refuses a segment with a memset / copy node (runtime.hip): inside a
+  replayed graph such a node was not reliably complete before the kernel behind it when a second
+  process shared the GPU (the fused observe scan's barrier counters, docs/LABLOG.md end of
+  round 6).  A torch device-to-device `copy_` inside a captured function is such a node (hipMemcpyAsync);
+  kernels alone pass."""
+  from daydreamer_amd import graphs, hipops
+  ops = hipops.HipOps('cuda:0')
+  x = torch.ones(1024, device='cuda:0')
+  y = torch.zeros(1024, device='cuda:0')
+  ok = graphs.GraphPlan('cuda:0')
+  ok.capture(lambda: ops.fill(x, 2.0))
+  ok.replay()
+  torch.cuda.synchronize()
+  assert float(x.sum()) == 2048.0
+  bad = graphs.GraphPlan('cuda:0')
+  with pytest.raises(RuntimeError, match='not kernel launches'):
+    bad.capture(lambda: (ops.fill(x, 3.0), y.copy_(x)))
+  # the process is still usable afterwards
+  ok.replay()
+  torch.cuda.synchronize()
+  assert float(x.sum()) == 2048.0
