@@ -585,7 +585,8 @@ class HipOps:
     return bool(self.lib.dd_observe_scan_supported(B, D, U, G, C, A))
 
   def scan_wprep(self, W, planes, Kp):
-    """Weight cache of the fused scan: W [K, N] fp32 -> bf16 planes [3, N, Kp]."""
+    """Weight cache of the fused scan: W [K, N] fp32 -> three bf16 planes of N x Kp values in
+    fragment-major order (include/daydreamer_hip.h; N % 16 == 0, Kp % 128 == 0)."""
     K, N = W.shape
     assert W.stride(1) == 1 and planes.dtype == torch.int16 and planes.numel() == 3 * N * Kp
     self._check(self.lib.dd_scan_wprep(W.data_ptr(), W.stride(0), K, N, Kp, planes.data_ptr(),
@@ -611,7 +612,8 @@ class HipOps:
     return bool(self.lib.dd_observe_scan_bwd_supported(B, D, U, G, C))
 
   def scan_wprep_rows(self, W, planes):
-    """Weight cache of the fused reverse scan: W [N, K] fp32 -> bf16 planes [3, N, K]."""
+    """Weight cache of the fused reverse scan: W [N, K] fp32 -> three bf16 planes, fragment-major,
+    operand column n = row n of W (N % 16 == 0, K % 128 == 0)."""
     N, K = W.shape
     assert W.stride(1) == 1 and planes.dtype == torch.int16 and planes.numel() == 3 * N * K
     self._check(self.lib.dd_scan_wprep_rows(W.data_ptr(), W.stride(0), N, K, planes.data_ptr(),

@@ -1131,3 +1131,48 @@ def test_axpy_and_balance_stats(hip, ref):
     g, c = res[0]
     assert torch.equal(g.cpu()[4], c[4]) and torch.equal(g.cpu()[2:4], c[2:4])  # counts are exact
     close(g, c, rtol=1e-6, what=f'balance_stats kind {kind}')
+
+
+def test_scan_weight_planes_are_fragment_major(hip):
+  """dd_scan_wprep / dd_scan_wprep_rows (include/daydreamer_hip.h): three bf16 planes of the exact
+  3-way split of every weight, stored [column tile n/16][k-step k/128][plane][wave][lane] x 8 values
+  with lane = ((k % 32) / 8) * 16 + n % 16 - the order in which the scans' workgroups read their
+  MFMA B fragments (a wave's load = 1 KB contiguous).  Every element is checked against a numpy
+  restatement of the split and of the index; columns beyond K are zero."""
+  rng = np.random.RandomState(0)
+
+  def split3(x):
+    bits = x.view(np.uint32)
+    h = bits & 0xFFFF0000
+    r1 = x - h.view(np.float32)
+    m = r1.view(np.uint32) & 0xFFFF0000
+    lo = (r1 - m.view(np.float32)).view(np.uint32)
+    return (h >> 16).astype(np.uint16), (m >> 16).astype(np.uint16), (lo >> 16).astype(np.uint16)
+
+  def index(n, k, p, Kp):
+    tile, r, it, kk = n >> 4, n & 15, k >> 7, k & 127
+    w, q, e = kk >> 5, (kk & 31) >> 3, kk & 7
+    return ((((tile * (Kp >> 7) + it) * 3 + p) * 4 + w) * 64 + (q * 16 + r)) * 8 + e
+
+  for K, N, Kp in ((200, 48, 256), (384, 32, 384)):
+    W = (rng.randn(K, N) * np.exp(rng.randn(K, N) * 3)).astype(np.float32)
+    planes = torch.zeros(3 * N * Kp, dtype=torch.int16, device='cuda:0')
+    hip.scan_wprep(torch.from_numpy(W).cuda(), planes, Kp)
+    got = planes.cpu().numpy().view(np.uint16)
+    Wp = np.zeros((Kp, N), np.float32)
+    Wp[:K] = W
+    n, k = np.meshgrid(np.arange(N), np.arange(Kp))
+    for p, pl in enumerate(split3(Wp)):
+      assert np.array_equal(got[index(n, k, p, Kp)], pl), (K, N, p)
+    # the three planes add up to the weight exactly
+    parts = [(got[index(n, k, p, Kp)].astype(np.uint32) << 16).view(np.float32) for p in range(3)]
+    assert np.array_equal((parts[0] + parts[1]) + parts[2], Wp)
+  # the reverse scan's cache: column n of the operand = row n of W
+  Nr, Kr = 32, 256
+  W = rng.randn(Nr, Kr).astype(np.float32)
+  planes = torch.zeros(3 * Nr * Kr, dtype=torch.int16, device='cuda:0')
+  hip.scan_wprep_rows(torch.from_numpy(W).cuda(), planes)
+  got = planes.cpu().numpy().view(np.uint16)
+  k, n = np.meshgrid(np.arange(Kr), np.arange(Nr))
+  for p, pl in enumerate(split3(W)):
+    assert np.array_equal(got[index(n, k, p, Kr)], pl), p
