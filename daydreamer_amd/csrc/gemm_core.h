@@ -1570,10 +1570,10 @@ int run_mat(AL al, BL bl, int M, int N, int K, float* C, long ldc, const float* 
       (long)dd_ceil_div(M, 128) * dd_ceil_div(N, 64) < (K > 768 ? 128 : 512)) TMS = 64;
   {  // experimentation hook: DD_FORCE_TILE=128x128|128x64|64x64
     static const char* force = getenv("DD_FORCE_TILE");
-    if (force && M > 64) {
-      if (!strcmp(force, "128x128")) { TMS = 128; TNS = 128; }
-      else if (!strcmp(force, "128x64")) { TMS = 128; TNS = 64; }
-      else if (!strcmp(force, "64x64")) { TMS = 64; TNS = 64; }
+    if (force && (M > 64 || force[strlen(force) - 1] == '!')) {   // ("128x128!": also for few rows)
+      if (!strncmp(force, "128x128", 7)) { TMS = 128; TNS = 128; }
+      else if (!strncmp(force, "128x64", 6)) { TMS = 128; TNS = 64; }
+      else if (!strncmp(force, "64x64", 5)) { TMS = 64; TNS = 64; }
 #ifdef DD_EXP_BIG
       else if (!strcmp(force, "256x128") && gemm_mode() == 6 && M > 128 && N > 64) { TMS = 256; TNS = 128; }
 #endif

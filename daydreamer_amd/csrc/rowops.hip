@@ -579,21 +579,35 @@ __device__ __forceinline__ float4 f4_norm(float4 x, float mean, float rstd, floa
                      (x.z - mean) * rstd * g.z + b.z, (x.w - mean) * rstd * g.w + b.w);
 }
 
-template <int Q>
+// sum over the TPR threads that share a row: a wave (TPR = 64) or the whole workgroup (TPR = 256:
+// every thread of the block is in the same loop iteration, so the barriers are uniform)
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v, float* sh) {
+  v = wave_sum(v);
+  if constexpr (TPR == 64) return v;
+  __syncthreads();   // sh free (the previous sum's readers are done)
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <int Q, int TPR>
 __global__ void __launch_bounds__(256)
 k_gru_fwd_v(float* __restrict__ z3, long ldz, const float* __restrict__ gamma,
             const float* __restrict__ beta, const float* __restrict__ h, long ldh,
             float* __restrict__ hn, long ldn, float* __restrict__ stats, long lds, int rows,
             PreSum ps) {
-  constexpr int D = 256 * Q, C = 3 * D, V = 3 * Q;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
+  // TPR threads per row (64: a wave per row, D = 256 Q; 256: the workgroup per row, D = 1024 Q)
+  constexpr int D = 4 * TPR * Q, C = 3 * D, V = 3 * Q, RPB = 256 / TPR;
+  __shared__ float sh[4];
+  const int lane = threadIdx.x % TPR, wave = threadIdx.x / TPR;
+  for (long row = (long)blockIdx.x * RPB + wave; row < rows; row += (long)gridDim.x * RPB) {
     float* zr = z3 + row * ldz;
     float4 x[V];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const int c = 4 * (lane + 64 * i);
+      const int c = 4 * (lane + TPR * i);
       float4* zp = reinterpret_cast<float4*>(zr + c);
       if (ps.S) {
         x[i] = presum4(ps, row, c, ps.beta != 0.f ? *zp : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -603,17 +617,17 @@ k_gru_fwd_v(float* __restrict__ z3, long ldz, const float* __restrict__ gamma,
       }
       s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
     }
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = row_sum<TPR>(s, sh) / (float)C;
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float a = x[i].x - mean, b = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
       v += (a * a + b * b) + (c * c + d * d);
     }
-    const float rstd = rsqrtf(wave_sum(v) / (float)C + LN_EPS);
+    const float rstd = rsqrtf(row_sum<TPR>(v, sh) / (float)C + LN_EPS);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int j = 4 * (lane + 64 * q);
+      const int j = 4 * (lane + TPR * q);
       const float4 yr = f4_norm(x[q], mean, rstd, *reinterpret_cast<const float4*>(gamma + j),
                                 *reinterpret_cast<const float4*>(beta + j));
       const float4 yc = f4_norm(x[Q + q], mean, rstd, *reinterpret_cast<const float4*>(gamma + D + j),
@@ -632,24 +646,25 @@ k_gru_fwd_v(float* __restrict__ z3, long ldz, const float* __restrict__ gamma,
   }
 }
 
-template <int Q>
+template <int Q, int TPR>
 __global__ void __launch_bounds__(256)
 k_gru_bwd_v(const float* __restrict__ dhn, long lddn, const float* __restrict__ z3, long ldz,
             const float* __restrict__ stats, long lds, const float* __restrict__ gamma,
             const float* __restrict__ beta, const float* __restrict__ h, long ldh,
             float* __restrict__ dz3, long lddz, float* __restrict__ dh, long lddh,
             float* __restrict__ dy3, long lddy, float* __restrict__ zx, long ldzx, int U, int rows) {
-  constexpr int D = 256 * Q, C = 3 * D;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
+  constexpr int D = 4 * TPR * Q, C = 3 * D, RPB = 256 / TPR;
+  __shared__ float sh[4];
+  const int lane = threadIdx.x % TPR, wave = threadIdx.x / TPR;
+  for (long row = (long)blockIdx.x * RPB + wave; row < rows; row += (long)gridDim.x * RPB) {
     const float* zr = z3 + row * ldz;
     const float mean = stats[row * lds], rstd = stats[row * lds + 1];
-    if (zx) for (int j = 4 * lane; j < U; j += 256) *reinterpret_cast<float4*>(zx + row * ldzx + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zx) for (int j = 4 * lane; j < U; j += 4 * TPR) *reinterpret_cast<float4*>(zx + row * ldzx + j) = make_float4(0.f, 0.f, 0.f, 0.f);
     float xh[3][Q][4], gy[3][Q][4];   // normalised inputs, gamma * dy per gate (r, c, u)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int j = 4 * (lane + 64 * q);
+      const int j = 4 * (lane + TPR * q);
       float zz[3][4], gm[3][4], bt[3][4], hp[4], d[4], dyo[3][4], dho[4];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -679,11 +694,11 @@ k_gru_bwd_v(const float* __restrict__ dhn, long lddn, const float* __restrict__ 
       for (int p = 0; p < 3; ++p)
         *reinterpret_cast<float4*>(dy3 + row * lddy + p * D + j) = *reinterpret_cast<float4*>(dyo[p]);
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
+    s1 = row_sum<TPR>(s1, sh) / (float)C;
+    s2 = row_sum<TPR>(s2, sh) / (float)C;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int j = 4 * (lane + 64 * q);
+      const int j = 4 * (lane + TPR * q);
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         float o[4];
@@ -958,13 +973,18 @@ extern "C" int dd_gru_cell_fwd(float* z3, long ldz, const float* gamma, const fl
     n_slabs = 0;
   }
   PreSum ps{slabs, n_slabs, (long)rows * 3 * D, 3 * D, beta_pre, nullptr};
-  const bool vec = (D == 256 || D == 512 || D == 1024) && ldz % 4 == 0 && ldh % 4 == 0 && ldn % 4 == 0 &&
+  const bool vec = (D == 256 || D == 512 || D == 1024 || D == 2048 || D == 4096) && ldz % 4 == 0 && ldh % 4 == 0 && ldn % 4 == 0 &&
                    al16(z3) && al16(h) && al16(hn) && al16(gamma) && al16(beta) && al16(slabs);
   const int blocks = row_blocks(rows, 1 << 20);
   hipStream_t st = (hipStream_t)stream;
-  if (vec && D == 256) k_gru_fwd_v<1><<<blocks, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, ps);
-  else if (vec && D == 512) k_gru_fwd_v<2><<<blocks, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, ps);
-  else if (vec) k_gru_fwd_v<4><<<blocks, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, ps);
+  // (D >= 2048: the row lives in the registers of a whole workgroup - a1_scaled's deter 4096; the
+  // scalar kernel read such a row three times with 4-byte loads: 550 us for 2 048 rows, 0.5 TB/s)
+  const int blocks1 = rows < (1 << 20) ? rows : (1 << 20);
+  if (vec && D == 256) k_gru_fwd_v<1, 64><<<blocks, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, ps);
+  else if (vec && D == 512) k_gru_fwd_v<2, 64><<<blocks, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, ps);
+  else if (vec && D == 1024) k_gru_fwd_v<4, 64><<<blocks, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, ps);
+  else if (vec && D == 2048) k_gru_fwd_v<2, 256><<<blocks1, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, ps);
+  else if (vec) k_gru_fwd_v<4, 256><<<blocks1, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, ps);
   else k_gru_fwd<<<blocks, 256, 0, st>>>(z3, ldz, gamma, beta, h, ldh, hn, ldn, stats, lds, rows, D, ps);
   DD_CHECK_LAUNCH("dd_gru_cell_fwd");
   return 0;
@@ -976,14 +996,17 @@ extern "C" int dd_gru_cell_bwd(const float* dhn, long lddn, const float* z3, lon
                                float* dh, long lddh, float* dy3, long lddy,
                                float* zx, long ldzx, int U, int rows, int D, void* stream) {
   if (rows <= 0) return 0;
-  const bool vec = (D == 256 || D == 512 || D == 1024) && lddn % 4 == 0 && ldz % 4 == 0 && ldh % 4 == 0 &&
+  const bool vec = (D == 256 || D == 512 || D == 1024 || D == 2048 || D == 4096) && lddn % 4 == 0 && ldz % 4 == 0 && ldh % 4 == 0 &&
                    lddz % 4 == 0 && lddh % 4 == 0 && lddy % 4 == 0 && (zx == nullptr || (ldzx % 4 == 0 && U % 4 == 0 && al16(zx))) &&
                    al16(dhn) && al16(z3) && al16(h) && al16(dz3) && al16(dh) && al16(dy3) && al16(gamma) && al16(beta);
   const int blocks = row_blocks(rows, 1 << 20);
   hipStream_t st = (hipStream_t)stream;
-  if (vec && D == 256) k_gru_bwd_v<1><<<blocks, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows);
-  else if (vec && D == 512) k_gru_bwd_v<2><<<blocks, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows);
-  else if (vec) k_gru_bwd_v<4><<<blocks, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows);
+  const int blocks1 = rows < (1 << 20) ? rows : (1 << 20);   // (a workgroup per row: D >= 2048)
+  if (vec && D == 256) k_gru_bwd_v<1, 64><<<blocks, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows);
+  else if (vec && D == 512) k_gru_bwd_v<2, 64><<<blocks, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows);
+  else if (vec && D == 1024) k_gru_bwd_v<4, 64><<<blocks, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows);
+  else if (vec && D == 2048) k_gru_bwd_v<2, 256><<<blocks1, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows);
+  else if (vec) k_gru_bwd_v<4, 256><<<blocks1, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows);
   else k_gru_bwd<<<blocks, 256, 0, st>>>(dhn, lddn, z3, ldz, stats, lds, gamma, beta, h, ldh, dz3, lddz, dh, lddh, dy3, lddy, zx, ldzx, U, rows, D);
   DD_CHECK_LAUNCH("dd_gru_cell_bwd");
   return 0;

@@ -569,7 +569,7 @@ def test_ln_act_views(hip, ref):
   close(g, c, rtol=1e-5, what='ln views')
 
 
-@pytest.mark.parametrize('rows,D', [(50, 256), (2500, 256), (17, 64), (5, 1024), (9, 96), (33, 512)])
+@pytest.mark.parametrize('rows,D', [(50, 256), (2500, 256), (17, 64), (5, 1024), (9, 96), (33, 512), (37, 4096), (7, 2048)])
 def test_gru(hip, ref, rows, D):
   z3, gamma, beta = rnd(rows, 3 * D, seed=1, scale=2.0), 1 + 0.1 * rnd(3 * D, seed=2), 0.1 * rnd(3 * D, seed=3)
   h, hn, stats, dhn = rnd(rows, D, seed=4), torch.zeros(rows, D), torch.zeros(rows, 2), rnd(rows, D, seed=5)
